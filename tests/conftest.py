@@ -1,0 +1,45 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+def tree_spec(fixture):
+    """Decode the tree description stored in a fixture (topology, time, G, K)."""
+    d = json.loads(str(fixture["tree"]) if not isinstance(fixture, str) else fixture)
+    if d["int_labels"]:
+        d["time"] = {int(k): v for k, v in d["time"].items()}
+    return d
+
+
+def label_of(spec, text):
+    return int(text) if spec["int_labels"] else str(text)
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden
+
+
+def has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False

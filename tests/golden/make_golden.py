@@ -1,0 +1,275 @@
+#!/usr/bin/env python3
+"""
+Generate the golden vectors under tests/golden/ by importing the REAL reference.
+
+Runs only in the build container (needs /root/reference); the GPU box never
+sees the reference, only the .npz files this script wrote.  The reference
+publishes no tests or fixtures of its own, so these vectors are the
+pin for every parity claim.
+
+    PYTHONDONTWRITEBYTECODE=1 python3 tests/golden/make_golden.py
+
+Everything stored is data: inputs (seeds, topologies, parameters) and the
+reference's outputs.  No reference source text is stored.
+"""
+import json
+import os
+import sys
+import types
+import warnings
+
+REF = os.environ.get("PROSSTT_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.modules["newick"] = types.ModuleType("newick")   # only Tree.from_newick needs it
+warnings.filterwarnings("ignore")
+
+import numpy as np                                     # noqa: E402
+import scipy.stats                                     # noqa: E402
+from prosstt import tree as rtree                      # noqa: E402
+from prosstt import simulation as rsim                 # noqa: E402
+from prosstt import sim_utils as rsut                  # noqa: E402
+from prosstt import count_model as rcm                 # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+# The five topologies of SURVEY section 8(c) G3/G5 (+ an unequal-length one).
+TREES = {
+    "bifurcation": dict(topology=[["A", "B"], ["A", "C"]],
+                        time={"A": 40, "B": 40, "C": 40}, branch_points=1),
+    "chain6": dict(topology=[["A", "B"], ["B", "C"], ["C", "D"], ["D", "E"], ["E", "F"]],
+                   time={b: 30 for b in "ABCDEF"}, branch_points=0),
+    "chainbif7": dict(topology=[["A", "B"], ["B", "C"], ["B", "D"], ["D", "E"], ["C", "F"], ["F", "G"]],
+                      time={b: 50 for b in "ABCDEFG"}, branch_points=1),
+    "star5": dict(topology=[[0, 1], [0, 2], [0, 3], [0, 4], [0, 5]],
+                  time={b: 20 for b in range(6)}, branch_points=1),
+    "unequal": dict(topology=[["A", "B"], ["A", "C"], ["C", "D"], ["C", "E"]],
+                    time={"A": 70, "B": 100, "C": 60, "D": 25, "E": 33}, branch_points=2),
+}
+
+
+def build_tree(spec, G, modules):
+    return rtree.Tree(topology=spec["topology"], time=spec["time"],
+                      num_branches=len(spec["time"]), branch_points=spec["branch_points"],
+                      modules=modules, G=G)
+
+
+def tree_json(spec, G, modules, extra=None):
+    d = dict(topology=spec["topology"], time={str(k): int(v) for k, v in spec["time"].items()},
+             int_labels=isinstance(next(iter(spec["time"])), int),
+             branch_points=spec["branch_points"], G=G, modules=modules)
+    d.update(extra or {})
+    return json.dumps(d)
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("%-28s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+# --------------------------------------------------------------------- G1
+def g1_get_pr_umi():
+    m = np.concatenate([10.0 ** np.arange(-7, 5), [0.5, 1.5, 3.0, 12.0, 16.0, 250.0]])
+    a = np.array([0.0, 1e-4, 0.05, 0.2, 1.0, 3.0])
+    b = np.array([1.0 + 1e-8, 1.3, 2.0, 3.0, 8.0])
+    A, B, M = [x.reshape(-1) for x in np.meshgrid(a, b, m, indexing="ij")]
+    p, r = rcm.get_pr_umi(A, B, M)
+    save("g1_get_pr_umi", a=A, b=B, m=M, p=p, r=r)
+
+
+# --------------------------------------------------------------------- G2
+def g2_walks():
+    out = {}
+    for seed in (0, 1, 92):
+        for T in (2, 40, 50):
+            np.random.seed(seed)
+            out["diffusion_s%d_T%d" % (seed, T)] = rsim.diffusion(T)
+    np.random.seed(7)
+    out["sim_expr_branch_s7_T50_K5"] = rsim.sim_expr_branch(50, 5)
+    save("g2_walks", **out)
+
+
+# --------------------------------------------------------------------- G3
+def g3_lineage():
+    for name, spec in TREES.items():
+        for mode, kwargs in (("gamma", dict(a=0.05)), ("beta", dict(a=2, b=2))):
+            if mode == "beta" and name not in ("bifurcation", "star5"):
+                continue
+            G, K, seed = 64, 5, 1000 + len(name)
+            np.random.seed(seed)
+            t = build_tree(spec, G, K)
+            log = []
+            orig_pearson = rsut.pearson_between_programs
+            orig_branch = rsim.sim_expr_branch
+
+            def spy_pearson(genes, p1, p2):
+                r = orig_pearson(genes, p1, p2)
+                log[-1][1].append(int(np.sum(r < 0)))
+                return r
+
+            def spy_branch(*a, **k):
+                log.append([None, []])
+                return orig_branch(*a, **k)
+
+            rsut.pearson_between_programs = spy_pearson
+            rsim.sim_expr_branch = spy_branch
+            try:
+                rel, prog, H = rsim.simulate_lineage(t, intra_branch_tol=0, **kwargs)
+            finally:
+                rsut.pearson_between_programs = orig_pearson
+                rsim.sim_expr_branch = orig_branch
+            state_after = np.random.random_sample()      # pins total RNG consumption
+            arrays = dict(tree=tree_json(spec, G, K, dict(seed=seed, kwargs=kwargs)),
+                          H=H, attempts=len(log), state_after=state_after,
+                          anticorr=np.array([json.dumps(c[1]) for c in log]),
+                          bfs=np.array([str(b) for b in rsut.breadth_first_branches(t)]))
+            for b in t.branches:
+                arrays["rel_%s" % b] = rel[b]
+                arrays["prog_%s" % b] = prog[b]
+            save("g3_lineage_%s_%s" % (name, mode), **arrays)
+
+
+# --------------------------------------------------------------------- G4
+def g4_params():
+    spec = TREES["bifurcation"]
+    np.random.seed(11)
+    t = build_tree(spec, 200, 6)
+    rel, _, _ = rsim.simulate_lineage(t, a=0.05, intra_branch_tol=0)
+    np.random.seed(12)
+    base = rsut.simulate_base_gene_exp(t, rel)
+    np.random.seed(13)
+    al, be = rcm.generate_negbin_params(t, mean_alpha=0.2, mean_beta=3)
+    np.random.seed(14)
+    sc = rsut.calc_scalings(300, True, 0.1, 0.7)
+    sc_off = rsut.calc_scalings(5, False)
+    arrays = dict(tree=tree_json(spec, 200, 6), base=base, alpha=al, beta=be,
+                  scalings=sc, scalings_off=sc_off)
+    for b in t.branches:
+        arrays["rel_%s" % b] = rel[b]
+    save("g4_params", **arrays)
+
+
+# --------------------------------------------------------------------- G5
+def g5_topology():
+    out = {}
+    for name, spec in TREES.items():
+        t = build_tree(spec, 10, 3)
+        bt = t.branch_times()
+        zones = t.populate_timezone()
+        rec = dict(
+            branch_times={str(k): [int(x) for x in v] for k, v in bt.items()},
+            timezone=[[int(x) for x in z] for z in zones],
+            assign={str(i): [str(b) for b in v] for i, v in rsut.assign_branches(bt, zones).items()},
+            bfs=[str(b) for b in rsut.breadth_first_branches(t)],
+            parallel={str(k): [str(x) for x in v] for k, v in t.get_parallel_branches().items()},
+            max_time=int(t.get_max_time()),
+            density_sum=float(sum(np.sum(v) for v in t.density.values())),
+            cover=[[int(x) for x in rsim.cover_whole_tree(t)[0]],
+                   [str(x) for x in rsim.cover_whole_tree(t)[1]]],
+        )
+        out[name] = json.dumps(rec)
+        out[name + "_tree"] = tree_json(spec, 10, 3)
+    np.random.seed(5)
+    out["random_topology_bp4_seed5"] = np.array(rtree.Tree.gen_random_topology(4))
+    np.random.seed(2024)
+    out["random_topology_bp3_seed2024"] = np.array(rtree.Tree.gen_random_topology(3))
+    save("g5_topology", **out)
+
+
+# --------------------------------------------------------------------- G6
+def g6_sampling():
+    for name, N, G, K in (("bifurcation", 60, 48, 5), ("unequal", 80, 40, 4), ("star5", 50, 32, 4)):
+        spec = TREES[name]
+        seed = 300 + N
+        np.random.seed(seed)
+        t = build_tree(spec, G, K)
+        rel, prog, H = rsim.simulate_lineage(t, a=0.05, intra_branch_tol=0)
+        base = rsut.simulate_base_gene_exp(t, rel)
+        t.add_genes(rel, base)
+        alpha = np.exp(np.random.normal(np.log(0.2), np.log(1.5), G))
+        beta = np.exp(np.random.normal(np.log(1), np.log(1.5), G)) + 1
+        np.random.seed(seed + 1)
+        X, pt, br, sc = rsim.sample_density(t, N, alpha=alpha, beta=beta)
+        # deterministic intermediates of draw_counts (simulation.py:633-645)
+        bt = t.branch_times()
+        mu = np.array([t.means[b][p - bt[b][0]] * s for p, b, s in zip(pt, br, sc)])
+        pr = [rcm.get_pr_umi(alpha, beta, row) for row in mu]
+        arrays = dict(tree=tree_json(spec, G, K, dict(seed=seed)), base=base, H=H,
+                      alpha=alpha, beta=beta, X=X, pt=pt, br=np.array([str(b) for b in br]),
+                      scalings=sc, mu=mu, p=np.array([x[0] for x in pr]),
+                      r=np.array([x[1] for x in pr]))
+        for b in t.branches:
+            arrays["means_%s" % b] = t.means[b]
+            arrays["rel_%s" % b] = rel[b]
+        # the other samplers, same tree, fresh seeds
+        np.random.seed(seed + 2)
+        X2, pt2, br2, sc2 = rsim.sample_whole_tree(t, 2, alpha=alpha, beta=beta)
+        arrays.update(wt_X=X2, wt_pt=np.array(pt2), wt_br=np.array([str(b) for b in br2]), wt_sc=sc2)
+        np.random.seed(seed + 3)
+        times = np.arange(0, t.get_max_time(), 3)
+        X3, pt3, br3, sc3 = rsim._sample_data_at_times(t, times, alpha=alpha, beta=beta)
+        arrays.update(at_X=X3, at_pt=pt3, at_br=np.array([str(b) for b in br3]), at_sc=sc3)
+        np.random.seed(seed + 4)
+        X4, pt4, br4, sc4 = rsim.sample_pseudotime_series(
+            t, 30, [5, 30, 60], 6.0, alpha=0.3, beta=2)
+        arrays.update(ps_X=X4, ps_pt=pt4, ps_br=np.array([str(b) for b in br4]), ps_sc=sc4)
+        np.random.seed(seed + 5)
+        gp = dict(alpha=alpha[:7], beta=beta[:7], base_expr=base[:7])
+        arrays.update(nd_X=rsim.add_non_diff_genes(X, 7, gp, sc))
+        save("g6_sampling_%s" % name, **arrays)
+
+
+# --------------------------------------------------------------------- G7
+def g7_nb_tables():
+    """Analytic NB law for a grid of (m, a, b): pmf[0..kmax], mean, variance
+    (scipy.stats.nbinom with the reference's parametrisation n=r, p=1-p)."""
+    grid = [(0.05, 0.2, 2.0), (0.5, 0.2, 2.0), (1.5, 0.15, 2.2), (1.5, 1e-4, 1.5), (4.0, 0.3, 3.0),
+            (9.0, 0.2, 2.0), (11.9, 1.0, 1.3), (12.1, 0.2, 2.0), (30.0, 0.2, 2.0), (30.0, 2.0, 2.0),
+            (100.0, 0.05, 1.5), (100.0, 1.2, 4.0), (400.0, 0.2, 2.0), (3000.0, 0.25, 2.0),
+            (3.0, 5.0, 2.0), (20.0, 0.0, 1.0 + 1e-8), (0.7, 0.0, 1.0 + 1e-8), (2.0, 0.0, 7.0),
+            (8.0, 3.0, 1.0), (50.0, 1e-4, 1.2)]
+    kmax = 4096
+    k = np.arange(kmax)
+    pmf = np.zeros((len(grid), kmax))
+    par = np.zeros((len(grid), 7))
+    for i, (m, a, b) in enumerate(grid):
+        p, r = rcm.get_pr_umi(np.array([a]), np.array([b]), np.array([m]))
+        d = scipy.stats.nbinom(n=r[0], p=1 - p[0])
+        pmf[i] = d.pmf(k)
+        par[i] = (m, a, b, r[0], p[0], d.mean(), d.var())
+    save("g7_nb_tables", params=par, pmf=pmf.astype(np.float64))
+
+
+# --------------------------------------------------------------------- G8
+def g8_end_to_end():
+    np.random.seed(92)
+    t = rtree.Tree()
+    X, pt, br, sc = rsim.sample_whole_tree_restricted(t)
+    save("g8_minimal_example", X=X, pt=pt, br=np.array([str(b) for b in br]), scalings=sc,
+         modules=t.modules, total=int(X.sum()))
+    # config C1 of BASELINE.json: 5-branch chain x 40 steps, sample_whole_tree(t, 1) -> 200 x 500
+    spec = dict(topology=[["A", "B"], ["B", "C"], ["C", "D"], ["D", "E"]],
+                time={b: 40 for b in "ABCDE"}, branch_points=0)
+    np.random.seed(92)
+    t = build_tree(spec, 500, 15)
+    rel, _, H = rsim.simulate_lineage(t, a=0.05, intra_branch_tol=0)
+    base = rsut.simulate_base_gene_exp(t, rel)
+    t.add_genes(rel, base)
+    alpha, beta = rcm.generate_negbin_params(t)
+    np.random.seed(93)
+    X, pt, br, sc = rsim.sample_whole_tree(t, 1, alpha=alpha, beta=beta)
+    save("g8_config1_chain", tree=tree_json(spec, 500, 15), X=X.astype(np.int32), pt=np.array(pt),
+         br=np.array([str(b) for b in br]), scalings=sc, alpha=alpha, beta=beta, base=base,
+         H=H.astype(np.float64), rel_E=rel["E"], total=int(X.sum()))
+
+
+if __name__ == "__main__":
+    g1_get_pr_umi()
+    g2_walks()
+    g3_lineage()
+    g4_params()
+    g5_topology()
+    g6_sampling()
+    g7_nb_tables()
+    g8_end_to_end()
