@@ -1,0 +1,129 @@
+/*
+ * prosstt_amd -- C ABI of the MI355X-native PROSSTT hot path (libprosstt_amd.so).
+ *
+ * The reference (soedinglab/prosstt v1.2.0) is pure Python and has no FFI or
+ * plugin interface; its boundary is a set of Python call signatures.  Each entry
+ * point below replaces the numeric body of the reference functions it cites
+ * (file:line under prosstt/), and is what a ctypes stub inside those functions
+ * would bind (INTEGRATION.md shows the stubs).
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes; never throws, never calls back.
+ *  - return 0 on success, a negative PROSSTT_AMD_E* code otherwise; the message
+ *    is in the thread-local prosstt_amd_last_error().
+ *  - One ctx per (device, stream).  Calls on one ctx are serialised by the caller.
+ *    All work is enqueued on the ctx's HIP stream; entry points that hand results
+ *    back through HOST pointers synchronise that stream before returning.
+ *  - Array arguments are DEVICE pointers unless a flag or the comment says host.
+ *  - Results are a pure function of (inputs, seed, cell_offset): independent of
+ *    launch geometry, chunking over cells and the number of GPUs.
+ */
+#ifndef PROSSTT_AMD_H
+#define PROSSTT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PROSSTT_AMD_VERSION 100 /* 0.1.0 */
+
+enum {
+    PROSSTT_AMD_OK = 0,
+    PROSSTT_AMD_EINVAL = -1,  /* bad argument */
+    PROSSTT_AMD_EDOMAIN = -2, /* a mean <= 0 or a*m+b < 1 (the reference raises ValueError there) */
+    PROSSTT_AMD_EHIP = -3,    /* HIP runtime error */
+    PROSSTT_AMD_ENOMEM = -4,
+    PROSSTT_AMD_ENODEV = -5   /* no gfx950 device visible */
+};
+
+/* flags of prosstt_amd_sample_counts / prosstt_amd_nb_params */
+#define PROSSTT_AMD_HOST_INPUTS  1u /* every input array is a host pointer (staged by the library) */
+#define PROSSTT_AMD_HOST_OUTPUT  2u /* every output array is a host pointer */
+#define PROSSTT_AMD_CHECK_DOMAIN 4u /* synchronise and return EDOMAIN like scipy's argument check */
+#define PROSSTT_AMD_TIME_KERNEL  8u /* bracket the main kernel with HIP events (last_kernel_ms) */
+
+typedef struct prosstt_amd_ctx prosstt_amd_ctx;
+
+int prosstt_amd_version(void);
+const char* prosstt_amd_last_error(void);
+int prosstt_amd_device_count(int* count);
+
+/* stream: a hipStream_t owned by the caller (e.g. torch's current stream); NULL is
+ * the device's default stream.  The ctx never creates or destroys a stream. */
+int prosstt_amd_ctx_create(int device, void* stream, prosstt_amd_ctx** out);
+int prosstt_amd_ctx_destroy(prosstt_amd_ctx* ctx);
+int prosstt_amd_ctx_synchronize(prosstt_amd_ctx* ctx);
+/* elapsed ms of the last kernel launched with PROSSTT_AMD_TIME_KERNEL (synchronises on it) */
+int prosstt_amd_last_kernel_ms(prosstt_amd_ctx* ctx, float* ms);
+
+/*
+ * Fused count sampler.  Replaces the body of
+ *   simulation.draw_counts                      simulation.py:602-651
+ *   count_model.get_pr_umi (per cell)           count_model.py:131-161
+ *   scipy.stats.nbinom(n=r, p=1-p).rvs()        simulation.py:647-648
+ * out[n*ld_out + g] ~ NB(mean m, variance alpha*m^2 + beta*m),
+ *   m = means[row_of_cell[n]*G + g] * scaling[n],
+ * drawn by the PRNB-1 counter-based sampler keyed by
+ * (seed, cell_offset + n, g).
+ *   means        [rows][G] binary32, row-major: the (branch, time, gene) mean tensor
+ *   row_of_cell  [N] row of every cell = row offset of its branch + time inside the branch
+ *   scaling      [N] library-size factor (sim_utils.calc_scalings, sim_utils.py:473-498)
+ *   alpha, beta  [G] variance hyper-parameters
+ *   out          [N][ld_out] int32 counts (the reference returns int64)
+ */
+int prosstt_amd_sample_counts(prosstt_amd_ctx* ctx, const float* means, int64_t rows, int32_t G,
+                              const int32_t* row_of_cell, const double* scaling,
+                              const double* alpha, const double* beta, int64_t N, uint64_t seed,
+                              uint64_t cell_offset, int32_t* out, int64_t ld_out, uint32_t flags);
+
+/*
+ * The deterministic intermediates of the same path (simulation.py:633-645,
+ * count_model.py:156-158), as the sampler forms them:  mu = m,  p = theta/(1+theta),
+ * r = m/theta  with theta = alpha*m + beta - 1;  path = 0 degenerate / 1 inversion /
+ * 2 gamma-Poisson.  Each [N][G]; any output pointer may be NULL.
+ */
+int prosstt_amd_nb_params(prosstt_amd_ctx* ctx, const float* means, int64_t rows, int32_t G,
+                          const int32_t* row_of_cell, const double* scaling, const double* alpha,
+                          const double* beta, int64_t N, float* mu, float* p, float* r,
+                          int32_t* path, uint32_t flags);
+
+/*
+ * One attempt of the accept/reject loop of simulation.simulate_lineage
+ * (simulation.py:264-282) for one branch, without materialising (T,G):
+ *   rel = programs @ H                                   simulation.py:269
+ *   *out_max = max(rel)                                  simulation.py:270
+ *   out_anticorr[j] = #genes with Pearson r < 0 between rel and sibling j's
+ *     rel over the first min(T, sib_T[j]) steps          sim_utils.py:145-168, 249-250
+ *   programs      HOST [T][K] (already adjusted to the parent, sim_utils.py:611-640)
+ *   H             DEVICE [K][G] coefficients (simulation.py:192-212)
+ *   sib_programs  HOST array of n_sib HOST pointers, each [sib_T[j]][K]
+ *   out_max, out_anticorr  HOST
+ */
+int prosstt_amd_lineage_attempt(prosstt_amd_ctx* ctx, const double* programs, int32_t T, int32_t K,
+                                const double* H, int64_t G, int32_t n_sib,
+                                const double* const* sib_programs, const int32_t* sib_T,
+                                double* out_max, int64_t* out_anticorr);
+
+/*
+ * Materialise an accepted branch: rel_out[t][g] = sum_k programs[t][k]*H[k][g]
+ * (binary64; simulation.py:269) and fold max_t rel into gene_max[g] (the log of
+ * sim_utils.max_relat_exp, sim_utils.py:406-426).
+ *   programs HOST [T][K];  H, rel_out ([T][G], may be NULL), gene_max ([G], may be NULL) DEVICE.
+ *   gene_max must be initialised to -inf by the caller before the first branch.
+ */
+int prosstt_amd_lineage_commit(prosstt_amd_ctx* ctx, const double* programs, int32_t T, int32_t K,
+                               const double* H, int64_t G, double* rel_out, double* gene_max);
+
+/*
+ * Tree.add_genes (tree.py:166-183): means[row][g] = exp(rel[row][g]) * base[g],
+ * evaluated in binary64 and stored as binary32.  All DEVICE; rows = sum of T_b.
+ */
+int prosstt_amd_means_from_rel(prosstt_amd_ctx* ctx, const double* rel, const double* base,
+                               int64_t rows, int64_t G, float* means_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PROSSTT_AMD_H */

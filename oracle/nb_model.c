@@ -1,0 +1,394 @@
+/*
+ * ORACLE -- test infrastructure only.  NOT part of the product path.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library; prosstt_amd never does.
+ *
+ * Scalar C model of the *device* count sampler ("PRNB-1"): the
+ * fused  gather * scale -> get_pr_umi -> negative-binomial draw  that replaces
+ *   simulation.draw_counts           /root/reference/prosstt/simulation.py:602-651
+ *   count_model.get_pr_umi           /root/reference/prosstt/count_model.py:131-161
+ *   scipy.stats.nbinom(n=r,p=1-p).rvs() = RandomState.negative_binomial  (simulation.py:647-648)
+ *
+ * The reference draws from numpy's sequential MT19937 stream, which no
+ * parallel device can reproduce (SURVEY.md section 0 "RNG reality check"); the count
+ * law, not the stream, is the contract.  PRNB-1 is a counter-based sampler of
+ * the SAME law  NB(n = r, p = 1-p)  with  theta = a*m + b - 1,  r = m/theta,
+ * p = theta/(1+theta)  (the algebraic form of get_pr_umi), defined so that
+ * every sample is a pure function of (M, s, a, b, seed, cell, gene):
+ *   - randomness: Philox4x32-10 (Salmon et al. 2011), key = seed,
+ *     counter = (cell_lo, cell_hi, gene-or-quad, domain);
+ *   - arithmetic: IEEE binary32 add/mul/fma/sqrt only, plus the polynomial
+ *     log/exp/cos and the Newton reciprocal below -- no libm, no hardware
+ *     approximations -- so this C model and the HIP kernel agree BIT FOR BIT.
+ * The law itself is pinned on the CPU against scipy/numpy (tests/test_nb_model.py,
+ * fixture g7) and the kernel is pinned against this model (tests/test_gpu_*.py).
+ *
+ * Build: see oracle/Makefile  (-O2 -ffp-contract=off; never -ffast-math).
+ */
+#include <stdint.h>
+#include <string.h>
+#include <math.h>
+
+#define PRNB_EXPORT __attribute__((visibility("default")))
+#if defined(__x86_64__)
+#define PRNB_CLONES __attribute__((target_clones("avx2,fma", "default")))
+#else
+#define PRNB_CLONES
+#endif
+
+/* ---- sampler constants (part of the PRNB-1 definition) ------------------ */
+#define PRNB_LIGHT_M      12.0f        /* light path iff m <= 12 and theta <= 16 */
+#define PRNB_LIGHT_THETA  16.0f
+#define PRNB_THETA_MIN    8.6736174e-19f /* 2^-60: below this NB == Poisson in binary32 */
+#define PRNB_THETA_MAX    1.0e18f
+#define PRNB_R_MIN        9.094947e-13f  /* 2^-40: P(X>0) < 2^-32, return 0 */
+#define PRNB_KTAB         1024         /* 1/k table size */
+#define PRNB_POIS_INV     10.0f        /* Poisson: inversion below, PTRS above */
+#define PRNB_LAM_BIG      4194304.0f   /* 2^22: rounded normal above */
+#define PRNB_MAX_TRIES    64
+
+static inline uint32_t f2u(float x) { uint32_t u; memcpy(&u, &x, 4); return u; }
+static inline float u2f(uint32_t u) { float x; memcpy(&x, &u, 4); return x; }
+#define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+
+/* ---- Philox4x32-10 -------------------------------------------------------- */
+static inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                 uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+    for (int round = 0; round < 10; ++round) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* ---- deterministic binary32 math ----------------------------------------- */
+
+/* 1/x for normal x>0: integer seed + 3 Newton steps (rel. err < 2^-23). */
+static inline float det_rcp(float x)
+{
+    float y = u2f(0x7EF311C7u - f2u(x));
+    float e = FMA(-x, y, 1.0f); y = FMA(y, e, y);
+    e = FMA(-x, y, 1.0f); y = FMA(y, e, y);
+    e = FMA(-x, y, 1.0f); y = FMA(y, e, y);
+    return y;
+}
+
+/* log(1+f) - f + f*f/2  =  f^3 * P(f)  on  f in [sqrt(1/2)-1, sqrt(2)-1]  (Cephes logf) */
+static inline float log_tail(float f)
+{
+    float p = 7.0376836292e-2f;
+    p = FMA(p, f, -1.1514610310e-1f);
+    p = FMA(p, f, 1.1676998740e-1f);
+    p = FMA(p, f, -1.2420140846e-1f);
+    p = FMA(p, f, 1.4249322787e-1f);
+    p = FMA(p, f, -1.6668057665e-1f);
+    p = FMA(p, f, 2.0000714765e-1f);
+    p = FMA(p, f, -2.4999993993e-1f);
+    p = FMA(p, f, 3.3333331174e-1f);
+    return p * f * (f * f);
+}
+
+/* log(x + c) for normal x>0 and a small correction c (|c| <= ulp(x)). */
+static inline float det_log_c(float x, float c)
+{
+    uint32_t ix = f2u(x);
+    int32_t e = (int32_t)(ix - 0x3F3504F3u) >> 23;           /* x = 2^e * mant, mant in [0.7071, 1.4142) */
+    float mant = u2f(ix - ((uint32_t)e << 23));
+    float scale = u2f((uint32_t)(127 - e) << 23);            /* 2^-e */
+    float f = (mant - 1.0f) + c * scale;
+    float fe = (float)e;
+    float y = log_tail(f);
+    y = FMA(fe, -2.12194440e-4f, y);
+    y = FMA(-0.5f, f * f, y);
+    return FMA(fe, 0.693359375f, f + y);
+}
+static inline float det_log(float x) { return det_log_c(x, 0.0f); }
+
+/* log(1+t), t >= 0 : exact two-sum of 1+t, residual folded into the mantissa. */
+static inline float det_log1p(float t)
+{
+    float u = 1.0f + t;
+    float c = (t >= 1.0f) ? (1.0f - (u - t)) : (t - (u - 1.0f));
+    return det_log_c(u, c);
+}
+
+/* log(1+d) - d for d > -1, without cancellation near 0. */
+static inline float det_log1pmx(float d, float rho /* = 1+d computed by the caller */)
+{
+    if (d >= -0.29289323f && d < 0.41421354f)
+        return FMA(-0.5f, d * d, log_tail(d));
+    return det_log(rho) - d;
+}
+
+/* exp(x) for x <= 0 (Cephes expf); 0 below -87. */
+static inline float det_exp(float x)
+{
+    if (!(x > -87.0f)) return 0.0f;
+    float z = floorf(FMA(x, 1.44269504088896341f, 0.5f));
+    float r = FMA(z, -0.693359375f, x);
+    r = FMA(z, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = FMA(p, r, 1.3981999507e-3f);
+    p = FMA(p, r, 8.3334519073e-3f);
+    p = FMA(p, r, 4.1665795894e-2f);
+    p = FMA(p, r, 1.6666665459e-1f);
+    p = FMA(p, r, 5.0000001201e-1f);
+    float y = FMA(p, r * r, r) + 1.0f;
+    return y * u2f((uint32_t)((int32_t)z + 127) << 23);
+}
+
+/* cos(2*pi*w/2^32): octant from the top 3 bits, Cephes sinf/cosf kernels. */
+static inline float det_cos2pi(uint32_t w)
+{
+    uint32_t j = w >> 29;
+    float f = (float)(w & 0x1FFFFFFFu) * 1.862645149230957e-9f;   /* 2^-29 */
+    if (j & 1u) f = f - 1.0f;
+    uint32_t q = ((j + 1u) >> 1) & 3u;
+    float y = f * 0.78539816339744830962f;
+    float z = y * y;
+    float s = FMA(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    s = FMA(s, z, -1.6666654611e-1f);
+    s = FMA(s * z, y, y);
+    float c = FMA(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    c = FMA(c, z, 4.166664568298827e-2f);
+    c = FMA(c * z, z, FMA(-0.5f, z, 1.0f));
+    float v = (q & 1u) ? s : c;
+    return (q == 1u || q == 2u) ? -v : v;
+}
+
+/* uniform in (0,1] from 32 bits, full resolution near 0 */
+static inline float unif(uint32_t w) { return ((float)w + 0.5f) * 2.3283064365386963e-10f; }
+
+static float g_inv_k[PRNB_KTAB];       /* 1/k, correctly rounded */
+static const float LOGFACT[10] = {0.0f, 0.0f, 0.69314718f, 1.7917595f, 3.1780538f, 4.7874917f,
+                                  6.5792512f, 8.5251614f, 10.604603f, 12.801827f};
+
+__attribute__((constructor)) static void prnb_init(void)
+{
+    g_inv_k[0] = 0.0f;
+    for (int k = 1; k < PRNB_KTAB; ++k) g_inv_k[k] = 1.0f / (float)k;
+}
+
+/*
+ * Inversion by chop-down in 0.32 fixed point.  pmf recurrence
+ *   P(k) = P(k-1) * (mp + (k-1)*q) / k      (NB: mp = m/(1+theta), q = theta/(1+theta);
+ *                                            Poisson: mp = lambda, q = 0)
+ * `w` is the 32-bit uniform.  If the pmf falls below 2^-32 before w is used up
+ * (mass lost to rounding, < 1e-6) the draw falls back to floor(mean).
+ */
+static inline int32_t chop_down(uint32_t w, float p0, float mp, float q, float mean)
+{
+    float p = fminf(p0, 0.99999994f);
+    uint32_t rem = w;
+    float kf = 0.0f;
+    for (int k = 0; ; ) {
+        uint32_t pf = (uint32_t)(p * 4294967296.0f);
+        if (rem < pf) return k;
+        if (pf == 0u || k == PRNB_KTAB - 1) return (int32_t)mean;
+        rem -= pf;
+        float num = FMA(kf, q, mp);
+        ++k; kf += 1.0f;
+        p = (p * num) * g_inv_k[k];
+    }
+}
+
+/* Poisson(lam) on counter domain 0x80000000+j of (cell, gene). */
+static inline int32_t poisson_draw(float lam, uint32_t c0, uint32_t c1, uint32_t gene,
+                                   uint32_t k0, uint32_t k1)
+{
+    uint32_t w[4];
+    if (!(lam > 0.0f)) return 0;
+    if (lam < PRNB_POIS_INV) {
+        philox4x32_10(c0, c1, gene, 0x80000000u, k0, k1, w);
+        return chop_down(w[0], det_exp(-lam), lam, 0.0f, lam);
+    }
+    float slam = sqrtf(lam);
+    if (!(lam < PRNB_LAM_BIG)) {               /* rounded normal; never reached with abs_max=5000 */
+        philox4x32_10(c0, c1, gene, 0x80000000u, k0, k1, w);
+        float z = sqrtf(-2.0f * det_log(unif(w[0]))) * det_cos2pi(w[1]);
+        float kf = floorf(FMA(slam, z, lam) + 0.5f);
+        return (int32_t)fminf(fmaxf(kf, 0.0f), 2147483520.0f);
+    }
+    /* PTRS, Hoermann 1993 (the algorithm behind numpy's random_poisson for lam >= 10) */
+    float bb = FMA(2.53f, slam, 0.931f);
+    float aa = FMA(0.02483f, bb, -0.059f);
+    float invalpha = FMA(1.1328f, det_rcp(bb - 3.4f), 1.1239f);
+    float vr = FMA(-3.6224f, det_rcp(bb - 2.0f), 0.9277f);
+    float kf = floorf(lam);
+    for (int j = 0; j < 2 * PRNB_MAX_TRIES; ++j) {
+        if ((j & 1) == 0) philox4x32_10(c0, c1, gene, 0x80000000u + (uint32_t)(j >> 1), k0, k1, w);
+        float U = unif(w[(j & 1) * 2]) - 0.5f;
+        float V = unif(w[(j & 1) * 2 + 1]);
+        float us = fmaxf(0.5f - fabsf(U), 5.8207661e-11f);       /* 2^-34 */
+        float rus = det_rcp(us);
+        kf = floorf(FMA(FMA(2.0f * aa, rus, bb), U, lam + 0.43f));
+        if (us >= 0.07f && V <= vr) break;
+        if (kf < 0.0f || (us < 0.013f && V > us)) { kf = floorf(lam); continue; }
+        float lhs = det_log((V * invalpha) * det_rcp(FMA(aa * rus, rus, bb)));
+        float rhs;
+        if (kf < 10.0f) {
+            rhs = FMA(kf, det_log(lam), -lam) - LOGFACT[(int)kf];
+        } else {
+            float rk = det_rcp(kf);
+            float d = (lam - kf) * rk;
+            float lp = det_log1pmx(d, lam * rk);
+            float st = rk * FMA(-0.0027777778f, rk * rk, 0.083333336f);
+            rhs = FMA(kf, lp, FMA(-0.5f, det_log(6.2831855f * kf), -st));
+        }
+        if (lhs <= rhs) break;
+        kf = floorf(lam);
+    }
+    return (int32_t)fminf(fmaxf(kf, 0.0f), 2147483520.0f);
+}
+
+/* Gamma(r) * theta on counter domain 1+i of (cell, gene): Marsaglia-Tsang 2000,
+ * Box-Muller normal, U^(1/r) boost below r = 1. */
+static inline float gamma_scaled(float r, float theta, uint32_t c0, uint32_t c1, uint32_t gene,
+                                 uint32_t k0, uint32_t k1)
+{
+    uint32_t w[4];
+    int boost = r < 1.0f;
+    float rr = boost ? r + 1.0f : r;
+    float dd = rr - 0.33333334f;
+    float cc = det_rcp(3.0f * sqrtf(dd));
+    float v = 1.0f;
+    for (int i = 0; i < PRNB_MAX_TRIES; ++i) {
+        philox4x32_10(c0, c1, gene, 1u + (uint32_t)i, k0, k1, w);
+        float x = sqrtf(-2.0f * det_log(unif(w[0]))) * det_cos2pi(w[1]);
+        float t = cc * x;
+        float v1 = 1.0f + t;
+        if (!(v1 > 0.0f)) continue;
+        v = v1 * v1 * v1;
+        float u = unif(w[2]);
+        float x2 = x * x;
+        if (u < FMA(-0.0331f, x2 * x2, 1.0f)) break;
+        /* log u < x^2/2 + d*(1 - v + log v),  1 - v + log v = 3*log1pmx(t) - 3t^2 - t^3 */
+        float t2 = t * t;
+        float h = FMA(3.0f, det_log1pmx(t, v1), FMA(-t2, t, -3.0f * t2));
+        if (det_log(u) < FMA(dd, h, 0.5f * x2)) break;
+    }
+    float g = dd * v;
+    if (boost) g = g * det_exp(det_log(unif(w[3])) * det_rcp(r));
+    return theta * g;
+}
+
+typedef struct { float m, theta, p, r; int32_t path; } prnb_detail;
+
+/* One count.  path: 0 = degenerate (returns 0), 1 = light NB inversion, 2 = gamma-Poisson. */
+static inline int32_t prnb_one(float M, float s, float a, float bm1, uint32_t k0, uint32_t k1,
+                               uint64_t cell, uint32_t gene, prnb_detail* det)
+{
+    float m = M * s;
+    float theta = FMA(a, m, bm1);
+    uint32_t c0 = (uint32_t)cell, c1 = (uint32_t)(cell >> 32);
+    if (det) { det->m = m; det->theta = theta; det->p = 0.0f; det->r = 0.0f; det->path = 0; }
+    if (!(m > 0.0f) || !(theta > 0.0f)) return 0;
+    theta = fminf(fmaxf(theta, PRNB_THETA_MIN), PRNB_THETA_MAX);
+    float u1 = 1.0f + theta;
+    float d = det_rcp(theta * u1);
+    float inv_th = d * u1, inv_u1 = d * theta;
+    float q = theta * inv_u1;
+    float r = m * inv_th;
+    if (det) { det->p = q; det->r = r; }
+    if (m <= PRNB_LIGHT_M && theta <= PRNB_LIGHT_THETA) {
+        uint32_t w[4];
+        if (det) det->path = 1;
+        philox4x32_10(c0, c1, gene >> 2, 0u, k0, k1, w);
+        float t = m * (det_log1p(theta) * inv_th);
+        return chop_down(w[gene & 3u], det_exp(-t), m * inv_u1, q, m);
+    }
+    if (det) det->path = 2;
+    if (!(r >= PRNB_R_MIN)) return 0;
+    float lam = gamma_scaled(r, theta, c0, c1, gene, k0, k1);
+    return poisson_draw(lam, c0, c1, gene, k0, k1);
+}
+
+/* ---- exported entry points (ctypes) --------------------------------------- */
+
+/* Per-gene parameters reach the sampler as binary32:  a = (float)alpha  and
+ * bm1 = (float)(beta - 1.0)  with the subtraction in binary64 -- the reference's
+ * own examples use beta = 1 + 1e-8 (examples/linear.ipynb), which binary32 beta
+ * cannot hold.  Scalings are rounded to binary32. */
+#define GENE_A(alpha, g)   ((float)(alpha)[g])
+#define GENE_BM1(beta, g)  ((float)((beta)[g] - 1.0))
+
+PRNB_EXPORT void prnb_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
+}
+
+/* elementwise math probes: which = 0 rcp, 1 log, 2 log1p, 3 exp, 4 cos2pi(bits of x), 5 unif(bits) */
+PRNB_EXPORT PRNB_CLONES void prnb_math(int which, const float* x, float* y, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        switch (which) {
+        case 0: y[i] = det_rcp(x[i]); break;
+        case 1: y[i] = det_log(x[i]); break;
+        case 2: y[i] = det_log1p(x[i]); break;
+        case 3: y[i] = det_exp(x[i]); break;
+        case 4: y[i] = det_cos2pi(f2u(x[i])); break;
+        case 5: y[i] = unif(f2u(x[i])); break;
+        case 6: y[i] = det_log1pmx(x[i], 1.0f + x[i]); break;
+        default: y[i] = 0.0f;
+        }
+    }
+}
+
+/*
+ * Same signature as the product's prosstt_amd_sample_counts (include/prosstt_amd.h)
+ * minus flags/stream: counts[n*ld + g] for cell n (global index cell_offset+n), gene g.
+ */
+PRNB_EXPORT PRNB_CLONES void prnb_sample_counts(const float* means, int64_t rows, int32_t G,
+                                                const int32_t* row_of_cell, const double* scaling,
+                                                const double* alpha, const double* beta, int64_t N,
+                                                uint64_t seed, uint64_t cell_offset,
+                                                int32_t* out, int64_t ld)
+{
+    (void)rows;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < N; ++n) {
+        const float* mrow = means + (int64_t)row_of_cell[n] * G;
+        float s = (float)scaling[n];
+        for (int32_t g = 0; g < G; ++g)
+            out[n * ld + g] = prnb_one(mrow[g], s, GENE_A(alpha, g), GENE_BM1(beta, g), k0, k1,
+                                       cell_offset + (uint64_t)n, (uint32_t)g, 0);
+    }
+}
+
+/* Deterministic intermediates (mu, p, r) exactly as the kernel forms them, plus the path taken. */
+PRNB_EXPORT PRNB_CLONES void prnb_nb_params(const float* means, int64_t rows, int32_t G,
+                                            const int32_t* row_of_cell, const double* scaling,
+                                            const double* alpha, const double* beta, int64_t N,
+                                            float* mu, float* p, float* r, int32_t* path)
+{
+    (void)rows;
+    for (int64_t n = 0; n < N; ++n) {
+        const float* mrow = means + (int64_t)row_of_cell[n] * G;
+        for (int32_t g = 0; g < G; ++g) {
+            prnb_detail d;
+            prnb_one(mrow[g], (float)scaling[n], GENE_A(alpha, g), GENE_BM1(beta, g), 0u, 0u, 0u,
+                     (uint32_t)g, &d);
+            mu[n * (int64_t)G + g] = d.m; p[n * (int64_t)G + g] = d.p; r[n * (int64_t)G + g] = d.r;
+            if (path) path[n * (int64_t)G + g] = d.path;
+        }
+    }
+}
+
+/* n draws from one parameter set (law tests): cell = first_cell + i, gene fixed. */
+PRNB_EXPORT PRNB_CLONES void prnb_sample_iid(float m, double a, double b, uint64_t seed,
+                                             uint64_t first_cell, uint32_t gene, int64_t n,
+                                             int32_t* out)
+{
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i)
+        out[i] = prnb_one(m, 1.0f, (float)a, (float)(b - 1.0), k0, k1, first_cell + (uint64_t)i, gene, 0);
+}

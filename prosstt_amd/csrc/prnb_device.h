@@ -1,0 +1,303 @@
+// PRNB-1 count sampler, device side (gfx950).  DESIGN.md section 4 defines it; this is
+// the product implementation.  Replaces, per (cell, gene):
+//   count_model.get_pr_umi                 /root/reference/prosstt/count_model.py:131-161
+//   scipy.stats.nbinom(n=r,p=1-p).rvs()    /root/reference/prosstt/simulation.py:647-648
+//
+// Every arithmetic step is an IEEE binary32 add / mul / fma / sqrt or an integer
+// op, so results do not depend on the hardware's approximate v_rcp/v_log/v_exp:
+// the translation unit is compiled with -ffp-contract=off and every fused
+// multiply-add below is spelled out.  (Quarter-rate transcendentals would be
+// cheaper per call, but a sampler whose integer output can be checked bit for
+// bit against a scalar model is worth the extra VALU work.)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace prnb {
+
+constexpr float kLightM = 12.0f;       // light path iff m <= 12 and theta <= 16
+constexpr float kLightTheta = 16.0f;
+constexpr float kThetaMin = 8.6736174e-19f;  // 2^-60
+constexpr float kThetaMax = 1.0e18f;
+constexpr float kRMin = 9.094947e-13f;       // 2^-40
+constexpr int kKTab = 1024;                  // entries of the 1/k table
+constexpr float kPoisInv = 10.0f;
+constexpr float kLamBig = 4194304.0f;        // 2^22
+constexpr int kMaxTries = 64;
+
+#define PRNB_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+
+__device__ __forceinline__ uint32_t f2u(float x) { return __float_as_uint(x); }
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+
+struct Words { uint32_t w[4]; };
+
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw 2011)
+__device__ __forceinline__ Words philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                               uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int round = 0; round < 10; ++round) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    Words r;
+    r.w[0] = c0; r.w[1] = c1; r.w[2] = c2; r.w[3] = c3;
+    return r;
+}
+
+// 1/x, x > 0 normal: integer seed (5 % error) + 3 Newton steps
+__device__ __forceinline__ float det_rcp(float x)
+{
+    float y = u2f(0x7EF311C7u - f2u(x));
+    float e = PRNB_FMA(-x, y, 1.0f); y = PRNB_FMA(y, e, y);
+    e = PRNB_FMA(-x, y, 1.0f); y = PRNB_FMA(y, e, y);
+    e = PRNB_FMA(-x, y, 1.0f); y = PRNB_FMA(y, e, y);
+    return y;
+}
+
+// log(1+f) - f + f^2/2 on [sqrt(1/2)-1, sqrt(2)-1]
+__device__ __forceinline__ float log_tail(float f)
+{
+    float p = 7.0376836292e-2f;
+    p = PRNB_FMA(p, f, -1.1514610310e-1f);
+    p = PRNB_FMA(p, f, 1.1676998740e-1f);
+    p = PRNB_FMA(p, f, -1.2420140846e-1f);
+    p = PRNB_FMA(p, f, 1.4249322787e-1f);
+    p = PRNB_FMA(p, f, -1.6668057665e-1f);
+    p = PRNB_FMA(p, f, 2.0000714765e-1f);
+    p = PRNB_FMA(p, f, -2.4999993993e-1f);
+    p = PRNB_FMA(p, f, 3.3333331174e-1f);
+    return (p * f) * (f * f);
+}
+
+__device__ __forceinline__ float det_log_c(float x, float c)
+{
+    const uint32_t ix = f2u(x);
+    const int32_t e = (int32_t)(ix - 0x3F3504F3u) >> 23;
+    const float mant = u2f(ix - ((uint32_t)e << 23));
+    const float scale = u2f((uint32_t)(127 - e) << 23);
+    const float f = (mant - 1.0f) + c * scale;
+    const float fe = (float)e;
+    float y = log_tail(f);
+    y = PRNB_FMA(fe, -2.12194440e-4f, y);
+    y = PRNB_FMA(-0.5f, f * f, y);
+    return PRNB_FMA(fe, 0.693359375f, f + y);
+}
+__device__ __forceinline__ float det_log(float x) { return det_log_c(x, 0.0f); }
+
+__device__ __forceinline__ float det_log1p(float t)
+{
+    const float u = 1.0f + t;
+    const float c = (t >= 1.0f) ? (1.0f - (u - t)) : (t - (u - 1.0f));
+    return det_log_c(u, c);
+}
+
+__device__ __forceinline__ float det_log1pmx(float d, float rho)
+{
+    if (d >= -0.29289323f && d < 0.41421354f)
+        return PRNB_FMA(-0.5f, d * d, log_tail(d));
+    return det_log(rho) - d;
+}
+
+__device__ __forceinline__ float det_exp(float x)
+{
+    if (!(x > -87.0f)) return 0.0f;
+    const float z = __builtin_floorf(PRNB_FMA(x, 1.44269504088896341f, 0.5f));
+    float r = PRNB_FMA(z, -0.693359375f, x);
+    r = PRNB_FMA(z, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = PRNB_FMA(p, r, 1.3981999507e-3f);
+    p = PRNB_FMA(p, r, 8.3334519073e-3f);
+    p = PRNB_FMA(p, r, 4.1665795894e-2f);
+    p = PRNB_FMA(p, r, 1.6666665459e-1f);
+    p = PRNB_FMA(p, r, 5.0000001201e-1f);
+    const float y = PRNB_FMA(p, r * r, r) + 1.0f;
+    return y * u2f((uint32_t)((int32_t)z + 127) << 23);
+}
+
+__device__ __forceinline__ float det_cos2pi(uint32_t w)
+{
+    const uint32_t j = w >> 29;
+    float f = (float)(w & 0x1FFFFFFFu) * 1.862645149230957e-9f;
+    if (j & 1u) f = f - 1.0f;
+    const uint32_t q = ((j + 1u) >> 1) & 3u;
+    const float y = f * 0.78539816339744830962f;
+    const float z = y * y;
+    float s = PRNB_FMA(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    s = PRNB_FMA(s, z, -1.6666654611e-1f);
+    s = PRNB_FMA(s * z, y, y);
+    float c = PRNB_FMA(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    c = PRNB_FMA(c, z, 4.166664568298827e-2f);
+    c = PRNB_FMA(c * z, z, PRNB_FMA(-0.5f, z, 1.0f));
+    const float v = (q & 1u) ? s : c;
+    return (q == 1u || q == 2u) ? -v : v;
+}
+
+__device__ __forceinline__ float unif(uint32_t w) { return ((float)w + 0.5f) * 2.3283064365386963e-10f; }
+
+__device__ __forceinline__ float det_sqrt(float x) { return __builtin_sqrtf(x); }  // IEEE (see Makefile)
+
+// Inversion by chop-down in 0.32 fixed point; inv_k = LDS table of 1/k.
+__device__ __forceinline__ int32_t chop_down(uint32_t w, float p0, float mp, float q, float mean,
+                                             const float* inv_k)
+{
+    float p = __builtin_fminf(p0, 0.99999994f);
+    uint32_t rem = w;
+    float kf = 0.0f;
+    int k = 0;
+    for (;;) {
+        const uint32_t pf = (uint32_t)(p * 4294967296.0f);
+        if (rem < pf) return k;
+        if (pf == 0u || k == kKTab - 1) return (int32_t)mean;
+        rem -= pf;
+        const float num = PRNB_FMA(kf, q, mp);
+        ++k;
+        kf += 1.0f;
+        p = (p * num) * inv_k[k];
+    }
+}
+
+__device__ __forceinline__ float logfact_small(int k)
+{
+    // log(k!) for k < 10, binary32-rounded
+    switch (k) {
+    case 0: case 1: return 0.0f;
+    case 2: return 0.69314718f;
+    case 3: return 1.7917595f;
+    case 4: return 3.1780538f;
+    case 5: return 4.7874917f;
+    case 6: return 6.5792512f;
+    case 7: return 8.5251614f;
+    case 8: return 10.604603f;
+    default: return 12.801827f;
+    }
+}
+
+__device__ __noinline__ int32_t poisson_draw(float lam, uint32_t c0, uint32_t c1, uint32_t gene,
+                                             uint32_t k0, uint32_t k1, const float* inv_k)
+{
+    if (!(lam > 0.0f)) return 0;
+    if (lam < kPoisInv) {
+        const Words w = philox4x32_10(c0, c1, gene, 0x80000000u, k0, k1);
+        return chop_down(w.w[0], det_exp(-lam), lam, 0.0f, lam, inv_k);
+    }
+    const float slam = det_sqrt(lam);
+    if (!(lam < kLamBig)) {
+        const Words w = philox4x32_10(c0, c1, gene, 0x80000000u, k0, k1);
+        const float z = det_sqrt(-2.0f * det_log(unif(w.w[0]))) * det_cos2pi(w.w[1]);
+        const float kf = __builtin_floorf(PRNB_FMA(slam, z, lam) + 0.5f);
+        return (int32_t)__builtin_fminf(__builtin_fmaxf(kf, 0.0f), 2147483520.0f);
+    }
+    // PTRS (Hoermann 1993)
+    const float bb = PRNB_FMA(2.53f, slam, 0.931f);
+    const float aa = PRNB_FMA(0.02483f, bb, -0.059f);
+    const float invalpha = PRNB_FMA(1.1328f, det_rcp(bb - 3.4f), 1.1239f);
+    const float vr = PRNB_FMA(-3.6224f, det_rcp(bb - 2.0f), 0.9277f);
+    float kf = __builtin_floorf(lam);
+    Words w;
+    for (int j = 0; j < 2 * kMaxTries; ++j) {
+        if ((j & 1) == 0) w = philox4x32_10(c0, c1, gene, 0x80000000u + (uint32_t)(j >> 1), k0, k1);
+        const uint32_t wu = (j & 1) ? w.w[2] : w.w[0];
+        const uint32_t wv = (j & 1) ? w.w[3] : w.w[1];
+        const float U = unif(wu) - 0.5f;
+        const float V = unif(wv);
+        const float us = __builtin_fmaxf(0.5f - __builtin_fabsf(U), 5.8207661e-11f);
+        const float rus = det_rcp(us);
+        kf = __builtin_floorf(PRNB_FMA(PRNB_FMA(2.0f * aa, rus, bb), U, lam + 0.43f));
+        if (us >= 0.07f && V <= vr) break;
+        if (kf < 0.0f || (us < 0.013f && V > us)) { kf = __builtin_floorf(lam); continue; }
+        const float lhs = det_log((V * invalpha) * det_rcp(PRNB_FMA(aa * rus, rus, bb)));
+        float rhs;
+        if (kf < 10.0f) {
+            rhs = PRNB_FMA(kf, det_log(lam), -lam) - logfact_small((int)kf);
+        } else {
+            const float rk = det_rcp(kf);
+            const float d = (lam - kf) * rk;
+            const float lp = det_log1pmx(d, lam * rk);
+            const float st = rk * PRNB_FMA(-0.0027777778f, rk * rk, 0.083333336f);
+            rhs = PRNB_FMA(kf, lp, PRNB_FMA(-0.5f, det_log(6.2831855f * kf), -st));
+        }
+        if (lhs <= rhs) break;
+        kf = __builtin_floorf(lam);
+    }
+    return (int32_t)__builtin_fminf(__builtin_fmaxf(kf, 0.0f), 2147483520.0f);
+}
+
+__device__ __noinline__ float gamma_scaled(float r, float theta, uint32_t c0, uint32_t c1,
+                                           uint32_t gene, uint32_t k0, uint32_t k1)
+{
+    const bool boost = r < 1.0f;
+    const float rr = boost ? r + 1.0f : r;
+    const float dd = rr - 0.33333334f;
+    const float cc = det_rcp(3.0f * det_sqrt(dd));
+    float v = 1.0f;
+    Words w;
+    for (int i = 0; i < kMaxTries; ++i) {
+        w = philox4x32_10(c0, c1, gene, 1u + (uint32_t)i, k0, k1);
+        const float x = det_sqrt(-2.0f * det_log(unif(w.w[0]))) * det_cos2pi(w.w[1]);
+        const float t = cc * x;
+        const float v1 = 1.0f + t;
+        if (!(v1 > 0.0f)) continue;
+        v = (v1 * v1) * v1;
+        const float u = unif(w.w[2]);
+        const float x2 = x * x;
+        if (u < PRNB_FMA(-0.0331f, x2 * x2, 1.0f)) break;
+        const float t2 = t * t;
+        const float h = PRNB_FMA(3.0f, det_log1pmx(t, v1), PRNB_FMA(-t2, t, -3.0f * t2));
+        if (det_log(u) < PRNB_FMA(dd, h, 0.5f * x2)) break;
+    }
+    float g = dd * v;
+    if (boost) g = g * det_exp(det_log(unif(w.w[3])) * det_rcp(r));
+    return theta * g;
+}
+
+// Per-sample parameters shared by the light and heavy paths.
+struct Params {
+    float m, theta, inv_th, inv_u1;
+    bool valid;   // m > 0 and theta > 0
+    bool light;
+};
+
+__device__ __forceinline__ Params make_params(float M, float s, float a, float bm1)
+{
+    Params P;
+    P.m = M * s;
+    float theta = PRNB_FMA(a, P.m, bm1);
+    P.valid = (P.m > 0.0f) && (theta > 0.0f);
+    theta = __builtin_fminf(__builtin_fmaxf(theta, kThetaMin), kThetaMax);
+    const float u1 = 1.0f + theta;
+    const float d = det_rcp(theta * u1);
+    P.theta = theta;
+    P.inv_th = d * u1;
+    P.inv_u1 = d * theta;
+    P.light = (P.m <= kLightM) && (theta <= kLightTheta);
+    return P;
+}
+
+// Light path: NB inversion with one 32-bit uniform.
+__device__ __forceinline__ int32_t light_draw(const Params& P, uint32_t w, const float* inv_k)
+{
+    const float q = P.theta * P.inv_u1;
+    const float t = P.m * (det_log1p(P.theta) * P.inv_th);
+    return chop_down(w, det_exp(-t), P.m * P.inv_u1, q, P.m, inv_k);
+}
+
+// Heavy path: Poisson(theta * Gamma(r)).
+__device__ __forceinline__ int32_t heavy_draw(const Params& P, uint32_t c0, uint32_t c1,
+                                              uint32_t gene, uint32_t k0, uint32_t k1,
+                                              const float* inv_k)
+{
+    const float r = P.m * P.inv_th;
+    if (!(r >= kRMin)) return 0;
+    const float lam = gamma_scaled(r, P.theta, c0, c1, gene, k0, k1);
+    return poisson_draw(lam, c0, c1, gene, k0, k1, inv_k);
+}
+
+}  // namespace prnb

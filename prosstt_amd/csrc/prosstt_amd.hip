@@ -1,0 +1,629 @@
+// libprosstt_amd.so -- HIP kernels (gfx950) and the C ABI of include/prosstt_amd.h.
+//
+// Kernels
+//   prep_params_kernel      binary64 scaling/alpha/beta -> binary32 sampler parameters
+//   sample_counts_kernel    K3: fused gather * scale -> get_pr_umi -> NB draw
+//                           (simulation.py:602-651, count_model.py:131-161)
+//   nb_params_kernel        the deterministic intermediates of the same path
+//   lineage_attempt_kernel  K2a: max(programs@H) and per-sibling anticorrelated-gene
+//                           counts without materialising (T,G)   (simulation.py:269-272)
+//   lineage_commit_kernel   K2b: rel = programs@H in binary64 + per-gene max
+//   means_from_rel_kernel   Tree.add_genes: exp(rel)*base -> binary32 mean tensor (tree.py:181-182)
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <vector>
+
+#include "../../include/prosstt_amd.h"
+#include "prnb_device.h"
+
+#define PA_EXPORT extern "C" __attribute__((visibility("default")))
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(e_ == hipErrorOutOfMemory ? PROSSTT_AMD_ENOMEM : PROSSTT_AMD_EHIP,     \
+                        "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);   \
+    } while (0)
+
+// ------------------------------------------------------------------ context
+struct prosstt_amd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    void* ws = nullptr;          // grow-only device workspace
+    size_t ws_bytes = 0;
+    int64_t* scratch = nullptr;  // device: [0] domain flag, [1] max bits, [2..] counters
+    int64_t* h_scratch = nullptr;  // pinned mirror
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+};
+constexpr int kScratchWords = 64;
+
+static int ws_reserve(prosstt_amd_ctx* c, size_t bytes)
+{
+    if (bytes <= c->ws_bytes) return 0;
+    if (c->ws) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipFree(c->ws));
+        c->ws = nullptr;
+        c->ws_bytes = 0;
+    }
+    bytes = (bytes + (1u << 20)) & ~((size_t)(1u << 20) - 1);
+    HIP_TRY(hipMalloc(&c->ws, bytes));
+    c->ws_bytes = bytes;
+    return 0;
+}
+
+// Temporary device copies of host arrays (PROSSTT_AMD_HOST_INPUTS / _OUTPUT).
+struct Staging {
+    std::vector<void*> bufs;
+    ~Staging() { for (void* p : bufs) (void)hipFree(p); }
+    int alloc(void** p, size_t bytes)
+    {
+        HIP_TRY(hipMalloc(p, bytes ? bytes : 1));
+        bufs.push_back(*p);
+        return 0;
+    }
+    int upload(const void* host, size_t bytes, const void** dev, hipStream_t s)
+    {
+        void* p = nullptr;
+        int rc = alloc(&p, bytes);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(p, host, bytes, hipMemcpyHostToDevice, s));
+        *dev = p;
+        return 0;
+    }
+};
+
+// ------------------------------------------------------------------ kernels
+
+__global__ void prep_params_kernel(const double* __restrict__ scaling, int64_t N,
+                                   const double* __restrict__ alpha,
+                                   const double* __restrict__ beta, int32_t G,
+                                   float* __restrict__ scal_f, float* __restrict__ a_f,
+                                   float* __restrict__ bm1_f)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) scal_f[i] = (float)scaling[i];
+    if (i < G) {
+        a_f[i] = (float)alpha[i];
+        bm1_f[i] = (float)(beta[i] - 1.0);   // binary64 subtraction: beta = 1 + 1e-8 must survive
+    }
+}
+
+constexpr int kTileG = 256;   // genes per tile = 64 lanes x 4
+constexpr int kTileC = 16;    // cells per tile = 4 waves x 4 steps
+constexpr int kBlock = 256;
+
+// One block = one (cell tile, gene tile).  A wave owns one cell per step and its 64
+// lanes own 4 consecutive genes each, so every global access is a 1 KiB contiguous
+// row segment.  Samples whose parameters need the gamma-Poisson path are queued in
+// LDS and handled afterwards by all 256 threads (compaction instead of divergence);
+// the tile is staged in LDS so that both paths land in one coalesced store.
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void sample_counts_kernel(
+    const float* __restrict__ means, int32_t G, const int32_t* __restrict__ row_of_cell,
+    const float* __restrict__ scal, const float* __restrict__ ga, const float* __restrict__ gbm1,
+    int64_t N, uint32_t k0, uint32_t k1, uint64_t cell_offset, int32_t* __restrict__ out,
+    int64_t ld, int64_t* __restrict__ domain_flag, int32_t tiles_c)
+{
+    __shared__ float inv_k[prnb::kKTab];
+    __shared__ int32_t tile[kTileC][kTileG];
+    __shared__ uint16_t queue[kTileC * kTileG];
+    __shared__ int q_count;
+
+    const int tid = threadIdx.x;
+    const int ql = tid & 63, wv = tid >> 6;
+    const int32_t tile_g = blockIdx.x / tiles_c;
+    const int32_t tile_c = blockIdx.x - tile_g * tiles_c;
+    const int32_t g0 = tile_g * kTileG + ql * 4;
+    const int64_t n0 = (int64_t)tile_c * kTileC;
+
+    for (int k = tid; k < prnb::kKTab; k += kBlock) inv_k[k] = k ? 1.0f / (float)k : 0.0f;
+    if (tid == 0) q_count = 0;
+    __syncthreads();
+
+    float a[4], bm1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool in = g0 + j < G;
+        a[j] = in ? ga[g0 + j] : 0.0f;
+        bm1[j] = in ? gbm1[g0 + j] : 0.0f;
+    }
+
+    bool bad = false;
+#pragma unroll 1
+    for (int step = 0; step < kTileC / 4; ++step) {
+        const int cl = step * 4 + wv;
+        const int64_t n = n0 + cl;
+        if (n >= N || g0 >= G) continue;
+        const int64_t row = row_of_cell[n];
+        const float s = scal[n];
+        const uint64_t cell = cell_offset + (uint64_t)n;
+        const uint32_t c0 = (uint32_t)cell, c1 = (uint32_t)(cell >> 32);
+        float M[4];
+        if (VEC) {
+            const float4 v = *reinterpret_cast<const float4*>(means + row * G + g0);
+            M[0] = v.x; M[1] = v.y; M[2] = v.z; M[3] = v.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) M[j] = (g0 + j < G) ? means[row * G + g0 + j] : 0.0f;
+        }
+        const prnb::Words W = prnb::philox4x32_10(c0, c1, (uint32_t)g0 >> 2, 0u, k0, k1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int32_t res = 0;
+            if (g0 + j < G) {
+                const prnb::Params P = prnb::make_params(M[j], s, a[j], bm1[j]);
+                if (!P.valid) {
+                    bad = bad || !(P.m > 0.0f) || (__builtin_fmaf(a[j], P.m, bm1[j]) < 0.0f);
+                } else if (P.light) {
+                    res = prnb::light_draw(P, W.w[j], inv_k);
+                } else {
+                    const int slot = atomicAdd(&q_count, 1);
+                    queue[slot] = (uint16_t)(cl * kTileG + ql * 4 + j);
+                }
+            }
+            tile[cl][ql * 4 + j] = res;
+        }
+    }
+    __syncthreads();
+
+    const int qn = q_count;
+    for (int e = tid; e < qn; e += kBlock) {
+        const int idx = queue[e];
+        const int cl = idx >> 8, gl = idx & (kTileG - 1);
+        const int64_t n = n0 + cl;
+        const int32_t g = tile_g * kTileG + gl;
+        const uint64_t cell = cell_offset + (uint64_t)n;
+        const prnb::Params P =
+            prnb::make_params(means[(int64_t)row_of_cell[n] * G + g], scal[n], ga[g], gbm1[g]);
+        tile[cl][gl] = prnb::heavy_draw(P, (uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)g, k0,
+                                        k1, inv_k);
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int step = 0; step < kTileC / 4; ++step) {
+        const int cl = step * 4 + wv;
+        const int64_t n = n0 + cl;
+        if (n >= N || g0 >= G) continue;
+        int32_t* dst = out + n * ld + g0;
+        if (VEC) {
+            *reinterpret_cast<int4*>(dst) = *reinterpret_cast<const int4*>(&tile[cl][ql * 4]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (g0 + j < G) dst[j] = tile[cl][ql * 4 + j];
+        }
+    }
+    if (bad) *domain_flag = 1;
+}
+
+__global__ void nb_params_kernel(const float* __restrict__ means, int32_t G,
+                                 const int32_t* __restrict__ row_of_cell,
+                                 const float* __restrict__ scal, const float* __restrict__ ga,
+                                 const float* __restrict__ gbm1, int64_t N, float* __restrict__ mu,
+                                 float* __restrict__ p, float* __restrict__ r,
+                                 int32_t* __restrict__ path)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * G) return;
+    const int64_t n = i / G;
+    const int32_t g = (int32_t)(i - n * G);
+    const prnb::Params P =
+        prnb::make_params(means[(int64_t)row_of_cell[n] * G + g], scal[n], ga[g], gbm1[g]);
+    if (mu) mu[i] = P.m;
+    if (p) p[i] = P.valid ? P.theta * P.inv_u1 : 0.0f;
+    if (r) r[i] = P.valid ? P.m * P.inv_th : 0.0f;
+    if (path) path[i] = !P.valid ? 0 : (P.light ? 1 : 2);
+}
+
+// order-preserving map double -> uint64 so that max() can be an integer atomic
+__device__ __forceinline__ unsigned long long ordered_bits(double x)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+static double from_ordered_bits(unsigned long long o)
+{
+    const unsigned long long b = (o >> 63) ? (o & 0x7fffffffffffffffull) : ~o;
+    double d;
+    memcpy(&d, &b, 8);
+    return d;
+}
+
+// progs: [0] current programs raw [T][K]; then for each sibling j two blocks, both
+// truncated to common_j = min(T, T_j) steps and centred over them:
+// current [common_j][K], sibling [common_j][K].   meta: n_sib, then common_j.
+// Thread = gene.  x_t = sum_k P[t][k] H[k][g]; all program reads are wave-uniform.
+__global__ __launch_bounds__(256) void lineage_attempt_kernel(
+    const double* __restrict__ progs, const int32_t* __restrict__ meta, int32_t T, int32_t K,
+    const double* __restrict__ H, int64_t G, unsigned long long* __restrict__ max_bits,
+    unsigned long long* __restrict__ anticorr)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = g < G;
+    const double* h = H + (live ? g : 0);
+    const int n_sib = meta[0];
+
+    double mx = -std::numeric_limits<double>::infinity();
+    for (int t = 0; t < T; ++t) {
+        double acc = 0.0;
+        for (int k = 0; k < K; ++k) acc = fma(progs[t * K + k], h[(int64_t)k * G], acc);
+        mx = fmax(mx, acc);
+    }
+    if (!live) mx = -std::numeric_limits<double>::infinity();
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(max_bits, ordered_bits(mx));
+
+    const double* blk = progs + (int64_t)T * K;
+    for (int j = 0; j < n_sib; ++j) {
+        const int common = meta[1 + j];
+        const double* pc = blk;
+        const double* ps = blk + (int64_t)common * K;
+        blk += 2 * (int64_t)common * K;
+        double cov = 0.0, vx = 0.0, vy = 0.0;
+        for (int t = 0; t < common; ++t) {
+            double x = 0.0, y = 0.0;
+            for (int k = 0; k < K; ++k) {
+                const double hk = h[(int64_t)k * G];
+                x = fma(pc[t * K + k], hk, x);
+                y = fma(ps[t * K + k], hk, y);
+            }
+            cov = fma(x, y, cov);
+            vx = fma(x, x, vx);
+            vy = fma(y, y, vy);
+        }
+        // Pearson r < 0  <=>  cov < 0 with both series non-constant (scipy returns NaN otherwise)
+        const bool neg = live && cov < 0.0 && vx > 0.0 && vy > 0.0;
+        const unsigned long long votes = __ballot(neg);
+        if ((threadIdx.x & 63) == 0 && votes) atomicAdd(&anticorr[j], (unsigned long long)__popcll(votes));
+    }
+}
+
+__global__ __launch_bounds__(256) void lineage_commit_kernel(const double* __restrict__ progs,
+                                                             int32_t T, int32_t K,
+                                                             const double* __restrict__ H, int64_t G,
+                                                             double* __restrict__ rel_out,
+                                                             double* __restrict__ gene_max)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const double* h = H + g;
+    double mx = gene_max ? gene_max[g] : 0.0;
+    for (int t = 0; t < T; ++t) {
+        double acc = 0.0;
+        for (int k = 0; k < K; ++k) acc = fma(progs[t * K + k], h[(int64_t)k * G], acc);
+        if (rel_out) rel_out[(int64_t)t * G + g] = acc;
+        mx = fmax(mx, acc);
+    }
+    if (gene_max) gene_max[g] = mx;
+}
+
+__global__ __launch_bounds__(256) void means_from_rel_kernel(const double* __restrict__ rel,
+                                                             const double* __restrict__ base,
+                                                             int64_t rows, int64_t G,
+                                                             float* __restrict__ out)
+{
+    const int64_t total = rows * G;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t g = i % G;
+        out[i] = (float)(exp(rel[i]) * base[g]);
+    }
+}
+
+// ------------------------------------------------------------------ ABI
+
+PA_EXPORT int prosstt_amd_version(void) { return PROSSTT_AMD_VERSION; }
+PA_EXPORT const char* prosstt_amd_last_error(void) { return g_err; }
+
+PA_EXPORT int prosstt_amd_device_count(int* count)
+{
+    if (!count) return fail(PROSSTT_AMD_EINVAL, "count is NULL");
+    *count = 0;
+    hipError_t e = hipGetDeviceCount(count);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(PROSSTT_AMD_ENODEV, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    return 0;
+}
+
+PA_EXPORT int prosstt_amd_ctx_create(int device, void* stream, prosstt_amd_ctx** out)
+{
+    if (!out) return fail(PROSSTT_AMD_EINVAL, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(PROSSTT_AMD_ENODEV, "no HIP device visible: the prosstt_amd path has no CPU fallback");
+    if (device < 0 || device >= n) return fail(PROSSTT_AMD_EINVAL, "device %d out of range [0,%d)", device, n);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(PROSSTT_AMD_ENODEV, "device %d is %s; this library is built for gfx950 only", device,
+                    prop.gcnArchName);
+    HIP_TRY(hipSetDevice(device));
+    prosstt_amd_ctx* c = new (std::nothrow) prosstt_amd_ctx();
+    if (!c) return fail(PROSSTT_AMD_ENOMEM, "out of host memory");
+    c->device = device;
+    c->stream = (hipStream_t)stream;   // NULL = the device's default stream
+    if (hipMalloc((void**)&c->scratch, kScratchWords * 8) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_scratch, kScratchWords * 8) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        prosstt_amd_ctx_destroy(c);
+        return fail(PROSSTT_AMD_EHIP, "ctx allocation failed");
+    }
+    *out = c;
+    return 0;
+}
+
+PA_EXPORT int prosstt_amd_ctx_destroy(prosstt_amd_ctx* c)
+{
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->ws) (void)hipFree(c->ws);
+    if (c->scratch) (void)hipFree(c->scratch);
+    if (c->h_scratch) (void)hipHostFree(c->h_scratch);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    delete c;
+    return 0;
+}
+
+PA_EXPORT int prosstt_amd_ctx_synchronize(prosstt_amd_ctx* c)
+{
+    if (!c) return fail(PROSSTT_AMD_EINVAL, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+PA_EXPORT int prosstt_amd_last_kernel_ms(prosstt_amd_ctx* c, float* ms)
+{
+    if (!c || !ms) return fail(PROSSTT_AMD_EINVAL, "NULL argument");
+    if (!c->timed) return fail(PROSSTT_AMD_EINVAL, "no kernel was launched with PROSSTT_AMD_TIME_KERNEL");
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return 0;
+}
+
+// Common front end of sample_counts / nb_params: validates, stages host inputs,
+// converts the binary64 per-cell / per-gene parameters into the workspace.
+struct SamplerArgs {
+    const float* means; const int32_t* row_of_cell;
+    float *scal, *ga, *gbm1;
+};
+
+static int sampler_setup(prosstt_amd_ctx* c, Staging& st, const float* means, int64_t rows, int32_t G,
+                         const int32_t* row_of_cell, const double* scaling, const double* alpha,
+                         const double* beta, int64_t N, uint32_t flags, SamplerArgs* A)
+{
+    if (!c) return fail(PROSSTT_AMD_EINVAL, "ctx is NULL");
+    if (N < 0 || G < 0 || rows < 0) return fail(PROSSTT_AMD_EINVAL, "negative size");
+    if (N > 0 && G > 0 && (!means || !row_of_cell || !scaling || !alpha || !beta))
+        return fail(PROSSTT_AMD_EINVAL, "NULL input array");
+    if ((int64_t)G * 4 > (int64_t)1 << 33) return fail(PROSSTT_AMD_EINVAL, "G too large");
+    HIP_TRY(hipSetDevice(c->device));
+    if (N == 0 || G == 0) return 0;
+    if (flags & PROSSTT_AMD_HOST_INPUTS) {
+        // host-side bounds check is free here; device pointers are the caller's contract
+        for (int64_t n = 0; n < N; ++n)
+            if (row_of_cell[n] < 0 || row_of_cell[n] >= rows)
+                return fail(PROSSTT_AMD_EINVAL, "row_of_cell[%lld] = %d outside [0,%lld)", (long long)n,
+                            row_of_cell[n], (long long)rows);
+        int rc;
+        const void* d;
+        if ((rc = st.upload(means, (size_t)rows * G * 4, &d, c->stream))) return rc;
+        means = (const float*)d;
+        if ((rc = st.upload(row_of_cell, (size_t)N * 4, &d, c->stream))) return rc;
+        row_of_cell = (const int32_t*)d;
+        if ((rc = st.upload(scaling, (size_t)N * 8, &d, c->stream))) return rc;
+        scaling = (const double*)d;
+        if ((rc = st.upload(alpha, (size_t)G * 8, &d, c->stream))) return rc;
+        alpha = (const double*)d;
+        if ((rc = st.upload(beta, (size_t)G * 8, &d, c->stream))) return rc;
+        beta = (const double*)d;
+    }
+    const int64_t n_pad = (N + 15) & ~(int64_t)15;
+    int rc = ws_reserve(c, ((size_t)n_pad + 2 * (size_t)G) * sizeof(float));
+    if (rc) return rc;
+    A->means = means;
+    A->row_of_cell = row_of_cell;
+    A->scal = (float*)c->ws;
+    A->ga = A->scal + n_pad;
+    A->gbm1 = A->ga + G;
+    const int64_t span = N > G ? N : G;
+    prep_params_kernel<<<dim3((unsigned)((span + 255) / 256)), dim3(256), 0, c->stream>>>(
+        scaling, N, alpha, beta, G, A->scal, A->ga, A->gbm1);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, int64_t rows, int32_t G,
+                                        const int32_t* row_of_cell, const double* scaling,
+                                        const double* alpha, const double* beta, int64_t N,
+                                        uint64_t seed, uint64_t cell_offset, int32_t* out,
+                                        int64_t ld_out, uint32_t flags)
+{
+    Staging st;
+    SamplerArgs A{};
+    int rc = sampler_setup(c, st, means, rows, G, row_of_cell, scaling, alpha, beta, N, flags, &A);
+    if (rc) return rc;
+    if (N == 0 || G == 0) return 0;
+    if (!out) return fail(PROSSTT_AMD_EINVAL, "out is NULL");
+    if (ld_out < G) return fail(PROSSTT_AMD_EINVAL, "ld_out %lld < G %d", (long long)ld_out, G);
+
+    int32_t* d_out = out;
+    if (flags & PROSSTT_AMD_HOST_OUTPUT) {
+        void* p = nullptr;
+        if ((rc = st.alloc(&p, (size_t)N * ld_out * 4))) return rc;
+        d_out = (int32_t*)p;
+    }
+    HIP_TRY(hipMemsetAsync(c->scratch, 0, 8, c->stream));
+
+    const int64_t tiles_c = (N + kTileC - 1) / kTileC;
+    const int64_t tiles_g = ((int64_t)G + kTileG - 1) / kTileG;
+    if (tiles_c * tiles_g > 0x7fffffffll) return fail(PROSSTT_AMD_EINVAL, "too many tiles; chunk the cells");
+    const bool vec = (G % 4 == 0) && (ld_out % 4 == 0) && (((uintptr_t)A.means & 15) == 0) &&
+                     (((uintptr_t)d_out & 15) == 0);
+    const dim3 grid((unsigned)(tiles_c * tiles_g)), block(kBlock);
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    if (flags & PROSSTT_AMD_TIME_KERNEL) HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    if (vec)
+        sample_counts_kernel<true><<<grid, block, 0, c->stream>>>(A.means, G, A.row_of_cell, A.scal, A.ga,
+                                                                 A.gbm1, N, k0, k1, cell_offset, d_out,
+                                                                 ld_out, c->scratch, (int32_t)tiles_c);
+    else
+        sample_counts_kernel<false><<<grid, block, 0, c->stream>>>(A.means, G, A.row_of_cell, A.scal, A.ga,
+                                                                  A.gbm1, N, k0, k1, cell_offset, d_out,
+                                                                  ld_out, c->scratch, (int32_t)tiles_c);
+    HIP_TRY(hipGetLastError());
+    if (flags & PROSSTT_AMD_TIME_KERNEL) {
+        HIP_TRY(hipEventRecord(c->ev1, c->stream));
+        c->timed = true;
+    }
+    if (flags & PROSSTT_AMD_HOST_OUTPUT)
+        HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)N * ld_out * 4, hipMemcpyDeviceToHost, c->stream));
+    if (flags & PROSSTT_AMD_CHECK_DOMAIN) {
+        HIP_TRY(hipMemcpyAsync(c->h_scratch, c->scratch, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->h_scratch[0])
+            return fail(PROSSTT_AMD_EDOMAIN, "Domain error in arguments: a mean <= 0 or alpha*m + beta < 1");
+    } else if (flags & (PROSSTT_AMD_HOST_OUTPUT | PROSSTT_AMD_HOST_INPUTS)) {
+        HIP_TRY(hipStreamSynchronize(c->stream));   // staging buffers die with `st`
+    }
+    return 0;
+}
+
+PA_EXPORT int prosstt_amd_nb_params(prosstt_amd_ctx* c, const float* means, int64_t rows, int32_t G,
+                                    const int32_t* row_of_cell, const double* scaling,
+                                    const double* alpha, const double* beta, int64_t N, float* mu,
+                                    float* p, float* r, int32_t* path, uint32_t flags)
+{
+    Staging st;
+    SamplerArgs A{};
+    int rc = sampler_setup(c, st, means, rows, G, row_of_cell, scaling, alpha, beta, N, flags, &A);
+    if (rc) return rc;
+    if (N == 0 || G == 0) return 0;
+    const size_t bytes = (size_t)N * G * 4;
+    void* d[4] = {mu, p, r, path};
+    void* h[4] = {mu, p, r, path};
+    if (flags & PROSSTT_AMD_HOST_OUTPUT)
+        for (int i = 0; i < 4; ++i)
+            if (h[i] && (rc = st.alloc(&d[i], bytes))) return rc;
+    const int64_t total = N * (int64_t)G;
+    nb_params_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream>>>(
+        A.means, G, A.row_of_cell, A.scal, A.ga, A.gbm1, N, (float*)d[0], (float*)d[1], (float*)d[2],
+        (int32_t*)d[3]);
+    HIP_TRY(hipGetLastError());
+    if (flags & PROSSTT_AMD_HOST_OUTPUT)
+        for (int i = 0; i < 4; ++i)
+            if (h[i]) HIP_TRY(hipMemcpyAsync(h[i], d[i], bytes, hipMemcpyDeviceToHost, c->stream));
+    if (flags & (PROSSTT_AMD_HOST_OUTPUT | PROSSTT_AMD_HOST_INPUTS)) HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// centre the first `steps` rows of a [*][K] program matrix over time (scipy.stats.pearsonr's xm = x - mean)
+static void centred(const double* src, int steps, int K, double* dst)
+{
+    for (int k = 0; k < K; ++k) {
+        double mean = 0.0;
+        for (int t = 0; t < steps; ++t) mean += src[t * K + k];
+        mean /= steps;
+        for (int t = 0; t < steps; ++t) dst[t * K + k] = src[t * K + k] - mean;
+    }
+}
+
+PA_EXPORT int prosstt_amd_lineage_attempt(prosstt_amd_ctx* c, const double* programs, int32_t T, int32_t K,
+                                          const double* H, int64_t G, int32_t n_sib,
+                                          const double* const* sib_programs, const int32_t* sib_T,
+                                          double* out_max, int64_t* out_anticorr)
+{
+    if (!c || !programs || !H || !out_max) return fail(PROSSTT_AMD_EINVAL, "NULL argument");
+    if (T <= 0 || K <= 0 || G <= 0 || n_sib < 0) return fail(PROSSTT_AMD_EINVAL, "bad size");
+    if (n_sib > kScratchWords - 2) return fail(PROSSTT_AMD_EINVAL, "more than %d siblings", kScratchWords - 2);
+    if (n_sib && (!sib_programs || !sib_T || !out_anticorr)) return fail(PROSSTT_AMD_EINVAL, "NULL sibling argument");
+    HIP_TRY(hipSetDevice(c->device));
+
+    std::vector<double> host((size_t)T * K);
+    std::vector<int32_t> meta(1 + n_sib);
+    memcpy(host.data(), programs, sizeof(double) * T * K);
+    meta[0] = n_sib;
+    for (int j = 0; j < n_sib; ++j) {
+        if (sib_T[j] <= 0 || !sib_programs[j]) return fail(PROSSTT_AMD_EINVAL, "bad sibling %d", j);
+        const int common = T < sib_T[j] ? T : sib_T[j];
+        meta[1 + j] = common;
+        const size_t at = host.size();
+        host.resize(at + 2 * (size_t)common * K);
+        centred(programs, common, K, host.data() + at);
+        centred(sib_programs[j], common, K, host.data() + at + (size_t)common * K);
+    }
+    const size_t prog_bytes = host.size() * 8, meta_bytes = (meta.size() * 4 + 7) & ~(size_t)7;
+    int rc = ws_reserve(c, prog_bytes + meta_bytes);
+    if (rc) return rc;
+    double* d_prog = (double*)c->ws;
+    int32_t* d_meta = (int32_t*)((char*)c->ws + prog_bytes);
+    HIP_TRY(hipMemcpyAsync(d_prog, host.data(), prog_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_meta, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->scratch, 0, kScratchWords * 8, c->stream));   // ordered_bits(x) > 0 for every x
+    lineage_attempt_kernel<<<dim3((unsigned)((G + 255) / 256)), dim3(256), 0, c->stream>>>(
+        d_prog, d_meta, T, K, H, G, (unsigned long long*)c->scratch + 1,
+        (unsigned long long*)c->scratch + 2);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->h_scratch, c->scratch, (2 + n_sib) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));   // also keeps `host` alive until the H2D copies are done
+    *out_max = from_ordered_bits((unsigned long long)c->h_scratch[1]);
+    for (int j = 0; j < n_sib; ++j) out_anticorr[j] = c->h_scratch[2 + j];
+    return 0;
+}
+
+PA_EXPORT int prosstt_amd_lineage_commit(prosstt_amd_ctx* c, const double* programs, int32_t T, int32_t K,
+                                         const double* H, int64_t G, double* rel_out, double* gene_max)
+{
+    if (!c || !programs || !H) return fail(PROSSTT_AMD_EINVAL, "NULL argument");
+    if (T <= 0 || K <= 0 || G <= 0) return fail(PROSSTT_AMD_EINVAL, "bad size");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t bytes = (size_t)T * K * 8;
+    int rc = ws_reserve(c, bytes);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->ws, programs, bytes, hipMemcpyHostToDevice, c->stream));
+    lineage_commit_kernel<<<dim3((unsigned)((G + 255) / 256)), dim3(256), 0, c->stream>>>(
+        (const double*)c->ws, T, K, H, G, rel_out, gene_max);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));   // `programs` is a pageable host buffer the caller may reuse
+    return 0;
+}
+
+PA_EXPORT int prosstt_amd_means_from_rel(prosstt_amd_ctx* c, const double* rel, const double* base,
+                                         int64_t rows, int64_t G, float* means_out)
+{
+    if (!c || !rel || !base || !means_out) return fail(PROSSTT_AMD_EINVAL, "NULL argument");
+    if (rows < 0 || G < 0) return fail(PROSSTT_AMD_EINVAL, "negative size");
+    if (rows == 0 || G == 0) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    int64_t blocks = (rows * G + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    means_from_rel_kernel<<<dim3((unsigned)blocks), dim3(256), 0, c->stream>>>(rel, base, rows, G, means_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,164 @@
+"""
+Thin object layer over the C ABI: one ``Context`` per (device, stream).
+
+torch supplies device memory and the stream handle; every numeric step is a
+call into libprosstt_amd.so.  Nothing here computes on the CPU.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _native
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def require_gpu():
+    """Raise unless the HIP library loads and a gfx950 device is visible."""
+    _native.load()
+    torch = _torch()
+    if not torch.cuda.is_available() or _native.device_count() == 0:
+        raise RuntimeError("prosstt_amd needs an AMD MI355X (gfx950) device: there is no CPU fallback")
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class Context:
+    """Owns a prosstt_amd_ctx bound to ``device`` and to torch's current stream there."""
+
+    def __init__(self, device=None):
+        require_gpu()
+        torch = _torch()
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self.torch_device = torch.device("cuda", self.device)
+        self.stream = torch.cuda.current_stream(self.device)
+        self._lib = _native.load()
+        handle = ctypes.c_void_p()
+        _native.check(self._lib.prosstt_amd_ctx_create(
+            self.device, ctypes.c_void_p(self.stream.cuda_stream), ctypes.byref(handle)))
+        self._h = handle
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.prosstt_amd_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- helpers ------------------------------------------------------------
+    def tensor(self, array, dtype):
+        """Host array (or tensor) -> contiguous device tensor of ``dtype``."""
+        torch = _torch()
+        if isinstance(array, torch.Tensor):
+            return array.to(device=self.torch_device, dtype=dtype).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(array), dtype=dtype).to(self.torch_device)
+
+    def synchronize(self):
+        _native.check(self._lib.prosstt_amd_ctx_synchronize(self._h))
+
+    def last_kernel_ms(self):
+        ms = ctypes.c_float(0)
+        _native.check(self._lib.prosstt_amd_last_kernel_ms(self._h, ctypes.byref(ms)))
+        return ms.value
+
+    # ---- K3: fused count sampler -------------------------------------------
+    def sample_counts(self, means, row_of_cell, scaling, alpha, beta, seed, cell_offset=0,
+                      out=None, check_domain=True, time_kernel=False):
+        """int32 device tensor (N, G) of counts; see prosstt_amd_sample_counts."""
+        torch = _torch()
+        means = self.tensor(means, torch.float32)
+        rows, G = means.shape
+        row_of_cell = self.tensor(row_of_cell, torch.int32)
+        N = row_of_cell.numel()
+        scaling = self.tensor(scaling, torch.float64)
+        alpha = self.tensor(alpha, torch.float64)
+        beta = self.tensor(beta, torch.float64)
+        if scaling.numel() != N or alpha.numel() != G or beta.numel() != G:
+            raise ValueError("scaling must have one entry per cell, alpha/beta one per gene")
+        if out is None:
+            out = torch.empty((N, G), dtype=torch.int32, device=self.torch_device)
+        elif out.dtype != torch.int32 or out.shape != (N, G) or out.stride(1) != 1:
+            raise ValueError("out must be an int32 (N, G) tensor with unit column stride")
+        flags = (_native.CHECK_DOMAIN if check_domain else 0) | (_native.TIME_KERNEL if time_kernel else 0)
+        _native.check(self._lib.prosstt_amd_sample_counts(
+            self._h, _ptr(means), rows, G, _ptr(row_of_cell), _ptr(scaling), _ptr(alpha), _ptr(beta),
+            N, ctypes.c_uint64(seed & (2 ** 64 - 1)), ctypes.c_uint64(cell_offset),
+            _ptr(out), out.stride(0) if N else G, flags))
+        return out
+
+    def nb_params(self, means, row_of_cell, scaling, alpha, beta):
+        """(mu, p, r, path) device tensors (N, G) -- the sampler's deterministic intermediates."""
+        torch = _torch()
+        means = self.tensor(means, torch.float32)
+        rows, G = means.shape
+        row_of_cell = self.tensor(row_of_cell, torch.int32)
+        N = row_of_cell.numel()
+        scaling = self.tensor(scaling, torch.float64)
+        alpha = self.tensor(alpha, torch.float64)
+        beta = self.tensor(beta, torch.float64)
+        mu = torch.empty((N, G), dtype=torch.float32, device=self.torch_device)
+        p = torch.empty_like(mu)
+        r = torch.empty_like(mu)
+        path = torch.empty((N, G), dtype=torch.int32, device=self.torch_device)
+        _native.check(self._lib.prosstt_amd_nb_params(
+            self._h, _ptr(means), rows, G, _ptr(row_of_cell), _ptr(scaling), _ptr(alpha), _ptr(beta),
+            N, _ptr(mu), _ptr(p), _ptr(r), _ptr(path), 0))
+        return mu, p, r, path
+
+    # ---- K2: lineage ---------------------------------------------------------
+    def lineage_attempt(self, programs, H, sib_programs=()):
+        """(max(programs@H), [#genes with r<0 per sibling]) -- simulation.py:269-272."""
+        programs = np.ascontiguousarray(programs, np.float64)
+        T, K = programs.shape
+        sibs = [np.ascontiguousarray(s, np.float64) for s in sib_programs]
+        n = len(sibs)
+        ptrs = (ctypes.c_void_p * max(n, 1))(*[s.ctypes.data for s in sibs])
+        lens = (ctypes.c_int32 * max(n, 1))(*[s.shape[0] for s in sibs])
+        for s in sibs:
+            if s.shape[1] != K:
+                raise ValueError("sibling programs must have %d columns" % K)
+        mx = ctypes.c_double(0)
+        counts = (ctypes.c_int64 * max(n, 1))()
+        _native.check(self._lib.prosstt_amd_lineage_attempt(
+            self._h, programs.ctypes.data_as(ctypes.c_void_p), T, K, _ptr(H), H.shape[1], n,
+            ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(lens, ctypes.c_void_p),
+            ctypes.cast(ctypes.byref(mx), ctypes.c_void_p), ctypes.cast(counts, ctypes.c_void_p)))
+        return mx.value, [int(counts[j]) for j in range(n)]
+
+    def lineage_commit(self, programs, H, rel_out=None, gene_max=None):
+        programs = np.ascontiguousarray(programs, np.float64)
+        T, K = programs.shape
+        _native.check(self._lib.prosstt_amd_lineage_commit(
+            self._h, programs.ctypes.data_as(ctypes.c_void_p), T, K, _ptr(H), H.shape[1],
+            _ptr(rel_out), _ptr(gene_max)))
+
+    def means_from_rel(self, rel, base, out=None):
+        torch = _torch()
+        rows, G = rel.shape
+        if out is None:
+            out = torch.empty((rows, G), dtype=torch.float32, device=self.torch_device)
+        _native.check(self._lib.prosstt_amd_means_from_rel(self._h, _ptr(rel), _ptr(base), rows, G, _ptr(out)))
+        return out
+
+
+_contexts = {}
+
+
+def get_context(device=None):
+    """Process-wide Context of a device, bound to torch's current stream at first use."""
+    torch = _torch()
+    require_gpu()
+    dev = torch.cuda.current_device() if device is None else int(device)
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    if key not in _contexts:
+        _contexts[key] = Context(dev)
+    return _contexts[key]

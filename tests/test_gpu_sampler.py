@@ -1,0 +1,175 @@
+"""
+-m gpu: the HIP count sampler (K3) against the oracle, through the C ABI.
+
+ * counts: BIT-EXACT against oracle/nb_model.c (the scalar C model of PRNB-1) on the
+   same seeded inputs -- integer work, no tolerance;
+ * (mu, p, r): bit-exact against the model AND within rtol 1e-6 of the reference's
+   float64 get_pr_umi (count_model.py:156-158) -- the stated fp32 tolerance;
+ * the law: chi-square of device draws against scipy's NB pmf tables (fixture g7);
+ * size-independent properties at larger sizes: chunking over cells and
+   cell_offset invariance, run-to-run determinism, sum(X)/sum(mu) -> 1.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from prosstt_amd import device
+    return device.get_context()
+
+
+def synthetic(seed, rows, G, N, heavy_frac=None):
+    """Inputs with the value mix SURVEY section 6 measured (median mu ~1.5, 90 % < 10, max ~1e4)."""
+    rng = np.random.default_rng(seed)
+    base = np.exp(rng.normal(0.8, 1.0, G))
+    rel = rng.normal(0.0, 0.6, (rows, G)).cumsum(axis=0) * 0.15
+    means = (np.exp(rel) * base).astype(np.float32)
+    if heavy_frac:
+        means[:, rng.random(G) < heavy_frac] *= 200.0
+    row_of_cell = rng.integers(0, rows, N).astype(np.int32)
+    scaling = np.exp(rng.normal(0, 0.7, N))
+    alpha = np.exp(rng.normal(np.log(0.2), np.log(1.5), G))
+    beta = np.exp(rng.normal(np.log(1.0), np.log(1.5), G)) + 1
+    return means, row_of_cell, scaling, alpha, beta
+
+
+@pytest.mark.parametrize("rows,G,N,seed", [
+    (30, 256, 64, 1),        # exactly one gene tile
+    (150, 1000, 333, 2),     # ragged in both directions, G % 256 != 0
+    (7, 37, 5, 3),           # G % 4 != 0 -> scalar load/store path
+    (40, 4, 1, 4),           # one cell, one quad
+    (400, 2048, 777, 5),
+])
+def test_counts_bit_exact_vs_model(ctx, rows, G, N, seed):
+    from oracle import nb_model
+    means, roc, sc, al, be = synthetic(seed, rows, G, N, heavy_frac=0.05)
+    got = ctx.sample_counts(means, roc, sc, al, be, seed=seed * 7919, cell_offset=seed * 10**6).cpu().numpy()
+    want = nb_model.sample_counts(means, roc, sc, al, be, seed * 7919, seed * 10**6)
+    assert got.dtype == np.int32 and got.shape == (N, G)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_params_vs_model_and_reference(ctx):
+    from oracle import nb_model, ref_numpy
+    means, roc, sc, al, be = synthetic(11, 60, 500, 200, heavy_frac=0.1)
+    mu, p, r, path = [t.cpu().numpy() for t in ctx.nb_params(means, roc, sc, al, be)]
+    mmu, mp, mr, mpath = nb_model.nb_params(means, roc, sc, al, be)
+    np.testing.assert_array_equal(mu, mmu)
+    np.testing.assert_array_equal(p, mp)
+    np.testing.assert_array_equal(r, mr)
+    np.testing.assert_array_equal(path, mpath)
+    assert set(np.unique(path)) == {1, 2}
+    # float64 reference formulas on the same (fp32-stored) means
+    mu64 = means.astype(np.float64)[roc] * sc[:, None]
+    p64, r64 = ref_numpy.get_pr_umi(al[None, :], be[None, :], mu64)
+    np.testing.assert_allclose(mu, mu64, rtol=1e-6)
+    np.testing.assert_allclose(p, p64, rtol=1e-6)
+    np.testing.assert_allclose(r, r64, rtol=2e-6)
+
+
+def test_edge_parameters_bit_exact(ctx):
+    """Poisson limit (beta = 1 + 1e-8, examples/linear.ipynb), alpha = 1e-4
+    (many_branches_cells.ipynb cell 11), huge alpha, tiny and large means."""
+    from oracle import nb_model
+    G = 64
+    means = np.tile(np.array([1e-7, 1e-3, 0.3, 2.0, 11.99, 12.01, 40.0, 3000.0], np.float32), (3, G // 8))
+    means[1] *= 0.5
+    means[2] *= 7.0
+    roc = np.arange(300, dtype=np.int32) % 3
+    sc = np.exp(np.random.default_rng(5).normal(0, 0.7, 300))
+    for al, be in ((0.0, 1 + 1e-8), (1e-4, 1.3), (5.0, 2.0), (0.2, 40.0), (0.0, 7.0)):
+        a, b = np.full(G, al), np.full(G, be)
+        got = ctx.sample_counts(means, roc, sc, a, b, seed=99).cpu().numpy()
+        want = nb_model.sample_counts(means, roc, sc, a, b, 99)
+        np.testing.assert_array_equal(got, want)
+        assert got.max() > 0
+
+
+def test_domain_errors_like_scipy(ctx):
+    """simulation.py:647-648: an exact-zero mean, or alpha*m + beta < 1, raises ValueError;
+    alpha = 0, beta = 1 silently yields zeros."""
+    means = np.ones((2, 8), np.float32)
+    means[1, 3] = 0.0
+    roc = np.array([0, 1], np.int32)
+    sc = np.ones(2)
+    with pytest.raises(ValueError):
+        ctx.sample_counts(means, roc, sc, np.full(8, 0.2), np.full(8, 2.0), seed=1)
+    ok = ctx.sample_counts(means, roc[:1], sc[:1], np.full(8, 0.2), np.full(8, 2.0), seed=1)
+    assert ok.shape == (1, 8)
+    with pytest.raises(ValueError):
+        ctx.sample_counts(means, roc[:1], sc[:1], np.full(8, 0.0), np.full(8, 0.5), seed=1)
+    z = ctx.sample_counts(means, roc[:1], sc[:1], np.zeros(8), np.ones(8), seed=1)
+    assert int(z.sum()) == 0
+    # unchecked mode never raises and writes 0 for the offending entries
+    u = ctx.sample_counts(means, roc, sc, np.full(8, 0.2), np.full(8, 2.0), seed=1, check_domain=False)
+    assert int(u[1, 3]) == 0
+
+
+def test_empty_inputs(ctx):
+    means = np.ones((3, 16), np.float32)
+    out = ctx.sample_counts(means, np.zeros(0, np.int32), np.zeros(0), np.full(16, 0.2), np.full(16, 2.0), seed=3)
+    assert tuple(out.shape) == (0, 16)
+
+
+def test_law_against_scipy_tables(ctx):
+    """Every parameter set of fixture g7: 2e6 device draws vs the analytic pmf."""
+    from scipy import stats
+    g = load_golden("g7_nb_tables")
+    par, pmf = g["params"], g["pmf"]
+    n = 2_000_000
+    pvals = []
+    for i, (m, a, b, r, p, mean, var) in enumerate(par):
+        means = np.full((1, 4), m, np.float32)
+        x = ctx.sample_counts(means, np.zeros(n // 4, np.int32), np.ones(n // 4), np.full(4, a), np.full(4, b),
+                              seed=4242 + i, check_domain=False).cpu().numpy().reshape(-1)
+        m32 = float(np.float32(m))
+        assert abs(x.mean() - m32) < 6 * np.sqrt(var / n) + 1e-6 * m32
+        kmax = pmf.shape[1]
+        cnt = np.bincount(np.minimum(x, kmax - 1), minlength=kmax).astype(float)
+        exp = pmf[i] * n
+        exp[-1] += n * max(0.0, 1 - pmf[i].sum())
+        obs_b, exp_b, co, ce = [], [], 0.0, 0.0
+        for k in range(kmax):
+            co += cnt[k]
+            ce += exp[k]
+            if ce >= 50:
+                obs_b.append(co); exp_b.append(ce); co = ce = 0.0
+        obs_b[-1] += co
+        exp_b[-1] += ce
+        obs_b, exp_b = np.array(obs_b), np.array(exp_b)
+        chi2 = ((obs_b - exp_b) ** 2 / exp_b).sum()
+        pvals.append(stats.chi2.sf(chi2, len(obs_b) - 1))
+    assert min(pvals) > 1e-4 / len(pvals), pvals     # Bonferroni
+
+
+def test_chunking_offset_and_determinism(ctx):
+    """Results are a pure function of (inputs, seed, global cell index): sampling cells
+    [0,N) in one call equals sampling them in ragged chunks with cell_offset."""
+    import torch
+    means, roc, sc, al, be = synthetic(21, 400, 5000, 5000)
+    full = ctx.sample_counts(means, roc, sc, al, be, seed=77)
+    again = ctx.sample_counts(means, roc, sc, al, be, seed=77)
+    assert torch.equal(full, again)
+    other = ctx.sample_counts(means, roc, sc, al, be, seed=78)
+    assert not torch.equal(full, other)
+    parts, start = [], 0
+    for size in (1, 15, 16, 17, 1000, 3951):
+        sl = slice(start, start + size)
+        parts.append(ctx.sample_counts(means, roc[sl], sc[sl], al, be, seed=77, cell_offset=start))
+        start += size
+    assert start == 5000
+    assert torch.equal(full, torch.cat(parts))
+    # strided output (ld_out > G) lands in the same values
+    wide = torch.zeros((5000, 5008), dtype=torch.int32, device=full.device)
+    ctx.sample_counts(means, roc, sc, al, be, seed=77, out=wide[:, :5000])
+    assert torch.equal(wide[:, :5000], full) and int(wide[:, 5000:].abs().sum()) == 0
+    # first-moment check at this size
+    mu = torch.as_tensor(means, device=full.device)[torch.as_tensor(roc, device=full.device).long()] \
+        * torch.as_tensor(sc, device=full.device, dtype=torch.float32)[:, None]
+    ratio = float(full.sum(dtype=torch.float64) / mu.sum(dtype=torch.float64))
+    assert abs(ratio - 1) < 2e-3
