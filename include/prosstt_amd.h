@@ -117,6 +117,14 @@ int prosstt_amd_lineage_commit(prosstt_amd_ctx* ctx, const double* programs, int
                                const double* H, int64_t G, double* rel_out, double* gene_max);
 
 /*
+ * gene_max[g] = max(gene_max[g], max_row rel[row][g]) for a DEVICE [rows][G] binary64
+ * matrix: the reduction inside sim_utils.max_relat_exp (sim_utils.py:423-425) in
+ * log space (exp is monotone).  gene_max is DEVICE [G], initialised by the caller.
+ */
+int prosstt_amd_gene_max(prosstt_amd_ctx* ctx, const double* rel, int64_t rows, int64_t G,
+                         double* gene_max);
+
+/*
  * Tree.add_genes (tree.py:166-183): means[row][g] = exp(rel[row][g]) * base[g],
  * evaluated in binary64 and stored as binary32.  All DEVICE; rows = sum of T_b.
  */

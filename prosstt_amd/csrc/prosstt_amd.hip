@@ -319,6 +319,16 @@ __global__ __launch_bounds__(256) void lineage_commit_kernel(const double* __res
     if (gene_max) gene_max[g] = mx;
 }
 
+__global__ __launch_bounds__(256) void gene_max_kernel(const double* __restrict__ rel, int64_t rows,
+                                                       int64_t G, double* __restrict__ gene_max)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    double mx = gene_max[g];
+    for (int64_t t = 0; t < rows; ++t) mx = fmax(mx, rel[t * G + g]);
+    gene_max[g] = mx;
+}
+
 __global__ __launch_bounds__(256) void means_from_rel_kernel(const double* __restrict__ rel,
                                                              const double* __restrict__ base,
                                                              int64_t rows, int64_t G,
@@ -611,6 +621,18 @@ PA_EXPORT int prosstt_amd_lineage_commit(prosstt_amd_ctx* c, const double* progr
         (const double*)c->ws, T, K, H, G, rel_out, gene_max);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));   // `programs` is a pageable host buffer the caller may reuse
+    return 0;
+}
+
+PA_EXPORT int prosstt_amd_gene_max(prosstt_amd_ctx* c, const double* rel, int64_t rows, int64_t G,
+                                   double* gene_max)
+{
+    if (!c || !rel || !gene_max) return fail(PROSSTT_AMD_EINVAL, "NULL argument");
+    if (rows < 0 || G < 0) return fail(PROSSTT_AMD_EINVAL, "negative size");
+    if (rows == 0 || G == 0) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    gene_max_kernel<<<dim3((unsigned)((G + 255) / 256)), dim3(256), 0, c->stream>>>(rel, rows, G, gene_max);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 

@@ -141,6 +141,12 @@ class Context:
             self._h, programs.ctypes.data_as(ctypes.c_void_p), T, K, _ptr(H), H.shape[1],
             _ptr(rel_out), _ptr(gene_max)))
 
+    def gene_max(self, rel, gene_max):
+        """gene_max[g] = max(gene_max[g], max over rows of rel[:, g]) -- sim_utils.py:423-425 in log space."""
+        rel = rel.contiguous()
+        _native.check(self._lib.prosstt_amd_gene_max(self._h, _ptr(rel), rel.shape[0], rel.shape[1], _ptr(gene_max)))
+        return gene_max
+
     def means_from_rel(self, rel, base, out=None):
         torch = _torch()
         rows, G = rel.shape

@@ -1,0 +1,347 @@
+"""
+Simulation entry points, mirroring ``prosstt.simulation``
+(reference: /root/reference/prosstt/simulation.py).  Same names, positional
+arguments, defaults and return values; new options are keyword-only.
+
+Division of labour
+ * host (numpy, same RandomState calls in the same order as the reference):
+   random-walk variates, coefficient draws, the (pseudotime, branch) plan of the
+   cells, library-size factors -- O(branches*K*T), O(K*G) or O(cells) numbers;
+ * device (hand-written HIP, through the C ABI of include/prosstt_amd.h):
+   ``programs @ coefficients`` with the accept/reject reductions, the mean tensor,
+   and the fused negative-binomial count sampler -- O(T*G*K) and O(cells*genes).
+
+There is no CPU fallback for the device part.
+"""
+import warnings
+
+import numpy as np
+from numpy import random
+import pandas as pd
+
+from . import count_model as cm
+from . import device as _device
+from . import sim_utils as sut
+
+
+# ----------------------------------------------------------------------------------
+# expression programs and coefficients (host draws)
+# ----------------------------------------------------------------------------------
+
+def diffusion(steps):
+    """Random walk with momentum (simulation.py:89-124).  Variates are drawn in the
+    reference's order -- U, N, U, then (steps-1) x N -- so the walk is the same
+    sequence of binary64 operations on the same numbers."""
+    start = random.random_sample() * 1.5 + 0
+    vel0 = random.standard_normal() * 0.2 + 0
+    s_eps = 2 / steps
+    eta = random.random_sample() * 1 + 0
+    eps = random.standard_normal(steps - 1) * s_eps + 0 if steps > 1 else np.zeros(0)
+    walk = np.zeros(steps)
+    velocity = np.zeros(steps)
+    walk[0] = np.log(start)
+    velocity[0] = vel0
+    for t in range(steps - 1):
+        walk[t + 1] = walk[t] + velocity[t]
+        velocity[t + 1] = eta * velocity[t] + eps[t]
+    return walk
+
+
+def sim_expr_branch(branch_length, expr_progr, cutoff=0.2, max_loops=100):
+    """(branch_length, expr_progr) matrix of independent walks (simulation.py:21-86).
+    The reference's correlation filter never fires (see sim_utils.test_correlation),
+    so ``cutoff`` and ``max_loops`` are accepted and ignored; a single program, which
+    hangs the reference, is refused."""
+    if expr_progr < 2:
+        raise ValueError("at least 2 expression programs are needed (the reference never "
+                         "terminates for 1)")
+    programs = np.zeros((expr_progr, branch_length))
+    for k in range(expr_progr):
+        programs[k] = diffusion(branch_length)
+    return np.transpose(programs)
+
+
+def simulate_coefficients(tree, fallback_a=0.04, **kwargs):
+    """(K, G) contribution of every program to every gene (simulation.py:127-161)."""
+    if "a" not in kwargs.keys():
+        warnings.warn("No argument 'a' specified in kwargs: using gamma and a=0.04", UserWarning)
+        return _sim_coeff_gamma(tree, fallback_a)
+    if "b" in kwargs.keys():
+        # the reference ignores the passed values and uses Beta(2, 2) (simulation.py:157-159, 164)
+        return _sim_coeff_beta(tree, sut.create_groups(tree.modules, tree.G))
+    return _sim_coeff_gamma(tree, a=kwargs['a'])
+
+
+def _sim_coeff_beta(tree, groups, a=2, b=2):
+    """simulation.py:164-189."""
+    H = np.zeros((tree.modules, tree.G))
+    for k in range(tree.modules):
+        for gene in groups[k]:
+            H[k][gene] += random.beta(a, b) * 1 + 0
+    return H
+
+
+def _sim_coeff_gamma(tree, a=0.05):
+    """simulation.py:192-212."""
+    K, G = tree.modules, tree.G
+    return np.reshape(random.standard_gamma(a, K * G) * 1 + 0, (K, G))
+
+
+# ----------------------------------------------------------------------------------
+# lineage (device: K2 kernels)
+# ----------------------------------------------------------------------------------
+
+def _stack_rows(tree, per_branch):
+    return np.concatenate([np.asarray(per_branch[b], dtype=np.float64) for b in tree.branches], axis=0)
+
+
+def _device_rel(tree, relative_means):
+    """(sum T_b, G) binary64 device tensor of ``relative_means``; the tensor that
+    simulate_lineage left on the device is reused when these are the arrays it returned."""
+    import torch
+    cache = tree._lineage
+    if cache is not None and all(relative_means[b] is cache["host"][b] for b in tree.branches):
+        return cache["rel"]
+    ctx = _device.get_context()
+    return ctx.tensor(_stack_rows(tree, relative_means), torch.float64)
+
+
+def _device_gene_max(tree, relative_means):
+    """(G,) device tensor: max over branches and time of the relative means (log of
+    sim_utils.max_relat_exp reduced over branches, sim_utils.py:460-461)."""
+    import torch
+    cache = tree._lineage
+    if cache is not None and all(relative_means[b] is cache["host"][b] for b in tree.branches):
+        return cache["gene_max"]
+    ctx = _device.get_context()
+    rel = ctx.tensor(_stack_rows(tree, relative_means), torch.float64)
+    gmax = torch.full((rel.shape[1],), -np.inf, dtype=torch.float64, device=ctx.torch_device)
+    return ctx.gene_max(rel, gmax)
+
+
+def simulate_lineage(tree, rel_exp_cutoff=8, intra_branch_tol=0.5, inter_branch_tol=0,
+                     *, max_attempts=None, stats=None, **kwargs):
+    """Relative mean expression of every gene at every point of the tree
+    (simulation.py:215-286).
+
+    Returns ``(pd.Series rel_means, pd.Series programs, coefficients)`` like the
+    reference.  Per branch, in breadth-first order, programs are redrawn until
+    ``max(programs @ H) <= rel_exp_cutoff`` and more than ``inter_branch_tol`` of
+    the genes are anticorrelated with every already-simulated sibling.  Each
+    attempt costs one ``lineage_attempt`` kernel (no (T, G) matrix is formed) and
+    two scalars back; the accepted branch is materialised once by ``lineage_commit``.
+
+    New keyword-only options: ``max_attempts`` bounds the redraws per branch
+    (default unlimited, like the reference); ``stats`` (a list) receives one
+    ``(branch, max, [anticorrelated counts])`` record per attempt.
+    """
+    import torch
+    if not len(tree.time) == tree.num_branches:
+        raise ValueError("the parameters are not enough for %i branches" % tree.num_branches)
+    ctx = _device.get_context()
+    topology = np.array(tree.topology)
+    coefficients = simulate_coefficients(tree, **kwargs)
+    H = ctx.tensor(coefficients, torch.float64)
+    offsets, rows = tree.row_offsets()
+    rel = torch.empty((rows, tree.G), dtype=torch.float64, device=ctx.torch_device)
+    gene_max = torch.full((tree.G,), -np.inf, dtype=torch.float64, device=ctx.torch_device)
+    programs = {}
+    for branch in sut.breadth_first_branches(tree):
+        tries = 0
+        while True:
+            tries += 1
+            programs[branch] = sim_expr_branch(tree.time[branch], tree.modules, cutoff=intra_branch_tol)
+            programs[branch] = sut.adjust_to_parent(programs, branch, topology)
+            siblings = [b for b in sut.find_parallel(tree, programs, branch)
+                        if b is not None and b != branch]
+            top, counts = ctx.lineage_attempt(programs[branch], H, [programs[s] for s in siblings])
+            if stats is not None:
+                stats.append((branch, top, counts))
+            diverges = all(c / (tree.G * 1.0) > inter_branch_tol for c in counts)
+            if not (top > rel_exp_cutoff) and diverges:
+                break
+            if max_attempts is not None and tries >= max_attempts:
+                raise RuntimeError("branch %r: no acceptable expression programs after %d attempts "
+                                   "(rel_exp_cutoff=%r, inter_branch_tol=%r)"
+                                   % (branch, tries, rel_exp_cutoff, inter_branch_tol))
+        key = _plain_label(tree, branch)
+        at = offsets[key]
+        ctx.lineage_commit(programs[branch], H, rel[at:at + int(tree.time[key])], gene_max)
+    host = rel.cpu().numpy()
+    rel_means = {b: host[offsets[b]:offsets[b] + int(tree.time[b])] for b in tree.branches}
+    tree._lineage = dict(rel=rel, gene_max=gene_max, host=rel_means, H=H)
+    ordered = {}
+    for branch in programs:                      # keep the reference's insertion (BFS) order
+        ordered[branch] = rel_means[_plain_label(tree, branch)]
+    return pd.Series(ordered), pd.Series(programs), coefficients
+
+
+def _plain_label(tree, label):
+    """numpy scalar label -> the key object used in ``tree.branches``."""
+    for b in tree.branches:
+        if b == label:
+            return b
+    raise KeyError(label)
+
+
+# ----------------------------------------------------------------------------------
+# sampling (host plan + device K3)
+# ----------------------------------------------------------------------------------
+
+def sample_whole_tree_restricted(tree, alpha=0.2, beta=3, **device_opts):
+    """Default one-shot simulation (simulation.py:289-316); returns 4 values like the
+    reference does (its docstring lists 3)."""
+    sample_time = np.arange(0, tree.get_max_time())
+    tree.default_gene_expression()
+    alphas, betas = cm.generate_negbin_params(tree, mean_alpha=alpha, mean_beta=beta)
+    return _sample_data_at_times(tree, sample_time, alpha=alphas, beta=betas, **device_opts)
+
+
+def sample_pseudotime_series(tree, cells, series_points, point_std, alpha=0.3, beta=2, scale=True,
+                             scale_mean=0, scale_v=0.7, **device_opts):
+    """Cells normally distributed around sample time points (simulation.py:319-379)."""
+    series_points, cells, point_std = sut.process_timeseries_input(series_points, cells, point_std)
+    pseudotimes = []
+    max_time = tree.get_max_time()
+    for t, n, var in zip(series_points, cells, point_std):
+        pseudotimes.extend(draw_times(t, n, max_time, var))
+    return _sample_data_at_times(tree, np.array(pseudotimes), alpha=alpha, beta=beta, scale=scale,
+                                 scale_mean=scale_mean, scale_v=scale_v, **device_opts)
+
+
+def draw_times(timepoint, no_cells, max_time, var=4):
+    """simulation.py:382-413."""
+    sample_pt = (random.standard_normal(no_cells) * var + timepoint).astype(int)
+    sample_pt[sample_pt < 0] = 0
+    sample_pt[sample_pt >= max_time] = max_time - 1
+    return sample_pt
+
+
+def _density_plan(tree, no_cells):
+    """(pseudotime, branch) of ``no_cells`` cells drawn from ``tree.density``
+    (simulation.py:452-467): one ``np.random.choice`` over all sum(T_b) positions."""
+    bt = tree.branch_times()
+    possible_pt = np.concatenate([np.arange(bt[b][0], bt[b][1] + 1) for b in tree.branches])
+    possible_branches = np.concatenate([[b] * tree.time[b] for b in tree.branches])
+    probabilities = np.concatenate([tree.density[b] for b in tree.branches])
+    sample = random.choice(np.arange(len(probabilities)), size=no_cells, p=probabilities)
+    return possible_pt[sample], possible_branches[sample]
+
+
+def sample_density(tree, no_cells, alpha=0.3, beta=2, scale=True, scale_v=0.7, scale_mean=0.,
+                   **device_opts):
+    """Sample cells according to the density along the tree (simulation.py:416-471)."""
+    sample_time, sample_branches = _density_plan(tree, no_cells)
+    return _sample_data_at_times(tree, sample_time, alpha=alpha, beta=beta, branches=sample_branches,
+                                 scale=scale, scale_mean=scale_mean, scale_v=scale_v, **device_opts)
+
+
+def sample_whole_tree(tree, n_factor, alpha=0.3, beta=2, scale=True, scale_mean=0., scale_v=0.7,
+                      **device_opts):
+    """Every (pseudotime, branch) position ``n_factor`` times (simulation.py:474-517)."""
+    pseudotime, branches = cover_whole_tree(tree)
+    return _sample_data_at_times(tree, np.repeat(pseudotime, n_factor), alpha=alpha, beta=beta,
+                                 branches=np.repeat(branches, n_factor), scale=scale,
+                                 scale_mean=scale_mean, scale_v=scale_v, **device_opts)
+
+
+def cover_whole_tree(tree):
+    """All (pseudotime, branch) pairs of the tree, timezone by timezone (simulation.py:520-548)."""
+    timezone = tree.populate_timezone()
+    assignments = sut.assign_branches(tree.branch_times(), timezone)
+    pseudotime, branches = [], []
+    for i, (start, last) in enumerate(timezone):
+        for branch in assignments[i]:
+            pseudotime.extend(np.arange(start, last + 1))
+            branches.extend([branch] * (last + 1 - start))
+    return pseudotime, branches
+
+
+def _sample_data_at_times(tree, sample_pt, branches=None, alpha=0.3, beta=2, scale=True,
+                          scale_mean=0., scale_v=0.7, **device_opts):
+    """Counts for cells at given pseudotimes (simulation.py:551-599)."""
+    no_cells = len(sample_pt)
+    if np.shape(alpha) == ():
+        alpha = [alpha] * tree.G
+    if np.shape(beta) == ():
+        beta = [beta] * tree.G
+    if branches is None:
+        branches = sut.pick_branches(tree, sample_pt)
+    scalings = sut.calc_scalings(no_cells, scale, scale_mean, scale_v)
+    expr_matrix = draw_counts(tree, sample_pt, branches, scalings, alpha, beta, **device_opts)
+    return expr_matrix, sample_pt, branches, scalings
+
+
+def cell_rows(tree, pseudotime, branches):
+    """Row of every cell in the device mean tensor: row offset of its branch plus
+    ``pseudotime - branch start`` (simulation.py:634-635), without the reference's
+    per-cell ``branch_times()`` call."""
+    bt = tree.branch_times()
+    offsets, _ = tree.row_offsets()
+    codes, uniques = pd.factorize(np.asarray(branches), sort=False)
+    start = np.empty(len(uniques), dtype=np.int64)
+    base = np.empty(len(uniques), dtype=np.int64)
+    length = np.empty(len(uniques), dtype=np.int64)
+    for i, label in enumerate(uniques):
+        key = _plain_label(tree, label)
+        start[i], base[i], length[i] = bt[key][0], offsets[key], int(tree.time[key])
+    inside = np.asarray(pseudotime, dtype=np.int64) - start[codes]
+    if len(inside) and (inside.min() < 0 or np.any(inside >= length[codes])):
+        raise IndexError("a pseudotime value lies outside its branch")
+    return (base[codes] + inside).astype(np.int32)
+
+
+def draw_counts(tree, pseudotime, branches, scalings, alpha, beta, *, seed=None, out="numpy",
+                strict=True):
+    """UMI counts of every cell and gene (simulation.py:602-651).
+
+    One launch of the fused HIP sampler: gather the cell's row of the mean tensor,
+    scale it, form the negative-binomial parameters of ``count_model.get_pr_umi`` and
+    draw.  Counts follow the reference's law, NB(n = r, p = 1 - p); the random
+    stream is the counter-based PRNB-1, not numpy's MT19937,
+    so individual values differ from the reference at equal numpy seed.
+
+    New keyword-only options
+      seed    64-bit sampler seed.  Default: two 32-bit draws from numpy's global
+              stream, so ``np.random.seed`` still determines the whole simulation.
+      out     "numpy" (default): int64 ndarray like the reference; "torch": the
+              int32 device tensor, no host copy.
+      strict  raise ``ValueError`` where scipy's argument check would (an exact-zero
+              mean, or alpha*m + beta < 1); False skips the check (no device sync).
+    """
+    no_cells = len(branches)
+    if len(pseudotime) != no_cells or len(scalings) != no_cells:
+        raise ValueError("pseudotime, branches and scalings must have one entry per cell")
+    if seed is None:
+        lo, hi = random.randint(0, 2 ** 32, size=2, dtype=np.uint64)
+        seed = int(lo) | (int(hi) << 32)
+    ctx = _device.get_context()
+    rows = cell_rows(tree, pseudotime, branches)
+    counts = ctx.sample_counts(tree.device_means(), rows, np.asarray(scalings, dtype=np.float64),
+                               np.asarray(alpha, dtype=np.float64), np.asarray(beta, dtype=np.float64),
+                               seed=seed, check_domain=strict)
+    if out == "torch":
+        return counts
+    if out != "numpy":
+        raise ValueError("out must be 'numpy' or 'torch'")
+    return counts.cpu().numpy().astype(np.int64)
+
+
+def add_non_diff_genes(inform_expr_matrix, genes, gene_params, cell_scalings, *, seed=None):
+    """Append ``genes`` non-differential genes (simulation.py:654-675): the same sampler
+    with one constant mean row; returns float64 like the reference."""
+    N, G = inform_expr_matrix.shape
+    if seed is None:
+        lo, hi = random.randint(0, 2 ** 32, size=2, dtype=np.uint64)
+        seed = int(lo) | (int(hi) << 32)
+    ctx = _device.get_context()
+    base = np.asarray(gene_params["base_expr"], dtype=np.float64).reshape(1, genes)
+    extra = ctx.sample_counts(base.astype(np.float32), np.zeros(N, dtype=np.int32),
+                              np.asarray(cell_scalings, dtype=np.float64),
+                              np.broadcast_to(np.asarray(gene_params["alpha"], dtype=np.float64), (genes,)),
+                              np.broadcast_to(np.asarray(gene_params["beta"], dtype=np.float64), (genes,)),
+                              seed=seed)
+    fusion = np.zeros((N, G + genes))
+    fusion[:, 0:G] = inform_expr_matrix
+    fusion[:, G:] = extra.cpu().numpy()
+    return fusion

@@ -1,0 +1,200 @@
+"""
+-m gpu: the drop-in Python surface (prosstt_amd.tree / simulation / sim_utils /
+count_model) end to end on the device, against the golden vectors of the real
+reference and against the oracle.
+
+Parity classes (SURVEY section 8 a/c):
+  programs, coefficients, attempt counts, (pseudotime, branch, scaling): bit-exact;
+  relative means (binary64 on device): rtol 1e-12;
+  mean tensor (binary32 storage): rtol 1.2e-7 = one binary32 rounding;
+  counts: bit-exact against the C model of the sampler on the device's own means,
+          and first-moment agreement with the reference's draw.
+"""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, tree_spec
+
+pytestmark = pytest.mark.gpu
+
+TREE_NAMES = ["bifurcation", "chain6", "chainbif7", "star5", "unequal"]
+
+
+def make_tree(spec):
+    from prosstt_amd import tree as ptree
+    return ptree.Tree(topology=spec["topology"], time=spec["time"], num_branches=len(spec["time"]),
+                      branch_points=spec["branch_points"], modules=spec["modules"], G=spec["G"])
+
+
+@pytest.mark.parametrize("name,mode", [(n, "gamma") for n in TREE_NAMES] +
+                         [("bifurcation", "beta"), ("star5", "beta")])
+def test_simulate_lineage_vs_reference(name, mode):
+    from prosstt_amd import simulation as sim
+    g = load_golden("g3_lineage_%s_%s" % (name, mode))
+    spec = tree_spec(g)
+    np.random.seed(spec["seed"])
+    t = make_tree(spec)
+    stats = []
+    rel, prog, H = sim.simulate_lineage(t, intra_branch_tol=0, stats=stats, **spec["kwargs"])
+    assert np.random.random_sample() == float(g["state_after"])      # same stream consumption
+    np.testing.assert_array_equal(H, g["H"])
+    assert len(stats) == int(g["attempts"])
+    assert [str(b) for b in rel.index] == list(g["bfs"])
+    for b in t.branches:
+        np.testing.assert_array_equal(prog[b], g["prog_%s" % b])
+        np.testing.assert_allclose(rel[b], g["rel_%s" % b], rtol=1e-12, atol=1e-13)
+        assert rel[b].dtype == np.float64 and rel[b].shape == (t.time[b], t.G)
+    # per-attempt anticorrelated-gene counts: the reference evaluates every pair of present
+    # siblings; the pairs that contain the branch under test are the ones that decide
+    ref_counts = [json.loads(s) for s in g["anticorr"]]
+    parallel = t.get_parallel_branches()
+    accepted = []
+    for idx, ((branch, top, counts), ref) in enumerate(zip(stats, ref_counts)):
+        sibs = next((list(v) for v in parallel.values() if branch in v), [branch])
+        present = sorted(s for s in sibs if s == branch or any(s == d for d in accepted))
+        pairs = [(i, j) for i in range(len(present) - 1) for j in range(i + 1, len(present))]
+        me = present.index(branch)
+        assert counts == [ref[k] for k, (i, j) in enumerate(pairs) if me in (i, j)]
+        if idx + 1 == len(stats) or stats[idx + 1][0] != branch:
+            accepted.append(branch)
+
+
+@pytest.mark.parametrize("name", ["bifurcation", "unequal", "star5"])
+def test_full_pipeline_vs_reference(name):
+    from prosstt_amd import simulation as sim, sim_utils as sut
+    from oracle import nb_model
+    g = load_golden("g6_sampling_%s" % name)
+    spec = tree_spec(g)
+    seed = spec["seed"]
+    np.random.seed(seed)
+    t = make_tree(spec)
+    rel, prog, H = sim.simulate_lineage(t, a=0.05, intra_branch_tol=0)
+    base = sut.simulate_base_gene_exp(t, rel)
+    np.testing.assert_array_equal(base, g["base"])            # same draws, same accept decisions
+    t.add_genes(rel, base)
+    for b in t.branches:
+        np.testing.assert_allclose(t.means[b], g["means_%s" % b], rtol=1.2e-7)
+    alpha = np.exp(np.random.normal(np.log(0.2), np.log(1.5), spec["G"]))
+    beta = np.exp(np.random.normal(np.log(1), np.log(1.5), spec["G"])) + 1
+    np.testing.assert_array_equal(alpha, g["alpha"])
+
+    np.random.seed(seed + 1)
+    X, pt, br, sc = sim.sample_density(t, len(g["pt"]), alpha=alpha, beta=beta, seed=1234)
+    np.testing.assert_array_equal(pt, g["pt"])
+    assert [str(b) for b in br] == list(g["br"])
+    np.testing.assert_array_equal(sc, g["scalings"])
+    assert X.dtype == np.int64 and X.shape == g["X"].shape
+    # counts: bit-exact against the C model fed with the device's own mean tensor
+    rows = sim.cell_rows(t, pt, br)
+    want = nb_model.sample_counts(t.device_means().cpu().numpy(), rows, sc, alpha, beta, 1234)
+    np.testing.assert_array_equal(X, want)
+    # and statistically indistinguishable from the reference's draw in the first moment
+    mu = g["mu"]
+    var = (alpha * mu ** 2 + beta * mu).sum()
+    assert abs(X.sum() - mu.sum()) < 6 * np.sqrt(var)
+    assert abs(g["X"].sum() - mu.sum()) < 6 * np.sqrt(var)
+    # deterministic intermediates against the reference's float64 (mu, p, r)
+    from prosstt_amd import device
+    dmu, dp, dr, _ = device.get_context().nb_params(t.device_means(), rows, sc, alpha, beta)
+    np.testing.assert_allclose(dmu.cpu().numpy(), mu, rtol=1e-6)
+    np.testing.assert_allclose(dp.cpu().numpy(), g["p"], rtol=1e-6)
+    np.testing.assert_allclose(dr.cpu().numpy(), g["r"], rtol=2e-6)
+
+    # the other samplers share the plan logic (bit-exact) and the kernel
+    np.random.seed(seed + 2)
+    X2, pt2, br2, sc2 = sim.sample_whole_tree(t, 2, alpha=alpha, beta=beta)
+    np.testing.assert_array_equal(np.array(pt2), g["wt_pt"])
+    np.testing.assert_array_equal(sc2, g["wt_sc"])
+    assert X2.shape == g["wt_X"].shape
+    np.random.seed(seed + 3)
+    X3, pt3, br3, sc3 = sim._sample_data_at_times(t, np.arange(0, t.get_max_time(), 3), alpha=alpha, beta=beta)
+    assert [str(b) for b in br3] == list(g["at_br"])
+    np.testing.assert_array_equal(sc3, g["at_sc"])
+    np.random.seed(seed + 4)
+    X4, pt4, br4, sc4 = sim.sample_pseudotime_series(t, 30, [5, 30, 60], 6.0, alpha=0.3, beta=2)
+    np.testing.assert_array_equal(pt4, g["ps_pt"])
+    assert [str(b) for b in br4] == list(g["ps_br"]) and X4.shape == g["ps_X"].shape
+    gp = dict(alpha=alpha[:7], beta=beta[:7], base_expr=base[:7])
+    nd = sim.add_non_diff_genes(X, 7, gp, sc)
+    assert nd.dtype == np.float64 and nd.shape == g["nd_X"].shape
+    np.testing.assert_array_equal(nd[:, :X.shape[1]], X)
+
+
+def test_config1_chain_200x500():
+    """BASELINE.json configs[0]: 5-branch chain x 40 steps, sample_whole_tree(t, 1) -> 200 x 500."""
+    from prosstt_amd import simulation as sim, sim_utils as sut, count_model as cm
+    g = load_golden("g8_config1_chain")
+    spec = tree_spec(g)
+    np.random.seed(92)
+    t = make_tree(spec)
+    rel, _, H = sim.simulate_lineage(t, a=0.05, intra_branch_tol=0)
+    np.testing.assert_array_equal(H, g["H"])
+    np.testing.assert_allclose(rel["E"], g["rel_E"], rtol=1e-12, atol=1e-13)
+    base = sut.simulate_base_gene_exp(t, rel)
+    np.testing.assert_array_equal(base, g["base"])
+    t.add_genes(rel, base)
+    alpha, beta = cm.generate_negbin_params(t)
+    np.testing.assert_array_equal(alpha, g["alpha"])
+    np.random.seed(93)
+    X, pt, br, sc = sim.sample_whole_tree(t, 1, alpha=alpha, beta=beta)
+    assert X.shape == (200, 500) and X.dtype == np.int64
+    np.testing.assert_array_equal(np.array(pt), g["pt"])
+    np.testing.assert_array_equal(sc, g["scalings"])
+    # same law as the reference's matrix: totals agree within sampling error
+    ref_total = int(g["total"])
+    assert abs(X.sum() - ref_total) < 0.05 * ref_total
+    assert abs((X == 0).mean() - (g["X"] == 0).mean()) < 0.02
+
+
+def test_minimal_example_and_alias():
+    """minimal_example.ipynb through the aliased import path; 4 return values."""
+    import sys
+    import prosstt_amd
+    saved = {k: v for k, v in sys.modules.items() if k == "prosstt" or k.startswith("prosstt.")}
+    try:
+        prosstt_amd.install_as_prosstt()
+        from prosstt import tree, simulation as sim
+        np.random.seed(92)
+        t = tree.Tree()
+        out = sim.sample_whole_tree_restricted(t)
+        assert len(out) == 4
+        X, pt, br, sc = out
+        g = load_golden("g8_minimal_example")
+        assert X.shape == (80, 500)
+        np.testing.assert_array_equal(pt, g["pt"])
+        assert [str(b) for b in br] == list(g["br"])
+        np.testing.assert_array_equal(sc, g["scalings"])
+        assert abs(X.sum() - int(g["total"])) < 0.1 * int(g["total"])
+        import torch
+        Xd = sim.draw_counts(t, pt, br, sc, [0.2] * t.G, [3.0] * t.G, seed=5, out="torch")
+        assert Xd.dtype == torch.int32 and Xd.is_cuda
+        with pytest.raises(ValueError):       # exact-zero mean -> scipy's domain error in the reference
+            t.means = {b: np.zeros((40, 500)) for b in t.branches}
+            sim.draw_counts(t, pt, br, sc, [0.2] * t.G, [3.0] * t.G)
+    finally:
+        for k in [k for k in sys.modules if k == "prosstt" or k.startswith("prosstt.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
+def test_sample_counts_new_name():
+    from prosstt_amd import count_model as cm
+    from oracle import nb_model
+    rng = np.random.default_rng(0)
+    mu = np.exp(rng.normal(0.5, 1.2, (50, 64)))
+    X = cm.sample_counts(mu, 0.2, 2.0, seed=9)
+    want = nb_model.sample_counts(mu.astype(np.float32), np.arange(50), np.ones(50), np.full(64, 0.2),
+                                  np.full(64, 2.0), 9)
+    np.testing.assert_array_equal(X, want)
+    assert X.dtype == np.int64
+
+
+def test_max_attempts_guard():
+    from prosstt_amd import simulation as sim
+    from prosstt_amd import tree as ptree
+    np.random.seed(1)
+    t = ptree.Tree(G=2000, modules=10)
+    with pytest.raises(RuntimeError):
+        sim.simulate_lineage(t, rel_exp_cutoff=-50, a=0.05, max_attempts=3)

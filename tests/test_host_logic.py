@@ -1,0 +1,262 @@
+"""
+CPU tests (-m "not gpu") of the product's HOST side: the Tree container, the index
+and RNG-order logic of prosstt_amd.simulation / sim_utils / count_model, checked
+bit-exact against the golden vectors of the real reference, and the C ABI surface
+(the library loads and exports every symbol include/prosstt_amd.h declares).
+No compute call is made: without a GPU the numeric entry points must raise.
+"""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden, tree_spec
+
+from prosstt_amd import tree as ptree
+from prosstt_amd import simulation as sim
+from prosstt_amd import sim_utils as sut
+from prosstt_amd import count_model as cm
+from prosstt_amd import tree_utils as tu
+from prosstt_amd import _native
+
+TREE_NAMES = ["bifurcation", "chain6", "chainbif7", "star5", "unequal"]
+
+
+def make_tree(spec, G=None, modules=None):
+    return ptree.Tree(topology=spec["topology"], time=spec["time"], num_branches=len(spec["time"]),
+                      branch_points=spec["branch_points"], modules=modules or spec["modules"],
+                      G=G or spec["G"])
+
+
+# ---- C ABI surface -------------------------------------------------------------
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "prosstt_amd.h")).read()
+    declared = set(re.findall(r"\b(prosstt_amd_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(_native.SYMBOLS)
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _native.load().prosstt_amd_version() == 100
+
+
+def test_no_cpu_fallback():
+    """Without a GPU every numeric entry point fails loudly."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    t = ptree.Tree(G=20, modules=3)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        sim.simulate_lineage(t, a=0.05)
+    t.means = {b: np.ones((40, 20)) for b in t.branches}
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        sim.draw_counts(t, np.array([0]), ["A"], np.ones(1), [0.2] * 20, [2.0] * 20)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        cm.sample_counts(np.ones((2, 3)), 0.2, 2.0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        t.add_genes({b: np.zeros((40, 20)) for b in t.branches}, np.ones(20))
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "prosstt_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("ORACLE", ""), os.path.join(dirpath, f)
+
+
+# ---- Tree container vs reference (fixture g5) --------------------------------------
+
+@pytest.mark.parametrize("name", TREE_NAMES)
+def test_tree_helpers(name):
+    g = load_golden("g5_topology")
+    rec = json.loads(str(g[name]))
+    t = make_tree(tree_spec(str(g[name + "_tree"])))
+    bt = t.branch_times()
+    assert {str(k): [int(x) for x in v] for k, v in bt.items()} == rec["branch_times"]
+    zones = t.populate_timezone()
+    assert [[int(x) for x in z] for z in zones] == rec["timezone"]
+    assign = sut.assign_branches(bt, zones)
+    assert {str(i): [str(b) for b in v] for i, v in assign.items()} == rec["assign"]
+    assert [str(b) for b in sut.breadth_first_branches(t)] == rec["bfs"]
+    assert {str(k): [str(x) for x in v] for k, v in t.get_parallel_branches().items()} == rec["parallel"]
+    assert t.get_max_time() == rec["max_time"]
+    assert abs(sum(np.sum(v) for v in t.density.values()) - rec["density_sum"]) < 1e-15
+    pt, br = sim.cover_whole_tree(t)
+    assert [int(x) for x in pt] == rec["cover"][0]
+    assert [str(x) for x in br] == rec["cover"][1]
+    offsets, rows = t.row_offsets()
+    assert rows == sum(t.time.values) and list(offsets) == t.branches
+
+
+def test_random_topology_and_default_modules():
+    g = load_golden("g5_topology")
+    np.random.seed(5)
+    np.testing.assert_array_equal(np.array(ptree.Tree.gen_random_topology(4)), g["random_topology_bp4_seed5"])
+    np.random.seed(2024)
+    np.testing.assert_array_equal(np.array(ptree.Tree.gen_random_topology(3)), g["random_topology_bp3_seed2024"])
+    np.random.seed(92)
+    assert ptree.Tree().modules == int(load_golden("g8_minimal_example")["modules"])
+
+
+def test_tree_validation():
+    with pytest.raises(ValueError):     # child listed before it exists as a branch end
+        ptree.Tree(topology=[["B", "C"], ["A", "B"]], time={"A": 5, "B": 5, "C": 5}, num_branches=3, modules=2)
+    t = ptree.Tree(G=7, modules=3)
+    with pytest.raises(ValueError):
+        t.add_genes({"A": np.ones((40, 7)), "B": np.ones((40, 7))})
+    with pytest.raises(ValueError):
+        t.add_genes({"A": np.ones((40, 7)), "B": np.ones((40, 7)), "C": np.ones((39, 7))})
+    with pytest.raises(ValueError):
+        t.set_density({"A": np.ones(40)})
+    t.add_genes({b: np.full((40, 7), 2.0) for b in t.branches})
+    assert t.means["B"].shape == (40, 7)
+    with pytest.raises(ValueError):
+        sim.simulate_lineage(ptree.Tree(num_branches=4, G=5, modules=2), a=0.05)
+
+
+def test_velocity_to_density():
+    t = ptree.Tree(G=5, modules=2)
+    t.set_velocity({b: np.linspace(-1, 2, 40) for b in t.branches})
+    total = sum(np.sum(v) for v in t.density.values())
+    assert abs(total - 1) < 1e-12 and all(np.all(v > 0) for v in t.density.values())
+
+
+# ---- RNG-order host draws vs reference -----------------------------------------------
+
+def test_walks_bit_exact():
+    g = load_golden("g2_walks")
+    for seed in (0, 1, 92):
+        for T in (2, 40, 50):
+            np.random.seed(seed)
+            np.testing.assert_array_equal(sim.diffusion(T), g["diffusion_s%d_T%d" % (seed, T)])
+    np.random.seed(7)
+    np.testing.assert_array_equal(sim.sim_expr_branch(50, 5), g["sim_expr_branch_s7_T50_K5"])
+    with pytest.raises(ValueError):
+        sim.sim_expr_branch(10, 1)
+
+
+@pytest.mark.parametrize("name,mode", [("bifurcation", "gamma"), ("star5", "beta")])
+def test_coefficients_bit_exact(name, mode):
+    g = load_golden("g3_lineage_%s_%s" % (name, mode))
+    spec = tree_spec(g)
+    np.random.seed(spec["seed"])
+    t = make_tree(spec)
+    H = sim.simulate_coefficients(t, **spec["kwargs"])
+    np.testing.assert_array_equal(H, g["H"])
+    with pytest.warns(UserWarning):
+        sim.simulate_coefficients(t)
+
+
+def test_first_root_attempt_programs_bit_exact():
+    """The first attempt of the root consumes the stream right after the coefficients."""
+    g = load_golden("g3_lineage_chain6_gamma")
+    spec = tree_spec(g)
+    if int(g["attempts"]) != len(spec["time"]):
+        pytest.skip("fixture has retries; covered on the GPU")
+    np.random.seed(spec["seed"])
+    t = make_tree(spec)
+    sim.simulate_coefficients(t, **spec["kwargs"])
+    programs = {}
+    topology = np.array(t.topology)
+    for b in sut.breadth_first_branches(t):
+        programs[b] = sim.sim_expr_branch(t.time[b], t.modules)
+        programs[b] = sut.adjust_to_parent(programs, b, topology)
+        np.testing.assert_array_equal(programs[b], g["prog_%s" % b])
+
+
+def test_params_and_scalings_bit_exact():
+    g = load_golden("g4_params")
+    t = make_tree(tree_spec(g))
+    np.random.seed(13)
+    al, be = cm.generate_negbin_params(t, mean_alpha=0.2, mean_beta=3)
+    np.testing.assert_array_equal(al, g["alpha"])
+    np.testing.assert_array_equal(be, g["beta"])
+    np.random.seed(14)
+    np.testing.assert_array_equal(sut.calc_scalings(300, True, 0.1, 0.7), g["scalings"])
+    np.testing.assert_array_equal(sut.calc_scalings(5, False), g["scalings_off"])
+    g1 = load_golden("g1_get_pr_umi")
+    p, r = cm.get_pr_umi(g1["a"], g1["b"], g1["m"])
+    np.testing.assert_array_equal(p, g1["p"])
+    np.testing.assert_array_equal(r, g1["r"])
+
+
+@pytest.mark.parametrize("name", ["bifurcation", "unequal", "star5"])
+def test_sampling_plans_bit_exact(name):
+    """(pseudotime, branch, scaling) of every sampler: integer assignments bit-exact."""
+    g = load_golden("g6_sampling_%s" % name)
+    spec = tree_spec(g)
+    t = make_tree(spec)
+    seed, N = spec["seed"], len(g["pt"])
+
+    np.random.seed(seed + 1)
+    pt, br = sim._density_plan(t, N)
+    sc = sut.calc_scalings(N)
+    np.testing.assert_array_equal(pt, g["pt"])
+    assert [str(b) for b in br] == list(g["br"])
+    np.testing.assert_array_equal(sc, g["scalings"])
+    rows = sim.cell_rows(t, pt, br)
+    offsets, _ = t.row_offsets()
+    bt = t.branch_times()
+    want = [offsets[type(t.branches[0])(b) if not isinstance(t.branches[0], str) else b] + p -
+            bt[type(t.branches[0])(b) if not isinstance(t.branches[0], str) else b][0] for p, b in zip(pt, br)]
+    np.testing.assert_array_equal(rows, np.array(want, dtype=np.int32))
+    with pytest.raises(IndexError):
+        sim.cell_rows(t, pt + 1000, br)
+
+    np.random.seed(seed + 3)
+    times = np.arange(0, t.get_max_time(), 3)
+    picked = sut.pick_branches(t, times)
+    assert [str(b) for b in picked] == list(g["at_br"])
+    np.testing.assert_array_equal(sut.calc_scalings(len(times)), g["at_sc"])
+
+    np.random.seed(seed + 4)
+    series, cells, std = sut.process_timeseries_input([5, 30, 60], 30, 6.0)
+    pts = np.concatenate([sim.draw_times(a, n, t.get_max_time(), v) for a, n, v in zip(series, cells, std)])
+    np.testing.assert_array_equal(pts, g["ps_pt"])
+    assert [str(b) for b in sut.pick_branches(t, pts)] == list(g["ps_br"])
+
+    pt2, br2 = sim.cover_whole_tree(t)
+    np.testing.assert_array_equal(np.repeat(pt2, 2), g["wt_pt"])
+    assert [str(b) for b in np.repeat(br2, 2)] == list(g["wt_br"])
+
+
+def test_pick_branch_single_matches_vector():
+    g = load_golden("g6_sampling_unequal")
+    t = make_tree(tree_spec(g))
+    zones = t.populate_timezone()
+    assign = sut.assign_branches(t.branch_times(), zones)
+    times = np.arange(0, t.get_max_time(), 7)
+    np.random.seed(3)
+    one = [sut.pick_branch(t, p, zones, assign) for p in times]
+    np.random.seed(3)
+    assert [str(b) for b in sut.pick_branches(t, times)] == [str(b) for b in one]
+
+
+def test_text_outputs(tmp_path):
+    X = np.arange(6).reshape(2, 3)
+    tu.save_matrices("job", str(tmp_path), X, {"A": np.ones((2, 3))}, np.eye(2))
+    tu.save_cell_params("job", str(tmp_path), [0, 1], ["A", "A"], [1.0, 2.0])
+    tu.save_gene_params("job", str(tmp_path), [1, 2, 3], [0.1, 0.2, 0.3], [2, 2, 2])
+    tu.save_params("job", str(tmp_path), ptree.Tree(G=3, modules=2), 7)
+    lines = open(tmp_path / "job_simulation.txt").read().splitlines()
+    assert lines[0].split("\t") == ["", "gene_0", "gene_1", "gene_2"] and lines[2].split("\t") == ["cell_1", "3", "4", "5"]
+    assert np.loadtxt(tmp_path / "job_umsA.txt").shape == (2, 3)
+    assert "Genes: 3" in open(tmp_path / "job_params.txt").read()
+
+
+def test_install_as_prosstt():
+    import sys
+    import prosstt_amd
+    saved = {k: v for k, v in sys.modules.items() if k == "prosstt" or k.startswith("prosstt.")}
+    try:
+        prosstt_amd.install_as_prosstt()
+        from prosstt import simulation as s2, tree as t2
+        assert s2 is sim and t2 is ptree
+    finally:
+        for k in [k for k in sys.modules if k == "prosstt" or k.startswith("prosstt.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
