@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""
+bench.py -- simulated cells x genes / second of the PROSSTT sampling hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json metric): config C3 -- 8-branch tree (T = 50 per branch, K = 25
+programs), 20 000 genes, 50 000 cells PER GPU; the tree goes through the product's own
+lineage stage on the device (timed separately, not part of the metric), the cells are drawn
+from the tree's density.  A *step* = one pass of the fused count sampler
+(prosstt_amd_sample_counts: parameter prep kernel + K3) over the rank's cells, all inputs
+resident in HBM, output left in HBM.  With N GPUs the plan has 50 000 x N cells sharded by
+branch (prosstt_amd.parallel), no collective on the data path: weak scaling.
+
+One JSON line on rank 0.  `roofline` is for the dominant kernel (sample_counts_kernel):
+algorithmic bytes per launch / its mean duration from HIP events on the
+launch stream.  `cpu_baseline` (N = 1 only) times the oracle's numpy restatement of the
+reference's draw_counts (1 core, as the reference is single-threaded) on a bounded sample
+of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12      # B/s, MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(n_cells, G, rows):
+    """4 B/count written once + the mean tensor read once + per-gene and per-cell vectors
+    (SURVEY.md section 8 d)."""
+    return 4 * n_cells * G + 4 * rows * G + 8 * G + 8 * n_cells
+
+
+def cpu_baseline(work, pt, br, sc, cells):
+    """Reference-equivalent CPU path: oracle/ref_numpy.draw_counts (bit-identical to the real
+    reference at equal seed, tests/test_oracle_golden.py) on the first `cells` cells, 1 core."""
+    from oracle import ref_numpy
+    tree = work.tree
+    ref = ref_numpy.RefTree(tree.topology, {b: int(tree.time[b]) for b in tree.branches},
+                            modules=tree.modules, G=tree.G)
+    ref.means = tree.means                      # host float64 view of the device tensor
+    np.random.seed(12345)
+    # chunks of 500 cells keep the reference's ~77 B per cell x gene of temporaries bounded
+    done, t0 = 0, time.perf_counter()
+    for lo in range(0, cells, 500):
+        hi = min(lo + 500, cells)
+        x = ref_numpy.draw_counts(ref, pt[lo:hi], list(br[lo:hi]), sc[lo:hi], work.alpha, work.beta)
+        done += x.size
+    dt = time.perf_counter() - t0
+    return dict(value=done / dt, unit="cells*genes/s", cores=1, kind="port",
+                sample="oracle/ref_numpy.draw_counts (numpy restatement of simulation.py:602-651, "
+                       "RandomState.negative_binomial) on the first %d cells x %d genes of the same plan, "
+                       "%.1f s" % (cells, tree.G, dt),
+                host_cpus=os.cpu_count())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4"])
+    ap.add_argument("--cells-per-gpu", type=int, default=None)
+    ap.add_argument("--cpu-cells", type=int, default=1500, help="cells timed by the CPU baseline (0 = skip)")
+    ap.add_argument("--gather", action="store_true", help="also time the optional row gather to rank 0")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                     "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from prosstt_amd import device, parallel, workloads
+    ctx = device.get_context(local)
+
+    # ---- build the tree through the product's lineage stage (not part of the metric) -------
+    work = workloads.build(args.config)
+    tree, G = work.tree, work.tree.G
+    rows_total = work.info["rows"]
+    per_gpu = args.cells_per_gpu or work.cfg["N"]
+    n_total = per_gpu * world
+    pt, br, sc, rows = work.plan(n_total)
+    mine, owner = parallel.shard_cells(br, rank, world)
+
+    means = tree.device_means()
+    d_rows = ctx.tensor(rows[mine], torch.int32)
+    d_sc = ctx.tensor(sc[mine], torch.float64)
+    d_al = ctx.tensor(work.alpha, torch.float64)
+    d_be = ctx.tensor(work.beta, torch.float64)
+    d_idx = ctx.tensor(mine, torch.int64)
+    out = torch.empty((len(mine), G), dtype=torch.int32, device=ctx.torch_device)
+
+    def step(seed, timed=False):
+        ctx.sample_counts(means, d_rows, d_sc, d_al, d_be, seed=seed, out=out, cell_index=d_idx,
+                          check_domain=False, time_kernel=timed)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(1000 + i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, timed=True)                    # HIP events bracket K3 on the launch stream
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = [ctx.last_kernel_ms()]         # mean over the K launches of the timed region
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=ctx.torch_device)
+    k_max = torch.tensor([float(np.mean(kernel_ms))], dtype=torch.float64, device=ctx.torch_device)
+    if world > 1:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(k_max, op=dist.ReduceOp.MAX)
+    elapsed = float(t_max.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = n_total * G / (elapsed / args.steps)
+
+    gather_ms = None
+    if args.gather:
+        fence()
+        t0 = time.perf_counter()
+        full = parallel.gather_rows(out, mine, n_total)
+        fence()
+        gather_ms = (time.perf_counter() - t0) * 1e3
+        del full
+
+    # sanity inside the bench: first moment of this rank's shard (catches a silently dead kernel)
+    mu_sum = float((means.double().sum(dim=1)[d_rows.long()] * d_sc).sum())
+    x_sum = float(out.sum(dtype=torch.float64))
+    ratio = x_sum / mu_sum
+
+    if rank == 0:
+        kms = float(np.mean(kernel_ms))
+        abytes = algorithmic_bytes(len(mine), G, rows_total)
+        achieved = abytes / (kms * 1e-3)
+        line = {
+            "metric": "simulated cells*genes per second (count sampling: sample_density -> draw_counts)",
+            "value": value, "unit": "cells*genes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %d-branch tree (T=50, K=25), %d genes, %d cells per GPU "
+                                   "(%d total), density sampling; lineage via the product pipeline"
+                                   % (args.config, work.info["branches"], G, per_gpu, n_total),
+                       "parallelism": "cells sharded by branch, %d rank(s), no data-path collective" % world,
+                       "lineage_attempts": work.info["attempts"], "lineage_s": round(work.info["lineage_s"], 3),
+                       "sum_counts_over_sum_means": round(ratio, 5)},
+            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK, "traffic": None,
+                         "kernel": "sample_counts_kernel<true>", "kernel_ms": kms,
+                         "algorithmic_bytes_per_launch": abytes,
+                         "note": "VALU-bound exact sampler: see DESIGN.md section 6 and profiles/"},
+        }
+        if gather_ms is not None:
+            line["gather_ms"] = gather_ms
+        if world == 1 and args.cpu_cells > 0:
+            line["cpu_baseline"] = cpu_baseline(work, pt, br, sc, min(args.cpu_cells, n_total))
+            line["speedup_vs_cpu_1core"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -55,7 +55,8 @@ int prosstt_amd_device_count(int* count);
 int prosstt_amd_ctx_create(int device, void* stream, prosstt_amd_ctx** out);
 int prosstt_amd_ctx_destroy(prosstt_amd_ctx* ctx);
 int prosstt_amd_ctx_synchronize(prosstt_amd_ctx* ctx);
-/* elapsed ms of the last kernel launched with PROSSTT_AMD_TIME_KERNEL (synchronises on it) */
+/* mean duration (ms) of the main kernels launched with PROSSTT_AMD_TIME_KERNEL since the
+ * previous call (HIP events on the ctx stream); synchronises on the last of them */
 int prosstt_amd_last_kernel_ms(prosstt_amd_ctx* ctx, float* ms);
 
 /*
@@ -66,17 +67,21 @@ int prosstt_amd_last_kernel_ms(prosstt_amd_ctx* ctx, float* ms);
  * out[n*ld_out + g] ~ NB(mean m, variance alpha*m^2 + beta*m),
  *   m = means[row_of_cell[n]*G + g] * scaling[n],
  * drawn by the PRNB-1 counter-based sampler keyed by
- * (seed, cell_offset + n, g).
+ * (seed, global cell id, g); the global id of cell n is cell_index[n] when
+ * cell_index is given, cell_offset + n otherwise.
  *   means        [rows][G] binary32, row-major: the (branch, time, gene) mean tensor
  *   row_of_cell  [N] row of every cell = row offset of its branch + time inside the branch
  *   scaling      [N] library-size factor (sim_utils.calc_scalings, sim_utils.py:473-498)
  *   alpha, beta  [G] variance hyper-parameters
+ *   cell_index   [N] global id of every cell, or NULL (a shard of a larger plan passes
+ *                the positions of its cells in that plan: results do not depend on sharding)
  *   out          [N][ld_out] int32 counts (the reference returns int64)
  */
 int prosstt_amd_sample_counts(prosstt_amd_ctx* ctx, const float* means, int64_t rows, int32_t G,
                               const int32_t* row_of_cell, const double* scaling,
                               const double* alpha, const double* beta, int64_t N, uint64_t seed,
-                              uint64_t cell_offset, int32_t* out, int64_t ld_out, uint32_t flags);
+                              uint64_t cell_offset, const int64_t* cell_index, int32_t* out,
+                              int64_t ld_out, uint32_t flags);
 
 /*
  * The deterministic intermediates of the same path (simulation.py:633-645,

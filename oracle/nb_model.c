@@ -349,7 +349,7 @@ PRNB_EXPORT PRNB_CLONES void prnb_sample_counts(const float* means, int64_t rows
                                                 const int32_t* row_of_cell, const double* scaling,
                                                 const double* alpha, const double* beta, int64_t N,
                                                 uint64_t seed, uint64_t cell_offset,
-                                                int32_t* out, int64_t ld)
+                                                const int64_t* cell_index, int32_t* out, int64_t ld)
 {
     (void)rows;
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
@@ -359,7 +359,8 @@ PRNB_EXPORT PRNB_CLONES void prnb_sample_counts(const float* means, int64_t rows
         float s = (float)scaling[n];
         for (int32_t g = 0; g < G; ++g)
             out[n * ld + g] = prnb_one(mrow[g], s, GENE_A(alpha, g), GENE_BM1(beta, g), k0, k1,
-                                       cell_offset + (uint64_t)n, (uint32_t)g, 0);
+                                       cell_index ? (uint64_t)cell_index[n] : cell_offset + (uint64_t)n,
+                                       (uint32_t)g, 0);
     }
 }
 

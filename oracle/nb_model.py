@@ -32,7 +32,7 @@ def lib():
         L.prnb_math.argtypes = [ctypes.c_int, _f32p, _f32p, ctypes.c_int64]
         L.prnb_sample_counts.argtypes = [_f32p, ctypes.c_int64, ctypes.c_int32, _i32p, _f64p, _f64p,
                                          _f64p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64,
-                                         _i32p, ctypes.c_int64]
+                                         ctypes.c_void_p, _i32p, ctypes.c_int64]
         L.prnb_nb_params.argtypes = [_f32p, ctypes.c_int64, ctypes.c_int32, _i32p, _f64p, _f64p, _f64p,
                                      ctypes.c_int64, _f32p, _f32p, _f32p, _i32p]
         L.prnb_sample_iid.argtypes = [ctypes.c_float, ctypes.c_double, ctypes.c_double, ctypes.c_uint64,
@@ -59,15 +59,18 @@ def math(which, x):
     return y
 
 
-def sample_counts(means, row_of_cell, scaling, alpha, beta, seed, cell_offset=0):
+def sample_counts(means, row_of_cell, scaling, alpha, beta, seed, cell_offset=0, cell_index=None):
     means = np.ascontiguousarray(means, np.float32)
     rows, G = means.shape
     row_of_cell = np.ascontiguousarray(row_of_cell, np.int32)
     N = row_of_cell.size
     out = np.empty((N, G), np.int32)
+    if cell_index is not None:
+        cell_index = np.ascontiguousarray(cell_index, np.int64)
     lib().prnb_sample_counts(means, rows, G, row_of_cell, np.ascontiguousarray(scaling, np.float64),
                              np.ascontiguousarray(alpha, np.float64),
-                             np.ascontiguousarray(beta, np.float64), N, seed, cell_offset, out, G)
+                             np.ascontiguousarray(beta, np.float64), N, seed, cell_offset,
+                             cell_index.ctypes.data if cell_index is not None else None, out, G)
     return out
 
 

@@ -57,7 +57,7 @@ def load():
         L.prosstt_amd_ctx_synchronize.argtypes = [vp]
         L.prosstt_amd_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
         L.prosstt_amd_sample_counts.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp, i64, u64, u64,
-                                                vp, i64, u32]
+                                                vp, vp, i64, u32]
         L.prosstt_amd_nb_params.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp, u32]
         L.prosstt_amd_lineage_attempt.argtypes = [vp, vp, i32, i32, vp, i64, i32, vp, vp, vp, vp]
         L.prosstt_amd_lineage_commit.argtypes = [vp, vp, i32, i32, vp, i64, vp, vp]

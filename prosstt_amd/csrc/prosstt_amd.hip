@@ -52,9 +52,25 @@ struct prosstt_amd_ctx {
     size_t ws_bytes = 0;
     int64_t* scratch = nullptr;  // device: [0] domain flag, [1] max bits, [2..] counters
     int64_t* h_scratch = nullptr;  // pinned mirror
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
+    std::vector<hipEvent_t> events;  // (start, stop) pairs of kernels launched with TIME_KERNEL
+    size_t events_used = 0;
 };
+
+// next (start, stop) event pair of the ctx's pool
+static int next_event_pair(prosstt_amd_ctx* c, hipEvent_t* a, hipEvent_t* b)
+{
+    if (c->events_used + 2 > c->events.size()) {
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        c->events.push_back(e0);
+        c->events.push_back(e1);
+    }
+    *a = c->events[c->events_used];
+    *b = c->events[c->events_used + 1];
+    c->events_used += 2;
+    return 0;
+}
 constexpr int kScratchWords = 64;
 
 static int ws_reserve(prosstt_amd_ctx* c, size_t bytes)
@@ -122,8 +138,8 @@ template <bool VEC>
 __global__ __launch_bounds__(kBlock) void sample_counts_kernel(
     const float* __restrict__ means, int32_t G, const int32_t* __restrict__ row_of_cell,
     const float* __restrict__ scal, const float* __restrict__ ga, const float* __restrict__ gbm1,
-    int64_t N, uint32_t k0, uint32_t k1, uint64_t cell_offset, int32_t* __restrict__ out,
-    int64_t ld, int64_t* __restrict__ domain_flag, int32_t tiles_c)
+    int64_t N, uint32_t k0, uint32_t k1, uint64_t cell_offset, const int64_t* __restrict__ cell_index,
+    int32_t* __restrict__ out, int64_t ld, int64_t* __restrict__ domain_flag, int32_t tiles_c)
 {
     __shared__ float inv_k[prnb::kKTab];
     __shared__ int32_t tile[kTileC][kTileG];
@@ -157,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void sample_counts_kernel(
         if (n >= N || g0 >= G) continue;
         const int64_t row = row_of_cell[n];
         const float s = scal[n];
-        const uint64_t cell = cell_offset + (uint64_t)n;
+        const uint64_t cell = cell_index ? (uint64_t)cell_index[n] : cell_offset + (uint64_t)n;
         const uint32_t c0 = (uint32_t)cell, c1 = (uint32_t)(cell >> 32);
         float M[4];
         if (VEC) {
@@ -193,7 +209,7 @@ __global__ __launch_bounds__(kBlock) void sample_counts_kernel(
         const int cl = idx >> 8, gl = idx & (kTileG - 1);
         const int64_t n = n0 + cl;
         const int32_t g = tile_g * kTileG + gl;
-        const uint64_t cell = cell_offset + (uint64_t)n;
+        const uint64_t cell = cell_index ? (uint64_t)cell_index[n] : cell_offset + (uint64_t)n;
         const prnb::Params P =
             prnb::make_params(means[(int64_t)row_of_cell[n] * G + g], scal[n], ga[g], gbm1[g]);
         tile[cl][gl] = prnb::heavy_draw(P, (uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)g, k0,
@@ -378,8 +394,7 @@ PA_EXPORT int prosstt_amd_ctx_create(int device, void* stream, prosstt_amd_ctx**
     c->device = device;
     c->stream = (hipStream_t)stream;   // NULL = the device's default stream
     if (hipMalloc((void**)&c->scratch, kScratchWords * 8) != hipSuccess ||
-        hipHostMalloc((void**)&c->h_scratch, kScratchWords * 8) != hipSuccess ||
-        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        hipHostMalloc((void**)&c->h_scratch, kScratchWords * 8) != hipSuccess) {
         prosstt_amd_ctx_destroy(c);
         return fail(PROSSTT_AMD_EHIP, "ctx allocation failed");
     }
@@ -395,8 +410,7 @@ PA_EXPORT int prosstt_amd_ctx_destroy(prosstt_amd_ctx* c)
     if (c->ws) (void)hipFree(c->ws);
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->h_scratch) (void)hipHostFree(c->h_scratch);
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     delete c;
     return 0;
 }
@@ -411,9 +425,17 @@ PA_EXPORT int prosstt_amd_ctx_synchronize(prosstt_amd_ctx* c)
 PA_EXPORT int prosstt_amd_last_kernel_ms(prosstt_amd_ctx* c, float* ms)
 {
     if (!c || !ms) return fail(PROSSTT_AMD_EINVAL, "NULL argument");
-    if (!c->timed) return fail(PROSSTT_AMD_EINVAL, "no kernel was launched with PROSSTT_AMD_TIME_KERNEL");
-    HIP_TRY(hipEventSynchronize(c->ev1));
-    HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    if (c->events_used == 0)
+        return fail(PROSSTT_AMD_EINVAL, "no kernel was launched with PROSSTT_AMD_TIME_KERNEL since the last call");
+    HIP_TRY(hipEventSynchronize(c->events[c->events_used - 1]));
+    double total = 0.0;
+    for (size_t i = 0; i < c->events_used; i += 2) {
+        float one = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&one, c->events[i], c->events[i + 1]));
+        total += one;
+    }
+    *ms = (float)(total / (double)(c->events_used / 2));
+    c->events_used = 0;
     return 0;
 }
 
@@ -472,8 +494,8 @@ static int sampler_setup(prosstt_amd_ctx* c, Staging& st, const float* means, in
 PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, int64_t rows, int32_t G,
                                         const int32_t* row_of_cell, const double* scaling,
                                         const double* alpha, const double* beta, int64_t N,
-                                        uint64_t seed, uint64_t cell_offset, int32_t* out,
-                                        int64_t ld_out, uint32_t flags)
+                                        uint64_t seed, uint64_t cell_offset, const int64_t* cell_index,
+                                        int32_t* out, int64_t ld_out, uint32_t flags)
 {
     Staging st;
     SamplerArgs A{};
@@ -483,6 +505,11 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
     if (!out) return fail(PROSSTT_AMD_EINVAL, "out is NULL");
     if (ld_out < G) return fail(PROSSTT_AMD_EINVAL, "ld_out %lld < G %d", (long long)ld_out, G);
 
+    if (cell_index && (flags & PROSSTT_AMD_HOST_INPUTS)) {
+        const void* d;
+        if ((rc = st.upload(cell_index, (size_t)N * 8, &d, c->stream))) return rc;
+        cell_index = (const int64_t*)d;
+    }
     int32_t* d_out = out;
     if (flags & PROSSTT_AMD_HOST_OUTPUT) {
         void* p = nullptr;
@@ -498,20 +525,21 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
                      (((uintptr_t)d_out & 15) == 0);
     const dim3 grid((unsigned)(tiles_c * tiles_g)), block(kBlock);
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    if (flags & PROSSTT_AMD_TIME_KERNEL) HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    if (flags & PROSSTT_AMD_TIME_KERNEL) {
+        if ((rc = next_event_pair(c, &ev_start, &ev_stop))) return rc;
+        HIP_TRY(hipEventRecord(ev_start, c->stream));
+    }
     if (vec)
         sample_counts_kernel<true><<<grid, block, 0, c->stream>>>(A.means, G, A.row_of_cell, A.scal, A.ga,
-                                                                 A.gbm1, N, k0, k1, cell_offset, d_out,
-                                                                 ld_out, c->scratch, (int32_t)tiles_c);
+                                                                 A.gbm1, N, k0, k1, cell_offset, cell_index,
+                                                                 d_out, ld_out, c->scratch, (int32_t)tiles_c);
     else
         sample_counts_kernel<false><<<grid, block, 0, c->stream>>>(A.means, G, A.row_of_cell, A.scal, A.ga,
-                                                                  A.gbm1, N, k0, k1, cell_offset, d_out,
-                                                                  ld_out, c->scratch, (int32_t)tiles_c);
+                                                                  A.gbm1, N, k0, k1, cell_offset, cell_index,
+                                                                  d_out, ld_out, c->scratch, (int32_t)tiles_c);
     HIP_TRY(hipGetLastError());
-    if (flags & PROSSTT_AMD_TIME_KERNEL) {
-        HIP_TRY(hipEventRecord(c->ev1, c->stream));
-        c->timed = true;
-    }
+    if (flags & PROSSTT_AMD_TIME_KERNEL) HIP_TRY(hipEventRecord(ev_stop, c->stream));
     if (flags & PROSSTT_AMD_HOST_OUTPUT)
         HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)N * ld_out * 4, hipMemcpyDeviceToHost, c->stream));
     if (flags & PROSSTT_AMD_CHECK_DOMAIN) {

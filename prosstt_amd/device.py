@@ -72,7 +72,7 @@ class Context:
 
     # ---- K3: fused count sampler -------------------------------------------
     def sample_counts(self, means, row_of_cell, scaling, alpha, beta, seed, cell_offset=0,
-                      out=None, check_domain=True, time_kernel=False):
+                      out=None, check_domain=True, time_kernel=False, cell_index=None):
         """int32 device tensor (N, G) of counts; see prosstt_amd_sample_counts."""
         torch = _torch()
         means = self.tensor(means, torch.float32)
@@ -88,10 +88,14 @@ class Context:
             out = torch.empty((N, G), dtype=torch.int32, device=self.torch_device)
         elif out.dtype != torch.int32 or out.shape != (N, G) or out.stride(1) != 1:
             raise ValueError("out must be an int32 (N, G) tensor with unit column stride")
+        if cell_index is not None:
+            cell_index = self.tensor(cell_index, torch.int64)
+            if cell_index.numel() != N:
+                raise ValueError("cell_index must have one entry per cell")
         flags = (_native.CHECK_DOMAIN if check_domain else 0) | (_native.TIME_KERNEL if time_kernel else 0)
         _native.check(self._lib.prosstt_amd_sample_counts(
             self._h, _ptr(means), rows, G, _ptr(row_of_cell), _ptr(scaling), _ptr(alpha), _ptr(beta),
-            N, ctypes.c_uint64(seed & (2 ** 64 - 1)), ctypes.c_uint64(cell_offset),
+            N, ctypes.c_uint64(seed & (2 ** 64 - 1)), ctypes.c_uint64(cell_offset), _ptr(cell_index),
             _ptr(out), out.stride(0) if N else G, flags))
         return out
 
