@@ -46,6 +46,11 @@ def load():
                 "%s not found: build it with `make -C prosstt_amd/csrc` (or "
                 "`python -c 'import __graft_entry__ as g; g.build()'`). prosstt_amd has no "
                 "CPU fallback." % LIB_PATH)
+        # torch first: it bundles its own libamdhip64.so.7, and the dynamic loader shares one
+        # copy per SONAME.  Loading ours first would bind torch to /opt/rocm's runtime instead;
+        # either way both must sit on ONE HIP runtime for streams and device pointers to be
+        # exchangeable, and torch's own is the combination the wheel was built against.
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         vp, i32, i64, u32, u64 = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
                                   ctypes.c_uint32, ctypes.c_uint64)

@@ -1,0 +1,133 @@
+"""
+CPU tests of oracle/nb_model.c, the scalar C model of the device count sampler (PRNB-1):
+known-answer vectors of Philox4x32-10, accuracy of the deterministic binary32 math, and the
+LAW of the sampler against the reference's distribution (scipy.stats.nbinom tables of fixture
+g7 and the oracle's numpy path).  The HIP kernel is then held bit-exact to this model (-m gpu).
+"""
+import numpy as np
+import pytest
+from scipy import stats
+
+from conftest import load_golden
+from oracle import nb_model as nm
+from oracle import ref_numpy
+
+
+def test_philox_known_answers():
+    """Random123 kat_vectors for philox4x32-10."""
+    kat = [([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+           ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+            [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+    for ctr, key, want in kat:
+        assert list(nm.philox(ctr, key)) == want
+
+
+def test_deterministic_math_accuracy():
+    rng = np.random.default_rng(0)
+    x = np.exp(rng.uniform(-40, 40, 400000)).astype(np.float32)
+    assert np.max(np.abs(nm.math("rcp", x) * x.astype(np.float64) - 1)) < 1.2e-7
+    ref = np.log(x.astype(np.float64))
+    assert np.max(np.abs(nm.math("log", x) - ref) / np.maximum(np.abs(ref), 1e-3)) < 2e-7
+    t = np.concatenate([x[x < 1e6], rng.uniform(0, 2, 200000).astype(np.float32)])
+    assert np.max(np.abs(nm.math("log1p", t) / np.log1p(t.astype(np.float64)) - 1)) < 2.5e-7
+    e = -rng.uniform(0, 87, 400000).astype(np.float32)
+    assert np.max(np.abs(nm.math("exp", e) / np.exp(e.astype(np.float64)) - 1)) < 2e-7
+    assert nm.math("exp", np.array([-88.0, -1e9], np.float32)).tolist() == [0.0, 0.0]
+    w = rng.integers(0, 2 ** 32, 400000, dtype=np.uint64).astype(np.uint32)
+    c = nm.math("cos2pi", w.view(np.float32))
+    assert np.max(np.abs(c - np.cos(2 * np.pi * w.astype(np.float64) / 2 ** 32))) < 3e-7
+    d = rng.uniform(-0.9, 3, 400000).astype(np.float32)
+    ref = np.log1p(d.astype(np.float64)) - d.astype(np.float64)
+    assert np.max(np.abs(nm.math("log1pmx", d) - ref) / np.abs(ref).clip(1e-30)) < 3e-6
+    u = nm.math("unif", np.array([0, 1, 2 ** 31, 2 ** 32 - 1], np.uint32).view(np.float32))
+    assert u[0] > 0 and u[-1] <= 1.0 and abs(u[2] - 0.5) < 1e-7
+
+
+def pooled_chi2(x, pmf, n):
+    kmax = len(pmf)
+    cnt = np.bincount(np.minimum(x, kmax - 1), minlength=kmax).astype(float)
+    exp = pmf * n
+    exp[-1] += n * max(0.0, 1 - pmf.sum())
+    obs_b, exp_b, co, ce = [], [], 0.0, 0.0
+    for k in range(kmax):
+        co += cnt[k]
+        ce += exp[k]
+        if ce >= 50:
+            obs_b.append(co); exp_b.append(ce); co = ce = 0.0
+    obs_b[-1] += co
+    exp_b[-1] += ce
+    obs_b, exp_b = np.array(obs_b), np.array(exp_b)
+    return stats.chi2.sf(((obs_b - exp_b) ** 2 / exp_b).sum(), len(obs_b) - 1)
+
+
+def test_law_against_scipy_tables():
+    """Each (m, a, b) of fixture g7 (light path, both Poisson branches of the heavy path, the
+    Poisson limit beta = 1+1e-8, r < 1, alpha = 0): chi-square vs nbinom(n=r, p=1-p).pmf,
+    mean within 6 SE, variance within 8 %."""
+    g = load_golden("g7_nb_tables")
+    n = 1_000_000
+    pvals = []
+    for i, (m, a, b, r, p, mean, var) in enumerate(g["params"]):
+        x = nm.sample_iid(m, a, b, n, seed=1234 + i, gene=i)
+        assert abs(x.mean() - mean) < 6 * np.sqrt(var / n) + 2e-6 * mean, (m, a, b)
+        assert abs(x.var() / var - 1) < 0.08, (m, a, b)
+        pvals.append(pooled_chi2(x, g["pmf"][i].copy(), n))
+    assert min(pvals) > 1e-4 / len(pvals), pvals
+
+
+def test_zero_fraction_matches_closed_form():
+    """P(X = 0) = (1+theta)^(-r) over a grid of small means (the dominant outcome: ~50 % zeros)."""
+    n = 400_000
+    for m, a, b in [(0.01, 0.2, 2.0), (0.3, 0.1, 1.5), (2.0, 0.5, 3.0), (11.0, 0.2, 2.0), (25.0, 0.3, 2.0)]:
+        theta = a * m + b - 1
+        p0 = (1 + theta) ** (-m / theta)
+        x = nm.sample_iid(m, a, b, n, seed=5)
+        assert abs((x == 0).mean() - p0) < 5 * np.sqrt(p0 * (1 - p0) / n) + 1e-6
+
+
+def test_matrix_entry_is_pure_function_of_global_cell_and_gene():
+    rng = np.random.default_rng(3)
+    means = np.exp(rng.normal(0.5, 1.5, (9, 40))).astype(np.float32)
+    roc = rng.integers(0, 9, 50).astype(np.int32)
+    sc = np.exp(rng.normal(0, 0.7, 50))
+    al, be = np.full(40, 0.2), np.full(40, 2.0)
+    full = nm.sample_counts(means, roc, sc, al, be, 11)
+    part = nm.sample_counts(means, roc[20:], sc[20:], al, be, 11, cell_offset=20)
+    np.testing.assert_array_equal(full[20:], part)
+    idx = np.array([7, 3, 44])
+    picked = nm.sample_counts(means, roc[idx], sc[idx], al, be, 11, cell_index=idx)
+    np.testing.assert_array_equal(full[idx], picked)
+    assert not np.array_equal(full, nm.sample_counts(means, roc, sc, al, be, 12))
+
+
+def test_model_vs_reference_draw_on_a_real_tree():
+    """Same (means, plan) as fixture g6: the model's matrix and the reference's matrix (numpy
+    stream) agree in total, zero fraction and per-gene means within sampling error; the
+    deterministic (mu, p, r) agree to binary32 rounding."""
+    g = load_golden("g6_sampling_unequal")
+    order = ["A", "B", "C", "D", "E"]
+    means = np.concatenate([g["means_%s" % b] for b in order])
+    offsets = np.cumsum([0] + [g["means_%s" % b].shape[0] for b in order])
+    starts = {"A": 0, "B": 70, "C": 70, "D": 130, "E": 130}
+    rows = np.array([offsets[order.index(b)] + p - starts[b] for p, b in zip(g["pt"], g["br"])], np.int32)
+    mu, p, r, path = nm.nb_params(means.astype(np.float32), rows, g["scalings"], g["alpha"], g["beta"])
+    np.testing.assert_allclose(mu, g["mu"], rtol=1e-6)
+    np.testing.assert_allclose(p, g["p"], rtol=1e-6)
+    np.testing.assert_allclose(r, g["r"], rtol=2e-6)
+    reps = 200
+    tot = np.array([nm.sample_counts(means.astype(np.float32), rows, g["scalings"], g["alpha"], g["beta"], s).sum()
+                    for s in range(reps)])
+    var = (g["alpha"] * g["mu"] ** 2 + g["beta"] * g["mu"]).sum()
+    assert abs(tot.mean() - g["mu"].sum()) < 5 * np.sqrt(var / reps)
+    assert abs(g["X"].sum() - g["mu"].sum()) < 5 * np.sqrt(var)
+    assert abs(tot.std() / np.sqrt(var) - 1) < 0.25
+
+
+def test_degenerate_parameters():
+    z = nm.sample_iid(0.0, 0.2, 2.0, 100)
+    assert not z.any()
+    assert not nm.sample_iid(3.0, 0.0, 1.0, 100).any()          # alpha=0, beta=1: zeros, as in the reference
+    assert not nm.sample_iid(3.0, 0.0, 0.5, 100).any()          # theta < 0: 0 (the wrapper raises ValueError)
+    big = nm.sample_iid(3.0e5, 0.3, 2.0, 2000, seed=1)           # far beyond abs_max=5000 x scaling
+    assert abs(big.mean() / 3.0e5 - 1) < 0.05 and big.min() >= 0
