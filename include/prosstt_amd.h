@@ -43,6 +43,8 @@ enum {
 #define PROSSTT_AMD_HOST_OUTPUT  2u /* every output array is a host pointer */
 #define PROSSTT_AMD_CHECK_DOMAIN 4u /* synchronise and return EDOMAIN like scipy's argument check */
 #define PROSSTT_AMD_TIME_KERNEL  8u /* bracket the main kernel with HIP events (last_kernel_ms) */
+#define PROSSTT_AMD_KERNEL_TILED 16u /* sample_counts: use the tile-per-block kernel instead of the
+                                        streaming one (same results; kept for A/B measurements) */
 
 typedef struct prosstt_amd_ctx prosstt_amd_ctx;
 

@@ -181,9 +181,9 @@ __attribute__((constructor)) static void prnb_init(void)
  *   P(k) = P(k-1) * (mp + (k-1)*q) / k      (NB: mp = m/(1+theta), q = theta/(1+theta);
  *                                            Poisson: mp = lambda, q = 0)
  * `w` is the 32-bit uniform.  If the pmf falls below 2^-32 before w is used up
- * (mass lost to rounding, < 1e-6) the draw falls back to floor(mean).
+ * (mass lost to rounding, < 1e-6) the draw falls back to floor(mp), a value in the bulk.
  */
-static inline int32_t chop_down(uint32_t w, float p0, float mp, float q, float mean)
+static inline int32_t chop_down(uint32_t w, float p0, float mp, float q)
 {
     float p = fminf(p0, 0.99999994f);
     uint32_t rem = w;
@@ -191,7 +191,7 @@ static inline int32_t chop_down(uint32_t w, float p0, float mp, float q, float m
     for (int k = 0; ; ) {
         uint32_t pf = (uint32_t)(p * 4294967296.0f);
         if (rem < pf) return k;
-        if (pf == 0u || k == PRNB_KTAB - 1) return (int32_t)mean;
+        if (pf == 0u || k == PRNB_KTAB - 1) return (int32_t)mp;
         rem -= pf;
         float num = FMA(kf, q, mp);
         ++k; kf += 1.0f;
@@ -207,7 +207,7 @@ static inline int32_t poisson_draw(float lam, uint32_t c0, uint32_t c1, uint32_t
     if (!(lam > 0.0f)) return 0;
     if (lam < PRNB_POIS_INV) {
         philox4x32_10(c0, c1, gene, 0x80000000u, k0, k1, w);
-        return chop_down(w[0], det_exp(-lam), lam, 0.0f, lam);
+        return chop_down(w[0], det_exp(-lam), lam, 0.0f);
     }
     float slam = sqrtf(lam);
     if (!(lam < PRNB_LAM_BIG)) {               /* rounded normal; never reached with abs_max=5000 */
@@ -302,7 +302,7 @@ static inline int32_t prnb_one(float M, float s, float a, float bm1, uint32_t k0
         if (det) det->path = 1;
         philox4x32_10(c0, c1, gene >> 2, 0u, k0, k1, w);
         float t = m * (det_log1p(theta) * inv_th);
-        return chop_down(w[gene & 3u], det_exp(-t), m * inv_u1, q, m);
+        return chop_down(w[gene & 3u], det_exp(-t), m * inv_u1, q);
     }
     if (det) det->path = 2;
     if (!(r >= PRNB_R_MIN)) return 0;

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libprosstt_amd.so")
 
 OK, EINVAL, EDOMAIN, EHIP, ENOMEM, ENODEV = 0, -1, -2, -3, -4, -5
-HOST_INPUTS, HOST_OUTPUT, CHECK_DOMAIN, TIME_KERNEL = 1, 2, 4, 8
+HOST_INPUTS, HOST_OUTPUT, CHECK_DOMAIN, TIME_KERNEL, KERNEL_TILED = 1, 2, 4, 8, 16
 
 # every symbol include/prosstt_amd.h declares
 SYMBOLS = [

@@ -1,0 +1,263 @@
+// K3, streaming form: the fused count sampler as a three-stage pipeline run by each wave
+// on its own strip of the count matrix, with LDS stacks between the stages so that every
+// stage executes with (nearly) all 64 lanes busy.
+//
+// The scalar algorithm (PRNB-1, prnb_device.h) has three very different costs per sample:
+//   ~67 % of the samples of the headline workload are zeros that a 5-instruction bound
+//         settles (exp(-m) <= P(X = 0));
+//   the rest need P(X = 0) exactly (reciprocal + log1p + exp, ~60 VALU), and
+//   ~30 % then walk the pmf for k >= 1 (data-dependent length), ~2 % need gamma-Poisson.
+// Run lane-per-sample, every wave pays for its slowest lane in every one of these.  Here
+//   stage 1 (uniform)   one count-matrix row segment per wave pass: 16-B mean load, one
+//                       Philox call per lane, bound test; the row is stored as zeros (one
+//                       coalesced 1 KiB store); survivors are pushed on stack S1, samples of
+//                       the gamma-Poisson path on SH;
+//   stage 2 (64 of S1)  exact P(X = 0); survivors (k >= 1) are pushed on S2 with the pmf
+//                       state at k = 1;
+//   stage 3 (lanes pull from S2)  one pmf step per lane per pass; a lane that finishes stores
+//                       its count (a 4-B store over the zero) and pulls the next entry;
+//   heavy  (64 of SH)   gamma-Poisson.
+// Results are pure functions of (sample parameters, seed, global cell id, gene), so the
+// order in which the stacks are drained cannot change them.
+#pragma once
+#include "prnb_device.h"
+
+namespace k3 {
+
+constexpr int kBlock = 256;        // 4 waves
+constexpr int kTileG = 256;        // genes per wave pass: 64 lanes x 4
+constexpr int kStripCells = 32;    // cells per wave
+constexpr int kS1Cap = 320;        // < 64 left over + 256 pushed by one pass
+constexpr int kS2Cap = 128;        // < 64 left over + 64 pushed by one stage-2 pass
+constexpr int kSHCap = 320;
+
+struct S1Entry { float m, theta; uint32_t w, pos; };
+struct S2Entry { float ps, mp, q; uint32_t rem; };
+
+struct WaveLds {
+    S1Entry s1[kS1Cap];
+    S2Entry s2[kS2Cap];
+    uint32_t s2pos[kS2Cap];
+    uint32_t sh[kSHCap];
+};
+
+// rank of this lane among the lanes whose bit is set in `mask`
+__device__ __forceinline__ int lane_rank(unsigned long long mask)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                          __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
+    const float* __restrict__ means, int32_t G, const int32_t* __restrict__ row_of_cell,
+    const float* __restrict__ scal, const float* __restrict__ ga, const float* __restrict__ gbm1,
+    int64_t N, uint32_t k0, uint32_t k1, uint64_t cell_offset, const int64_t* __restrict__ cell_index,
+    int32_t* __restrict__ out, int64_t ld, int64_t* __restrict__ domain_flag, int32_t strips)
+{
+    __shared__ float inv_k[prnb::kKTab];
+    __shared__ WaveLds lds_all[kBlock / 64];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    WaveLds& L = lds_all[wv];
+
+    for (int k = tid; k < prnb::kKTab; k += kBlock) inv_k[k] = k ? 1.0f / (float)k : 0.0f;
+    __syncthreads();
+
+    // block -> (gene tile, group of 4 strips); adjacent blocks share the gene tile (L2 reuse of
+    // the mean tensor's column slice and of the per-gene parameters)
+    const int32_t groups = (strips + 3) / 4;
+    const int32_t tile_g = blockIdx.x / groups;
+    const int32_t strip = (blockIdx.x - tile_g * groups) * 4 + wv;
+    const int32_t gbase = tile_g * kTileG;
+    const int32_t g0 = gbase + lane * 4;
+    const int64_t n0 = (int64_t)strip * kStripCells;
+    if (strip >= strips || n0 >= N) return;          // whole wave leaves together (no barrier below)
+    const int cells = (int)((N - n0 < kStripCells) ? (N - n0) : kStripCells);
+
+    float a[4], bm1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool in = g0 + j < G;
+        a[j] = in ? ga[g0 + j] : 0.0f;
+        bm1[j] = in ? gbm1[g0 + j] : 0.0f;
+    }
+
+    int s1_top = 0, s2_top = 0, sh_top = 0;          // wave-uniform
+    bool bad = false;
+    // stage-3 lane state
+    bool active = false;
+    float ps = 0.0f, mp = 0.0f, q = 0.0f, kf = 0.0f;
+    uint32_t rem = 0u, pos = 0u;
+    int k = 0;
+
+    auto out_ptr = [&](uint32_t p) -> int32_t* {
+        return out + (n0 + (int64_t)(p >> 8)) * ld + gbase + (int32_t)(p & 255u);
+    };
+
+    // ---- stage 3: one pmf step for every busy lane; idle lanes pull from S2 -------------------
+    auto stage3_pass = [&]() {
+        const unsigned long long want = __ballot(!active);
+        if (want != 0ull && s2_top > 0) {
+            const int rank = lane_rank(want);
+            if (!active && rank < s2_top) {
+                const int idx = s2_top - 1 - rank;
+                const S2Entry e = L.s2[idx];
+                ps = e.ps; mp = e.mp; q = e.q; rem = e.rem;
+                pos = L.s2pos[idx];
+                k = 1; kf = 1.0f;
+                active = true;
+            }
+            const int taken = __popcll(want);
+            s2_top = (taken < s2_top) ? s2_top - taken : 0;
+        }
+        if (active) {
+            const uint32_t pf = (uint32_t)ps;
+            if (rem < pf) {
+                *out_ptr(pos) = k;
+                active = false;
+            } else if (pf == 0u || k == prnb::kKTab - 1) {
+                *out_ptr(pos) = (int32_t)mp;
+                active = false;
+            } else {
+                rem -= pf;
+                const float num = PRNB_FMA(kf, q, mp);
+                ++k;
+                kf += 1.0f;
+                ps = (ps * num) * inv_k[k];
+            }
+        }
+    };
+
+    // ---- stage 2: exact P(X = 0) for up to 64 entries of S1 ----------------------------------
+    auto stage2_pass = [&]() {
+        const int cnt = s1_top < 64 ? s1_top : 64;
+        const bool mine = lane < cnt;
+        bool push = false;
+        S2Entry e2;
+        uint32_t p2 = 0u;
+        e2.ps = 0.0f; e2.mp = 0.0f; e2.q = 0.0f; e2.rem = 0u;
+        if (mine) {
+            const S1Entry e = L.s1[s1_top - 1 - lane];
+            const float u1 = 1.0f + e.theta;
+            const float d = prnb::det_rcp(e.theta * u1);
+            const float inv_th = d * u1, inv_u1 = d * e.theta;
+            const float qq = e.theta * inv_u1;
+            const float mpp = e.m * inv_u1;
+            const float t = e.m * (prnb::det_log1p(e.theta) * inv_th);
+            const float p0 = __builtin_fminf(prnb::det_exp(-t), 0.99999994f);
+            const float ps0 = p0 * 4294967296.0f;
+            const uint32_t pf = (uint32_t)ps0;
+            if (e.w >= pf) {                      // k >= 1 (pf > 0 on the light path: P0 >= e^-12)
+                e2.rem = e.w - pf;
+                e2.mp = mpp;
+                e2.q = qq;
+                e2.ps = (ps0 * mpp) * inv_k[1];   // pmf at k = 1, scaled by 2^32 (exact scaling)
+                p2 = e.pos;
+                push = true;
+            }
+        }
+        s1_top -= cnt;
+        const unsigned long long m2 = __ballot(push);
+        if (push) {
+            const int slot = s2_top + lane_rank(m2);
+            L.s2[slot] = e2;
+            L.s2pos[slot] = p2;
+        }
+        s2_top += __popcll(m2);
+    };
+
+    // ---- heavy: gamma-Poisson for up to 64 entries of SH -------------------------------------
+    auto heavy_pass = [&]() {
+        const int cnt = sh_top < 64 ? sh_top : 64;
+        if (lane < cnt) {
+            const uint32_t p = L.sh[sh_top - 1 - lane];
+            const int64_t n = n0 + (int64_t)(p >> 8);
+            const int32_t g = gbase + (int32_t)(p & 255u);
+            const uint64_t cell = cell_index ? (uint64_t)cell_index[n] : cell_offset + (uint64_t)n;
+            const prnb::Params P =
+                prnb::make_params(means[(int64_t)row_of_cell[n] * G + g], scal[n], ga[g], gbm1[g]);
+            const int32_t x = prnb::heavy_draw(P, (uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)g,
+                                               k0, k1, inv_k);
+            if (x != 0) *out_ptr(p) = x;
+        }
+        sh_top -= cnt;
+    };
+
+    // ---- stage 1 over the strip ----------------------------------------------------------------
+#pragma unroll 1
+    for (int cl = 0; cl < cells; ++cl) {
+        const int64_t n = n0 + cl;
+        // every lane runs the whole pass (lanes beyond G just never qualify): the stack tops
+        // must stay wave-uniform, so no ballot may sit under a divergent branch
+        const int64_t row = row_of_cell[n];
+        const float s = scal[n];
+        const uint64_t cell = cell_index ? (uint64_t)cell_index[n] : cell_offset + (uint64_t)n;
+        float M[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (g0 < G) {
+            int32_t* dst = out + n * ld + g0;
+            if (VEC) {
+                const float4 v = *reinterpret_cast<const float4*>(means + row * G + g0);
+                M[0] = v.x; M[1] = v.y; M[2] = v.z; M[3] = v.w;
+                *reinterpret_cast<int4*>(dst) = make_int4(0, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (g0 + j < G) {
+                        M[j] = means[row * G + g0 + j];
+                        dst[j] = 0;
+                    }
+                }
+            }
+        }
+        const prnb::Words W =
+            prnb::philox4x32_10((uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)g0 >> 2, 0u, k0, k1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float m = M[j] * s;
+            const float th_raw = PRNB_FMA(a[j], m, bm1[j]);
+            const bool in = g0 + j < G;
+            const bool valid = in && (m > 0.0f) && (th_raw > 0.0f);
+            bad = bad || (in && (!(m > 0.0f) || th_raw < 0.0f));
+            const float theta = __builtin_fminf(__builtin_fmaxf(th_raw, prnb::kThetaMin), prnb::kThetaMax);
+            const bool light = (m <= prnb::kLightM) && (theta <= prnb::kLightTheta);
+            // P(X=0) = exp(-m*log1p(theta)/theta) >= exp(-m) >= 1 - m + m^2/2 - m^3/6; the 1e-5
+            // margin covers every rounding of the exact evaluation, so a sample settled here
+            // is one the exact path would also call 0.
+            const float bound = PRNB_FMA(PRNB_FMA(PRNB_FMA(-0.16666667f, m, 0.5f), m, -1.0f), m, 1.0f) - 1.0e-5f;
+            const bool zero = (float)W.w[j] < bound * 4294967296.0f;
+            const bool to_s1 = valid && light && !zero;
+            const bool to_sh = valid && !light;
+            const uint32_t p = ((uint32_t)cl << 8) | (uint32_t)(lane * 4 + j);
+            const unsigned long long m1 = __ballot(to_s1);
+            if (to_s1) {
+                S1Entry e;
+                e.m = m; e.theta = theta; e.w = W.w[j]; e.pos = p;
+                L.s1[s1_top + lane_rank(m1)] = e;
+            }
+            s1_top += __popcll(m1);
+            const unsigned long long mh = __ballot(to_sh);
+            if (mh != 0ull) {
+                if (to_sh) L.sh[sh_top + lane_rank(mh)] = p;
+                sh_top += __popcll(mh);
+            }
+        }
+        while (s1_top >= 64) {
+            stage2_pass();
+            while (s2_top >= 64) stage3_pass();
+        }
+        while (sh_top >= 64) heavy_pass();
+    }
+
+    // ---- drain ------------------------------------------------------------------------------------
+    while (s1_top > 0) {
+        stage2_pass();
+        while (s2_top >= 64) stage3_pass();
+    }
+    while (s2_top > 0 || __ballot(active) != 0ull) stage3_pass();
+    while (sh_top > 0) heavy_pass();
+    if (bad) *domain_flag = 1;
+}
+
+}  // namespace k3

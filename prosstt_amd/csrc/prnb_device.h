@@ -145,7 +145,7 @@ __device__ __forceinline__ float unif(uint32_t w) { return ((float)w + 0.5f) * 2
 __device__ __forceinline__ float det_sqrt(float x) { return __builtin_sqrtf(x); }  // IEEE (see Makefile)
 
 // Inversion by chop-down in 0.32 fixed point; inv_k = LDS table of 1/k.
-__device__ __forceinline__ int32_t chop_down(uint32_t w, float p0, float mp, float q, float mean,
+__device__ __forceinline__ int32_t chop_down(uint32_t w, float p0, float mp, float q,
                                              const float* inv_k)
 {
     float p = __builtin_fminf(p0, 0.99999994f);
@@ -155,7 +155,7 @@ __device__ __forceinline__ int32_t chop_down(uint32_t w, float p0, float mp, flo
     for (;;) {
         const uint32_t pf = (uint32_t)(p * 4294967296.0f);
         if (rem < pf) return k;
-        if (pf == 0u || k == kKTab - 1) return (int32_t)mean;
+        if (pf == 0u || k == kKTab - 1) return (int32_t)mp;
         rem -= pf;
         const float num = PRNB_FMA(kf, q, mp);
         ++k;
@@ -186,7 +186,7 @@ __device__ __noinline__ int32_t poisson_draw(float lam, uint32_t c0, uint32_t c1
     if (!(lam > 0.0f)) return 0;
     if (lam < kPoisInv) {
         const Words w = philox4x32_10(c0, c1, gene, 0x80000000u, k0, k1);
-        return chop_down(w.w[0], det_exp(-lam), lam, 0.0f, lam, inv_k);
+        return chop_down(w.w[0], det_exp(-lam), lam, 0.0f, inv_k);
     }
     const float slam = det_sqrt(lam);
     if (!(lam < kLamBig)) {
@@ -286,7 +286,7 @@ __device__ __forceinline__ int32_t light_draw(const Params& P, uint32_t w, const
 {
     const float q = P.theta * P.inv_u1;
     const float t = P.m * (det_log1p(P.theta) * P.inv_th);
-    return chop_down(w, det_exp(-t), P.m * P.inv_u1, q, P.m, inv_k);
+    return chop_down(w, det_exp(-t), P.m * P.inv_u1, q, inv_k);
 }
 
 // Heavy path: Poisson(theta * Gamma(r)).

@@ -21,6 +21,7 @@
 
 #include "../../include/prosstt_amd.h"
 #include "prnb_device.h"
+#include "k3_stream.h"
 
 #define PA_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -518,26 +519,41 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
     }
     HIP_TRY(hipMemsetAsync(c->scratch, 0, 8, c->stream));
 
-    const int64_t tiles_c = (N + kTileC - 1) / kTileC;
     const int64_t tiles_g = ((int64_t)G + kTileG - 1) / kTileG;
-    if (tiles_c * tiles_g > 0x7fffffffll) return fail(PROSSTT_AMD_EINVAL, "too many tiles; chunk the cells");
     const bool vec = (G % 4 == 0) && (ld_out % 4 == 0) && (((uintptr_t)A.means & 15) == 0) &&
                      (((uintptr_t)d_out & 15) == 0);
-    const dim3 grid((unsigned)(tiles_c * tiles_g)), block(kBlock);
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     if (flags & PROSSTT_AMD_TIME_KERNEL) {
         if ((rc = next_event_pair(c, &ev_start, &ev_stop))) return rc;
         HIP_TRY(hipEventRecord(ev_start, c->stream));
     }
-    if (vec)
-        sample_counts_kernel<true><<<grid, block, 0, c->stream>>>(A.means, G, A.row_of_cell, A.scal, A.ga,
-                                                                 A.gbm1, N, k0, k1, cell_offset, cell_index,
-                                                                 d_out, ld_out, c->scratch, (int32_t)tiles_c);
-    else
-        sample_counts_kernel<false><<<grid, block, 0, c->stream>>>(A.means, G, A.row_of_cell, A.scal, A.ga,
-                                                                  A.gbm1, N, k0, k1, cell_offset, cell_index,
-                                                                  d_out, ld_out, c->scratch, (int32_t)tiles_c);
+    if (flags & PROSSTT_AMD_KERNEL_TILED) {
+        const int64_t tiles_c = (N + kTileC - 1) / kTileC;
+        if (tiles_c * tiles_g > 0x7fffffffll) return fail(PROSSTT_AMD_EINVAL, "too many tiles; chunk the cells");
+        const dim3 grid((unsigned)(tiles_c * tiles_g)), block(kBlock);
+        if (vec)
+            sample_counts_kernel<true><<<grid, block, 0, c->stream>>>(A.means, G, A.row_of_cell, A.scal, A.ga,
+                                                                     A.gbm1, N, k0, k1, cell_offset, cell_index,
+                                                                     d_out, ld_out, c->scratch, (int32_t)tiles_c);
+        else
+            sample_counts_kernel<false><<<grid, block, 0, c->stream>>>(A.means, G, A.row_of_cell, A.scal, A.ga,
+                                                                      A.gbm1, N, k0, k1, cell_offset, cell_index,
+                                                                      d_out, ld_out, c->scratch, (int32_t)tiles_c);
+    } else {
+        const int64_t strips = (N + k3::kStripCells - 1) / k3::kStripCells;
+        const int64_t groups = (strips + 3) / 4;
+        if (groups * tiles_g > 0x7fffffffll) return fail(PROSSTT_AMD_EINVAL, "too many tiles; chunk the cells");
+        const dim3 grid((unsigned)(groups * tiles_g)), block(k3::kBlock);
+        if (vec)
+            k3::sample_counts_stream_kernel<true><<<grid, block, 0, c->stream>>>(
+                A.means, G, A.row_of_cell, A.scal, A.ga, A.gbm1, N, k0, k1, cell_offset, cell_index, d_out,
+                ld_out, c->scratch, (int32_t)strips);
+        else
+            k3::sample_counts_stream_kernel<false><<<grid, block, 0, c->stream>>>(
+                A.means, G, A.row_of_cell, A.scal, A.ga, A.gbm1, N, k0, k1, cell_offset, cell_index, d_out,
+                ld_out, c->scratch, (int32_t)strips);
+    }
     HIP_TRY(hipGetLastError());
     if (flags & PROSSTT_AMD_TIME_KERNEL) HIP_TRY(hipEventRecord(ev_stop, c->stream));
     if (flags & PROSSTT_AMD_HOST_OUTPUT)

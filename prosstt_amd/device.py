@@ -5,6 +5,7 @@ torch supplies device memory and the stream handle; every numeric step is a
 call into libprosstt_amd.so.  Nothing here computes on the CPU.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -93,6 +94,8 @@ class Context:
             if cell_index.numel() != N:
                 raise ValueError("cell_index must have one entry per cell")
         flags = (_native.CHECK_DOMAIN if check_domain else 0) | (_native.TIME_KERNEL if time_kernel else 0)
+        if os.environ.get("PROSSTT_AMD_KERNEL", "") == "tiled":      # A/B switch; same results
+            flags |= _native.KERNEL_TILED
         _native.check(self._lib.prosstt_amd_sample_counts(
             self._h, _ptr(means), rows, G, _ptr(row_of_cell), _ptr(scaling), _ptr(alpha), _ptr(beta),
             N, ctypes.c_uint64(seed & (2 ** 64 - 1)), ctypes.c_uint64(cell_offset), _ptr(cell_index),
