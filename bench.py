@@ -165,7 +165,7 @@ def main():
                        "sum_counts_over_sum_means": round(ratio, 5)},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": None,
-                         "kernel": "sample_counts_kernel<true>", "kernel_ms": kms,
+                         "kernel": "k3::sample_counts_stream_kernel<true>", "kernel_ms": kms,
                          "algorithmic_bytes_per_launch": abytes,
                          "note": "VALU-bound exact sampler: see DESIGN.md section 6 and profiles/"},
         }

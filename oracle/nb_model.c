@@ -42,7 +42,7 @@
 #define PRNB_THETA_MIN    8.6736174e-19f /* 2^-60: below this NB == Poisson in binary32 */
 #define PRNB_THETA_MAX    1.0e18f
 #define PRNB_R_MIN        9.094947e-13f  /* 2^-40: P(X>0) < 2^-32, return 0 */
-#define PRNB_KTAB         1024         /* 1/k table size */
+#define PRNB_KTAB         1024         /* 1/k table size, last entry = 0 sentinel */
 #define PRNB_POIS_INV     10.0f        /* Poisson: inversion below, PTRS above */
 #define PRNB_LAM_BIG      4194304.0f   /* 2^22: rounded normal above */
 #define PRNB_MAX_TRIES    64
@@ -173,7 +173,8 @@ static const float LOGFACT[10] = {0.0f, 0.0f, 0.69314718f, 1.7917595f, 3.1780538
 __attribute__((constructor)) static void prnb_init(void)
 {
     g_inv_k[0] = 0.0f;
-    for (int k = 1; k < PRNB_KTAB; ++k) g_inv_k[k] = 1.0f / (float)k;
+    for (int k = 1; k < PRNB_KTAB - 1; ++k) g_inv_k[k] = 1.0f / (float)k;
+    g_inv_k[PRNB_KTAB - 1] = 0.0f;   /* sentinel: the walk ends (pmf 0 -> floor(mp)) at k = KTAB-1 */
 }
 
 /*

@@ -10,7 +10,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libprosstt_amd.so")
+LIB_PATH = os.environ.get("PROSSTT_AMD_LIB") or os.path.join(_HERE, "lib", "libprosstt_amd.so")
 
 OK, EINVAL, EDOMAIN, EHIP, ENOMEM, ENODEV = 0, -1, -2, -3, -4, -5
 HOST_INPUTS, HOST_OUTPUT, CHECK_DOMAIN, TIME_KERNEL, KERNEL_TILED = 1, 2, 4, 8, 16

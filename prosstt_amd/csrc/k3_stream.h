@@ -22,11 +22,15 @@
 #pragma once
 #include "prnb_device.h"
 
+#ifndef K3_ABLATE
+#define K3_ABLATE 0   // timing-only experiments (tools/ablate.sh); 0 in every shipped build
+#endif
+
 namespace k3 {
 
 constexpr int kBlock = 256;        // 4 waves
 constexpr int kTileG = 256;        // genes per wave pass: 64 lanes x 4
-constexpr int kStripCells = 32;    // cells per wave
+constexpr int kStripCells = 128;   // cells per wave: long strips amortise the drain of stage 3
 constexpr int kS1Cap = 320;        // < 64 left over + 256 pushed by one pass
 constexpr int kS2Cap = 128;        // < 64 left over + 64 pushed by one stage-2 pass
 constexpr int kSHCap = 320;
@@ -55,14 +59,14 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
     int64_t N, uint32_t k0, uint32_t k1, uint64_t cell_offset, const int64_t* __restrict__ cell_index,
     int32_t* __restrict__ out, int64_t ld, int64_t* __restrict__ domain_flag, int32_t strips)
 {
-    __shared__ float inv_k[prnb::kKTab];
+    __shared__ float inv_k[prnb::kKTab + 1];
     __shared__ WaveLds lds_all[kBlock / 64];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     WaveLds& L = lds_all[wv];
 
-    for (int k = tid; k < prnb::kKTab; k += kBlock) inv_k[k] = k ? 1.0f / (float)k : 0.0f;
+    for (int k = tid; k <= prnb::kKTab; k += kBlock) inv_k[k] = (k && k < prnb::kKTab - 1) ? 1.0f / (float)k : 0.0f;
     __syncthreads();
 
     // block -> (gene tile, group of 4 strips); adjacent blocks share the gene tile (L2 reuse of
@@ -92,9 +96,11 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
     uint32_t rem = 0u, pos = 0u;
     int k = 0;
 
-    auto out_ptr = [&](uint32_t p) -> int32_t* {
-        return out + (n0 + (int64_t)(p >> 8)) * ld + gbase + (int32_t)(p & 255u);
-    };
+    // S1/S2 carry the element offset of a sample from the strip's first output element
+    // (cl*ld + gene-in-tile < 2^32, checked by the host); SH carries (cl << 8 | gene-in-tile).
+    int32_t* const strip_out = out + n0 * ld + gbase;
+    const uint32_t ld32 = (uint32_t)ld;
+    float inv_next = 0.0f;
 
     // ---- stage 3: one pmf step for every busy lane; idle lanes pull from S2 -------------------
     auto stage3_pass = [&]() {
@@ -107,6 +113,7 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
                 ps = e.ps; mp = e.mp; q = e.q; rem = e.rem;
                 pos = L.s2pos[idx];
                 k = 1; kf = 1.0f;
+                inv_next = 0.5f;                       // 1/(k+1)
                 active = true;
             }
             const int taken = __popcll(want);
@@ -115,17 +122,18 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
         if (active) {
             const uint32_t pf = (uint32_t)ps;
             if (rem < pf) {
-                *out_ptr(pos) = k;
+                strip_out[pos] = k;
                 active = false;
-            } else if (pf == 0u || k == prnb::kKTab - 1) {
-                *out_ptr(pos) = (int32_t)mp;
+            } else if (pf == 0u) {                     // pmf under 2^-32 (or the table's end): floor(mp)
+                strip_out[pos] = (int32_t)mp;
                 active = false;
             } else {
                 rem -= pf;
                 const float num = PRNB_FMA(kf, q, mp);
                 ++k;
                 kf += 1.0f;
-                ps = (ps * num) * inv_k[k];
+                ps = (ps * num) * inv_next;
+                inv_next = inv_k[k + 1];               // for the next pass: off the critical path
             }
         }
     };
@@ -180,39 +188,61 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
                 prnb::make_params(means[(int64_t)row_of_cell[n] * G + g], scal[n], ga[g], gbm1[g]);
             const int32_t x = prnb::heavy_draw(P, (uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)g,
                                                k0, k1, inv_k);
-            if (x != 0) *out_ptr(p) = x;
+            if (x != 0) strip_out[(p >> 8) * ld32 + (p & 255u)] = x;
         }
         sh_top -= cnt;
     };
 
     // ---- stage 1 over the strip ----------------------------------------------------------------
+    // the row index, scaling and mean segment of the NEXT cell are loaded while this one is
+    // processed (their latency would otherwise sit in front of every pass)
+    struct Row { int64_t row; float s; uint64_t cell; float M[4]; };
+    auto load_row = [&](int cl) -> Row {
+        Row r;
+        const int64_t n = n0 + cl;
+        r.row = row_of_cell[n];
+        r.s = scal[n];
+        r.cell = cell_index ? (uint64_t)cell_index[n] : cell_offset + (uint64_t)n;
+        r.M[0] = r.M[1] = r.M[2] = r.M[3] = 0.0f;
+        if (g0 < G) {
+            if (VEC) {
+                const float4 v = *reinterpret_cast<const float4*>(means + r.row * G + g0);
+                r.M[0] = v.x; r.M[1] = v.y; r.M[2] = v.z; r.M[3] = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (g0 + j < G) r.M[j] = means[r.row * G + g0 + j];
+            }
+        }
+        return r;
+    };
+    Row cur = load_row(0);
 #pragma unroll 1
     for (int cl = 0; cl < cells; ++cl) {
-        const int64_t n = n0 + cl;
+        const Row nxt = load_row(cl + 1 < cells ? cl + 1 : cl);
         // every lane runs the whole pass (lanes beyond G just never qualify): the stack tops
         // must stay wave-uniform, so no ballot may sit under a divergent branch
-        const int64_t row = row_of_cell[n];
-        const float s = scal[n];
-        const uint64_t cell = cell_index ? (uint64_t)cell_index[n] : cell_offset + (uint64_t)n;
-        float M[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float s = cur.s;
+        const uint64_t cell = cur.cell;
+        const float M[4] = {cur.M[0], cur.M[1], cur.M[2], cur.M[3]};
         if (g0 < G) {
-            int32_t* dst = out + n * ld + g0;
+            int32_t* dst = strip_out + (int64_t)cl * ld + lane * 4;
             if (VEC) {
-                const float4 v = *reinterpret_cast<const float4*>(means + row * G + g0);
-                M[0] = v.x; M[1] = v.y; M[2] = v.z; M[3] = v.w;
                 *reinterpret_cast<int4*>(dst) = make_int4(0, 0, 0, 0);
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (g0 + j < G) {
-                        M[j] = means[row * G + g0 + j];
-                        dst[j] = 0;
-                    }
-                }
+                for (int j = 0; j < 4; ++j)
+                    if (g0 + j < G) dst[j] = 0;
             }
         }
+#if K3_ABLATE == 3     // no Philox: a 2-instruction hash stands in
+        prnb::Words W;
+        W.w[0] = ((uint32_t)cell * 2654435761u) ^ ((uint32_t)g0 * 40503u); W.w[1] = W.w[0] * 3u + k0;
+        W.w[2] = W.w[1] ^ 0x9E3779B9u; W.w[3] = W.w[2] + W.w[0];
+#else
         const prnb::Words W =
             prnb::philox4x32_10((uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)g0 >> 2, 0u, k0, k1);
+#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float m = M[j] * s;
@@ -233,7 +263,7 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
             const unsigned long long m1 = __ballot(to_s1);
             if (to_s1) {
                 S1Entry e;
-                e.m = m; e.theta = theta; e.w = W.w[j]; e.pos = p;
+                e.m = m; e.theta = theta; e.w = W.w[j]; e.pos = (uint32_t)cl * ld32 + (uint32_t)(lane * 4 + j);
                 L.s1[s1_top + lane_rank(m1)] = e;
             }
             s1_top += __popcll(m1);
@@ -243,11 +273,25 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
                 sh_top += __popcll(mh);
             }
         }
+#if K3_ABLATE == 2      // stage 1 only
+        s1_top = 0; sh_top = 0;
+#elif K3_ABLATE == 1    // no stage 3
+        while (s1_top >= 64) { stage2_pass(); s2_top = 0; }
+        while (sh_top >= 64) heavy_pass();
+#elif K3_ABLATE == 4    // no heavy
+        while (s1_top >= 64) {
+            stage2_pass();
+            while (s2_top >= 64) stage3_pass();
+        }
+        sh_top = 0;
+#else
         while (s1_top >= 64) {
             stage2_pass();
             while (s2_top >= 64) stage3_pass();
         }
         while (sh_top >= 64) heavy_pass();
+#endif
+        cur = nxt;
     }
 
     // ---- drain ------------------------------------------------------------------------------------

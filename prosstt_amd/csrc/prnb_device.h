@@ -20,7 +20,7 @@ constexpr float kLightTheta = 16.0f;
 constexpr float kThetaMin = 8.6736174e-19f;  // 2^-60
 constexpr float kThetaMax = 1.0e18f;
 constexpr float kRMin = 9.094947e-13f;       // 2^-40
-constexpr int kKTab = 1024;                  // entries of the 1/k table
+constexpr int kKTab = 1024;                  // entries of the 1/k table; the last one is a 0 sentinel
 constexpr float kPoisInv = 10.0f;
 constexpr float kLamBig = 4194304.0f;        // 2^22
 constexpr int kMaxTries = 64;
@@ -180,7 +180,7 @@ __device__ __forceinline__ float logfact_small(int k)
     }
 }
 
-__device__ __noinline__ int32_t poisson_draw(float lam, uint32_t c0, uint32_t c1, uint32_t gene,
+__device__ __forceinline__ int32_t poisson_draw(float lam, uint32_t c0, uint32_t c1, uint32_t gene,
                                              uint32_t k0, uint32_t k1, const float* inv_k)
 {
     if (!(lam > 0.0f)) return 0;
@@ -230,7 +230,7 @@ __device__ __noinline__ int32_t poisson_draw(float lam, uint32_t c0, uint32_t c1
     return (int32_t)__builtin_fminf(__builtin_fmaxf(kf, 0.0f), 2147483520.0f);
 }
 
-__device__ __noinline__ float gamma_scaled(float r, float theta, uint32_t c0, uint32_t c1,
+__device__ __forceinline__ float gamma_scaled(float r, float theta, uint32_t c0, uint32_t c1,
                                            uint32_t gene, uint32_t k0, uint32_t k1)
 {
     const bool boost = r < 1.0f;

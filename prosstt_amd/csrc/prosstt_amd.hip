@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kBlock) void sample_counts_kernel(
     const int32_t g0 = tile_g * kTileG + ql * 4;
     const int64_t n0 = (int64_t)tile_c * kTileC;
 
-    for (int k = tid; k < prnb::kKTab; k += kBlock) inv_k[k] = k ? 1.0f / (float)k : 0.0f;
+    for (int k = tid; k < prnb::kKTab; k += kBlock) inv_k[k] = (k && k < prnb::kKTab - 1) ? 1.0f / (float)k : 0.0f;
     if (tid == 0) q_count = 0;
     __syncthreads();
 
@@ -541,6 +541,8 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
                                                                       A.gbm1, N, k0, k1, cell_offset, cell_index,
                                                                       d_out, ld_out, c->scratch, (int32_t)tiles_c);
     } else {
+        if (ld_out * k3::kStripCells >= ((int64_t)1 << 32))
+            return fail(PROSSTT_AMD_EINVAL, "ld_out too large for 32-bit strip offsets");
         const int64_t strips = (N + k3::kStripCells - 1) / k3::kStripCells;
         const int64_t groups = (strips + 3) / 4;
         if (groups * tiles_g > 0x7fffffffll) return fail(PROSSTT_AMD_EINVAL, "too many tiles; chunk the cells");

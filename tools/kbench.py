@@ -1,0 +1,21 @@
+"""Kernel-only timing of K3 on a benchmark config (default C3) -- used for A/B and ablations."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from prosstt_amd import device, workloads
+cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
+ctx = device.get_context()
+w = workloads.build(cfg)
+pt, br, sc, rows = w.plan()
+G = w.tree.G
+dm = w.tree.device_means(); dr = ctx.tensor(rows, torch.int32); ds = ctx.tensor(sc, torch.float64)
+da = ctx.tensor(w.alpha, torch.float64); db = ctx.tensor(w.beta, torch.float64)
+out = torch.empty((len(rows), G), dtype=torch.int32, device='cuda')
+ts = []
+for i in range(6):
+    ctx.sample_counts(dm, dr, ds, da, db, seed=i, out=out, check_domain=False, time_kernel=True)
+    ts.append(ctx.last_kernel_ms())
+n = len(rows) * G
+ms = float(np.median(ts[1:]))
+print("%-34s %s: kernel %.3f ms  %.1f G samples/s  %.2f %% of 8 TB/s  (sum %d)" % (
+    os.environ.get("PROSSTT_AMD_LIB", "default")[-34:], cfg, ms, n / ms / 1e6, n * 4.0325 / ms / 1e9 * 1e3 / 8e12 * 100, int(out.sum())))
