@@ -179,24 +179,24 @@ __attribute__((constructor)) static void prnb_init(void)
 
 /*
  * Inversion by chop-down in 0.32 fixed point.  pmf recurrence
- *   P(k) = P(k-1) * (mp + (k-1)*q) / k      (NB: mp = m/(1+theta), q = theta/(1+theta);
- *                                            Poisson: mp = lambda, q = 0)
- * `w` is the 32-bit uniform.  If the pmf falls below 2^-32 before w is used up
- * (mass lost to rounding, < 1e-6) the draw falls back to floor(mp), a value in the bulk.
+ *   P(k+1) = P(k) * num_k / (k+1),   num_0 = mp,  num_(k+1) = num_k + q
+ * (NB: mp = m/(1+theta), q = theta/(1+theta);  Poisson: mp = lambda, q = 0).
+ * `w` is the 32-bit uniform.  If the pmf falls below 2^-32 before w is used up -- mass lost
+ * to rounding, < 1e-6, or the 0 sentinel that ends the 1/k table -- the draw is 0.
  */
 static inline int32_t chop_down(uint32_t w, float p0, float mp, float q)
 {
     float p = fminf(p0, 0.99999994f);
+    float num = mp;
     uint32_t rem = w;
-    float kf = 0.0f;
     for (int k = 0; ; ) {
         uint32_t pf = (uint32_t)(p * 4294967296.0f);
         if (rem < pf) return k;
-        if (pf == 0u || k == PRNB_KTAB - 1) return (int32_t)mp;
+        if (pf == 0u) return 0;
         rem -= pf;
-        float num = FMA(kf, q, mp);
-        ++k; kf += 1.0f;
+        ++k;
         p = (p * num) * g_inv_k[k];
+        num = num + q;
     }
 }
 

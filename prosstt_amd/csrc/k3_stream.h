@@ -36,7 +36,7 @@ constexpr int kS2Cap = 128;        // < 64 left over + 64 pushed by one stage-2 
 constexpr int kSHCap = 320;
 
 struct S1Entry { float m, theta; uint32_t w, pos; };
-struct S2Entry { float ps, mp, q; uint32_t rem; };
+struct S2Entry { float ps, num, q; uint32_t rem; };   // pmf (x 2^32) and numerator at k = 1
 
 struct WaveLds {
     S1Entry s1[kS1Cap];
@@ -59,14 +59,14 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
     int64_t N, uint32_t k0, uint32_t k1, uint64_t cell_offset, const int64_t* __restrict__ cell_index,
     int32_t* __restrict__ out, int64_t ld, int64_t* __restrict__ domain_flag, int32_t strips)
 {
-    __shared__ float inv_k[prnb::kKTab + 1];
+    __shared__ float inv_k[prnb::kKTab + 4];          // 0 from the sentinel (k = KTAB-1) on
     __shared__ WaveLds lds_all[kBlock / 64];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     WaveLds& L = lds_all[wv];
 
-    for (int k = tid; k <= prnb::kKTab; k += kBlock) inv_k[k] = (k && k < prnb::kKTab - 1) ? 1.0f / (float)k : 0.0f;
+    for (int k = tid; k < prnb::kKTab + 4; k += kBlock) inv_k[k] = (k && k < prnb::kKTab - 1) ? 1.0f / (float)k : 0.0f;
     __syncthreads();
 
     // block -> (gene tile, group of 4 strips); adjacent blocks share the gene tile (L2 reuse of
@@ -92,50 +92,61 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
     bool bad = false;
     // stage-3 lane state
     bool active = false;
-    float ps = 0.0f, mp = 0.0f, q = 0.0f, kf = 0.0f;
+    float ps = 0.0f, num = 0.0f, q = 0.0f;
     uint32_t rem = 0u, pos = 0u;
     int k = 0;
+    float inv1 = 0.0f, inv2 = 0.0f;                  // 1/(k+1), 1/(k+2): read one pass ahead
 
     // S1/S2 carry the element offset of a sample from the strip's first output element
     // (cl*ld + gene-in-tile < 2^32, checked by the host); SH carries (cl << 8 | gene-in-tile).
     int32_t* const strip_out = out + n0 * ld + gbase;
     const uint32_t ld32 = (uint32_t)ld;
-    float inv_next = 0.0f;
 
     // ---- stage 3: one pmf step for every busy lane; idle lanes pull from S2 -------------------
     auto stage3_pass = [&]() {
-        const unsigned long long want = __ballot(!active);
+        const unsigned long long want = __builtin_amdgcn_ballot_w64(!active);
         if (want != 0ull && s2_top > 0) {
             const int rank = lane_rank(want);
             if (!active && rank < s2_top) {
                 const int idx = s2_top - 1 - rank;
                 const S2Entry e = L.s2[idx];
-                ps = e.ps; mp = e.mp; q = e.q; rem = e.rem;
+                ps = e.ps; num = e.num; q = e.q; rem = e.rem;
                 pos = L.s2pos[idx];
-                k = 1; kf = 1.0f;
-                inv_next = 0.5f;                       // 1/(k+1)
+                k = 1;
+                inv1 = 0.5f;                           // 1/2
+                inv2 = 0.33333334f;                    // 1/3 (binary32-rounded, = inv_k[3])
                 active = true;
             }
             const int taken = __popcll(want);
             s2_top = (taken < s2_top) ? s2_top - taken : 0;
         }
-        if (active) {
-            const uint32_t pf = (uint32_t)ps;
-            if (rem < pf) {
-                strip_out[pos] = k;
-                active = false;
-            } else if (pf == 0u) {                     // pmf under 2^-32 (or the table's end): floor(mp)
-                strip_out[pos] = (int32_t)mp;
-                active = false;
-            } else {
-                rem -= pf;
-                const float num = PRNB_FMA(kf, q, mp);
-                ++k;
-                kf += 1.0f;
-                ps = (ps * num) * inv_next;
-                inv_next = inv_k[k + 1];               // for the next pass: off the critical path
-            }
+        // two pmf steps per pass, straight-line: lanes that are idle or finish at the first
+        // step compute garbage that nothing reads
+        const uint32_t pfa = (uint32_t)ps;
+        const bool hit_a = rem < pfa;
+        const bool end_a = hit_a || pfa == 0u;          // pmf under 2^-32 (or the table's end): 0
+        const uint32_t rem_b = rem - pfa;
+        const float ps_b = (ps * num) * inv1;
+        const float num_b = num + q;
+        const uint32_t pfb = (uint32_t)ps_b;
+        const bool hit_b = rem_b < pfb;
+        const bool end_b = hit_b || pfb == 0u;
+        const bool done = active && (end_a || end_b);
+        if (done) {
+            const int32_t res = end_a ? (hit_a ? k : 0) : (hit_b ? k + 1 : 0);
+#if K3_ABLATE == 5      // no scattered store of the walk's result
+            if (res == 0x7fffffff) strip_out[pos] = res;
+#else
+            if (res != 0) strip_out[pos] = res;
+#endif
+            active = false;
         }
+        rem = rem_b - pfb;
+        ps = (ps_b * num_b) * inv2;
+        num = num_b + q;
+        k = active ? k + 2 : 0;                        // idle lanes must not walk off the table
+        inv1 = inv_k[k + 1];
+        inv2 = inv_k[k + 2];
     };
 
     // ---- stage 2: exact P(X = 0) for up to 64 entries of S1 ----------------------------------
@@ -145,7 +156,7 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
         bool push = false;
         S2Entry e2;
         uint32_t p2 = 0u;
-        e2.ps = 0.0f; e2.mp = 0.0f; e2.q = 0.0f; e2.rem = 0u;
+        e2.ps = 0.0f; e2.num = 0.0f; e2.q = 0.0f; e2.rem = 0u;
         if (mine) {
             const S1Entry e = L.s1[s1_top - 1 - lane];
             const float u1 = 1.0f + e.theta;
@@ -159,7 +170,7 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
             const uint32_t pf = (uint32_t)ps0;
             if (e.w >= pf) {                      // k >= 1 (pf > 0 on the light path: P0 >= e^-12)
                 e2.rem = e.w - pf;
-                e2.mp = mpp;
+                e2.num = mpp + qq;                // numerator of the step 1 -> 2
                 e2.q = qq;
                 e2.ps = (ps0 * mpp) * inv_k[1];   // pmf at k = 1, scaled by 2^32 (exact scaling)
                 p2 = e.pos;
@@ -167,7 +178,7 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
             }
         }
         s1_top -= cnt;
-        const unsigned long long m2 = __ballot(push);
+        const unsigned long long m2 = __builtin_amdgcn_ballot_w64(push);
         if (push) {
             const int slot = s2_top + lane_rank(m2);
             L.s2[slot] = e2;
@@ -260,14 +271,14 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
             const bool to_s1 = valid && light && !zero;
             const bool to_sh = valid && !light;
             const uint32_t p = ((uint32_t)cl << 8) | (uint32_t)(lane * 4 + j);
-            const unsigned long long m1 = __ballot(to_s1);
+            const unsigned long long m1 = __builtin_amdgcn_ballot_w64(to_s1);
             if (to_s1) {
                 S1Entry e;
                 e.m = m; e.theta = theta; e.w = W.w[j]; e.pos = (uint32_t)cl * ld32 + (uint32_t)(lane * 4 + j);
                 L.s1[s1_top + lane_rank(m1)] = e;
             }
             s1_top += __popcll(m1);
-            const unsigned long long mh = __ballot(to_sh);
+            const unsigned long long mh = __builtin_amdgcn_ballot_w64(to_sh);
             if (mh != 0ull) {
                 if (to_sh) L.sh[sh_top + lane_rank(mh)] = p;
                 sh_top += __popcll(mh);
@@ -299,7 +310,7 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
         stage2_pass();
         while (s2_top >= 64) stage3_pass();
     }
-    while (s2_top > 0 || __ballot(active) != 0ull) stage3_pass();
+    while (s2_top > 0 || __builtin_amdgcn_ballot_w64(active) != 0ull) stage3_pass();
     while (sh_top > 0) heavy_pass();
     if (bad) *domain_flag = 1;
 }

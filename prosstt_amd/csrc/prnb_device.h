@@ -144,23 +144,23 @@ __device__ __forceinline__ float unif(uint32_t w) { return ((float)w + 0.5f) * 2
 
 __device__ __forceinline__ float det_sqrt(float x) { return __builtin_sqrtf(x); }  // IEEE (see Makefile)
 
-// Inversion by chop-down in 0.32 fixed point; inv_k = LDS table of 1/k.
+// Inversion by chop-down in 0.32 fixed point; inv_k = LDS table of 1/k (0 sentinel at the end).
+// P(k+1) = P(k) * num_k / (k+1), num_0 = mp, num_(k+1) = num_k + q; pmf below 2^-32 -> 0.
 __device__ __forceinline__ int32_t chop_down(uint32_t w, float p0, float mp, float q,
                                              const float* inv_k)
 {
     float p = __builtin_fminf(p0, 0.99999994f);
+    float num = mp;
     uint32_t rem = w;
-    float kf = 0.0f;
     int k = 0;
     for (;;) {
         const uint32_t pf = (uint32_t)(p * 4294967296.0f);
         if (rem < pf) return k;
-        if (pf == 0u || k == kKTab - 1) return (int32_t)mp;
+        if (pf == 0u) return 0;
         rem -= pf;
-        const float num = PRNB_FMA(kf, q, mp);
         ++k;
-        kf += 1.0f;
         p = (p * num) * inv_k[k];
+        num = num + q;
     }
 }
 
