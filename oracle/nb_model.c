@@ -37,7 +37,7 @@
 #endif
 
 /* ---- sampler constants (part of the PRNB-1 definition) ------------------ */
-#define PRNB_LIGHT_M      12.0f        /* light path iff m <= 12 and theta <= 16 */
+#define PRNB_LIGHT_M      19.0f        /* light path iff m <= 19 and theta <= 16 (P0 >= e^-19 > 2^-28) */
 #define PRNB_LIGHT_THETA  16.0f
 #define PRNB_THETA_MIN    8.6736174e-19f /* 2^-60: below this NB == Poisson in binary32 */
 #define PRNB_THETA_MAX    1.0e18f
@@ -261,12 +261,19 @@ static inline float gamma_scaled(float r, float theta, uint32_t c0, uint32_t c1,
     float cc = det_rcp(3.0f * sqrtf(dd));
     float v = 1.0f;
     for (int i = 0; i < PRNB_MAX_TRIES; ++i) {
+        /* every attempt is a pure function of (i, parameters); attempt MAX_TRIES-1 is final */
+        const int last = (i == PRNB_MAX_TRIES - 1);
         philox4x32_10(c0, c1, gene, 1u + (uint32_t)i, k0, k1, w);
         float x = sqrtf(-2.0f * det_log(unif(w[0]))) * det_cos2pi(w[1]);
         float t = cc * x;
         float v1 = 1.0f + t;
-        if (!(v1 > 0.0f)) continue;
+        if (!(v1 > 0.0f)) {
+            v = 1.0f;
+            if (last) break;
+            continue;
+        }
         v = v1 * v1 * v1;
+        if (last) break;
         float u = unif(w[2]);
         float x2 = x * x;
         if (u < FMA(-0.0331f, x2 * x2, 1.0f)) break;

@@ -1,0 +1,258 @@
+// K3h: the gamma-Poisson path of PRNB-1 (prnb_device.h) for the samples the streaming
+// kernel (k3_stream.h) flagged in its bit mask -- means above 12 or theta above 16, a few
+// per cent of a typical workload.  Both halves are rejection samplers; run lane-per-sample
+// they would make every wave repeat each half until its unluckiest lane is accepted.  Here
+// every ATTEMPT is a stack entry: a gamma pass runs one Marsaglia-Tsang attempt for 64
+// entries of HG (accepted -> the Poisson stack HP, rejected -> back on HG with the next
+// attempt number), a Poisson pass one PTRS attempt for 64 entries of HP.  Attempts are pure
+// functions of (parameters, seed, cell, gene, attempt), so the order of evaluation cannot
+// change a result, and every pass runs with all lanes doing the same thing.
+#pragma once
+#include "prnb_device.h"
+#include "k3_stream.h"
+
+namespace k3 {
+
+constexpr int kHCap = 192;     // < 64 left over + 64 new + 64 pushed back
+
+struct HGEntry { int32_t n, g, attempt, row; };   // row = row_of_cell[n], looked up once per ticket
+struct HPEntry { int32_t n, g; float lam; int32_t attempt; };
+
+struct HeavyLds {
+    HGEntry hg[kHCap];
+    HPEntry hp[kHCap];
+};
+
+// flags: [N][tiles_g][64] bytes written by the streaming kernel; bit j (< 4) of byte
+// (n, t, l) flags gene t*256 + 4*l + j of cell n.
+__global__ __launch_bounds__(kBlock) void sample_counts_heavy_kernel(
+    const uint8_t* __restrict__ flags, int32_t tiles_g, const float* __restrict__ means,
+    int32_t G, const int32_t* __restrict__ row_of_cell, const float* __restrict__ scal,
+    const float* __restrict__ ga, const float* __restrict__ gbm1, int64_t N, uint32_t k0, uint32_t k1,
+    uint64_t cell_offset, const int64_t* __restrict__ cell_index, int32_t* __restrict__ out, int64_t ld,
+    unsigned long long* __restrict__ next_ticket)
+{
+    __shared__ float inv_k[prnb::kKTab];
+    __shared__ HeavyLds lds_all[kBlock / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    HeavyLds& L = lds_all[wv];
+    for (int k = tid; k < prnb::kKTab; k += kBlock) inv_k[k] = (k && k < prnb::kKTab - 1) ? 1.0f / (float)k : 0.0f;
+    __syncthreads();
+
+    int hg_top = 0, hp_top = 0;      // wave-uniform
+
+    auto cell_id = [&](int32_t n) -> uint64_t {
+        return cell_index ? (uint64_t)cell_index[n] : cell_offset + (uint64_t)n;
+    };
+
+    // ---- one PTRS attempt (or the whole of the rare small/huge-lambda branches) ---------------
+    auto poisson_pass = [&]() {
+        const int cnt = hp_top < 64 ? hp_top : 64;
+        bool again = false;
+        HPEntry e;
+        e.n = 0; e.g = 0; e.lam = 0.0f; e.attempt = 0;
+        if (lane < cnt) {
+            e = L.hp[hp_top - 1 - lane];
+            const uint64_t cell = cell_id(e.n);
+            const uint32_t c0 = (uint32_t)cell, c1 = (uint32_t)(cell >> 32);
+            const float lam = e.lam;
+            int32_t x = 0;
+            if (!(lam > 0.0f)) {
+                x = 0;
+            } else if (lam < prnb::kPoisInv) {
+                const prnb::Words w = prnb::philox4x32_10(c0, c1, (uint32_t)e.g, 0x80000000u, k0, k1);
+                x = prnb::chop_down(w.w[0], prnb::det_exp(-lam), lam, 0.0f, inv_k);
+            } else if (!(lam < prnb::kLamBig)) {
+                const prnb::Words w = prnb::philox4x32_10(c0, c1, (uint32_t)e.g, 0x80000000u, k0, k1);
+                const float z = prnb::det_sqrt(-2.0f * prnb::det_log(prnb::unif(w.w[0]))) * prnb::det_cos2pi(w.w[1]);
+                const float kf = __builtin_floorf(PRNB_FMA(prnb::det_sqrt(lam), z, lam) + 0.5f);
+                x = (int32_t)__builtin_fminf(__builtin_fmaxf(kf, 0.0f), 2147483520.0f);
+            } else {
+                const int j = e.attempt;
+                const prnb::Words w =
+                    prnb::philox4x32_10(c0, c1, (uint32_t)e.g, 0x80000000u + (uint32_t)(j >> 1), k0, k1);
+                const float slam = prnb::det_sqrt(lam);
+                const float bb = PRNB_FMA(2.53f, slam, 0.931f);
+                const float aa = PRNB_FMA(0.02483f, bb, -0.059f);
+                const float U = prnb::unif((j & 1) ? w.w[2] : w.w[0]) - 0.5f;
+                const float V = prnb::unif((j & 1) ? w.w[3] : w.w[1]);
+                const float us = __builtin_fmaxf(0.5f - __builtin_fabsf(U), 5.8207661e-11f);
+                const float rus = prnb::det_rcp(us);
+                float kf = __builtin_floorf(PRNB_FMA(PRNB_FMA(2.0f * aa, rus, bb), U, lam + 0.43f));
+                const float vr = PRNB_FMA(-3.6224f, prnb::det_rcp(bb - 2.0f), 0.9277f);
+                bool accept = (us >= 0.07f) && (V <= vr);
+                if (!accept && !(kf < 0.0f || (us < 0.013f && V > us))) {
+                    const float invalpha = PRNB_FMA(1.1328f, prnb::det_rcp(bb - 3.4f), 1.1239f);
+                    const float lhs = prnb::det_log((V * invalpha) * prnb::det_rcp(PRNB_FMA(aa * rus, rus, bb)));
+                    float rhs;
+                    if (kf < 10.0f) {
+                        rhs = PRNB_FMA(kf, prnb::det_log(lam), -lam) - prnb::logfact_small((int)kf);
+                    } else {
+                        const float rk = prnb::det_rcp(kf);
+                        const float d = (lam - kf) * rk;
+                        const float lp = prnb::det_log1pmx(d, lam * rk);
+                        const float st = rk * PRNB_FMA(-0.0027777778f, rk * rk, 0.083333336f);
+                        rhs = PRNB_FMA(kf, lp, PRNB_FMA(-0.5f, prnb::det_log(6.2831855f * kf), -st));
+                    }
+                    accept = lhs <= rhs;
+                }
+                if (!accept) {
+                    kf = __builtin_floorf(lam);
+                    again = j + 1 < 2 * prnb::kMaxTries;
+                }
+                x = (int32_t)__builtin_fminf(__builtin_fmaxf(kf, 0.0f), 2147483520.0f);
+            }
+            if (!again && x != 0) out[(int64_t)e.n * ld + e.g] = x;
+        }
+        hp_top -= cnt;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(again);
+        if (again) {
+            e.attempt += 1;
+            L.hp[hp_top + lane_rank(m)] = e;
+        }
+        hp_top += __popcll(m);
+    };
+
+    // ---- one Marsaglia-Tsang attempt ------------------------------------------------------------
+    auto gamma_pass = [&]() {
+        const int cnt = hg_top < 64 ? hg_top : 64;
+        bool again = false, accepted = false;
+        HGEntry e;
+        e.n = 0; e.g = 0; e.attempt = 0; e.row = 0;
+        float lam = 0.0f;
+        if (lane < cnt) {
+            e = L.hg[hg_top - 1 - lane];
+            const prnb::Params P = prnb::make_params(means[(int64_t)e.row * G + e.g], scal[e.n],
+                                                     ga[e.g], gbm1[e.g]);
+            const float r = P.m * P.inv_th;
+            if (r >= prnb::kRMin) {             // else P(X > 0) < 2^-32: the count stays 0
+                const uint64_t cell = cell_id(e.n);
+                const bool boost = r < 1.0f;
+                const float rr = boost ? r + 1.0f : r;
+                const float dd = rr - 0.33333334f;
+                const float cc = prnb::det_rcp(3.0f * prnb::det_sqrt(dd));
+                const int i = e.attempt;
+                const bool last = (i == prnb::kMaxTries - 1);
+                const prnb::Words w = prnb::philox4x32_10((uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)e.g,
+                                                          1u + (uint32_t)i, k0, k1);
+                const float x = prnb::det_sqrt(-2.0f * prnb::det_log(prnb::unif(w.w[0]))) * prnb::det_cos2pi(w.w[1]);
+                const float t = cc * x;
+                const float v1 = 1.0f + t;
+                float v = 1.0f;
+                bool ok;
+                if (!(v1 > 0.0f)) {
+                    ok = last;
+                } else {
+                    v = (v1 * v1) * v1;
+                    ok = last;
+                    if (!ok) {
+                        const float u = prnb::unif(w.w[2]);
+                        const float x2 = x * x;
+                        ok = u < PRNB_FMA(-0.0331f, x2 * x2, 1.0f);
+                        if (!ok) {
+                            const float t2 = t * t;
+                            const float h = PRNB_FMA(3.0f, prnb::det_log1pmx(t, v1), PRNB_FMA(-t2, t, -3.0f * t2));
+                            ok = prnb::det_log(u) < PRNB_FMA(dd, h, 0.5f * x2);
+                        }
+                    }
+                }
+                if (ok) {
+                    float g = dd * v;
+                    if (boost) g = g * prnb::det_exp(prnb::det_log(prnb::unif(w.w[3])) * prnb::det_rcp(r));
+                    lam = P.theta * g;
+                    accepted = true;
+                } else {
+                    again = true;
+                }
+            }
+        }
+        hg_top -= cnt;
+        const unsigned long long ma = __builtin_amdgcn_ballot_w64(again);
+        if (again) {
+            e.attempt += 1;
+            L.hg[hg_top + lane_rank(ma)] = e;
+        }
+        hg_top += __popcll(ma);
+        const unsigned long long mp = __builtin_amdgcn_ballot_w64(accepted);
+        if (accepted) {
+            HPEntry p;
+            p.n = e.n; p.g = e.g; p.lam = lam; p.attempt = 0;
+            L.hp[hp_top + lane_rank(mp)] = p;
+        }
+        hp_top += __popcll(mp);
+        while (hp_top >= 64) poisson_pass();
+    };
+
+    // ---- scan the flags in tickets of 512 bytes (one 8-byte load per lane) ----------------------
+    // The number of flagged genes of a cell grows steeply with its library-size factor, so the
+    // work per ticket is very uneven.  The first 15/16 of the tickets are dealt round-robin
+    // (consecutive tickets of a cell land on different waves); the last sixteenth is handed out
+    // dynamically to level the tail.  One atomic head saturates near 90 tickets/us on this
+    // chip, so there are eight heads (tickets t with t % 8 == s belong to head s) and a wave
+    // starts at the head of its block's slot (blocks b and b+8 share an XCD) and moves on
+    // when a head runs dry.
+    const int32_t bytes_per_cell = tiles_g * 64;          // a multiple of 8
+    const int32_t batches_per_cell = (bytes_per_cell + 511) / 512;
+    const int64_t tickets = N * batches_per_cell;
+    const int64_t static_tickets = tickets - tickets / 16;
+    const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + wv;
+    const int64_t n_waves = (int64_t)gridDim.x * (kBlock / 64);
+
+    // a ticket's flag bytes and row index are requested one ticket ahead of their use
+    struct Ticket { int64_t n; int32_t byte0, row; unsigned long long bits; };
+    auto fetch = [&](int64_t tk) -> Ticket {
+        Ticket t;
+        t.n = 0; t.byte0 = 0; t.row = 0; t.bits = 0ull;
+        if (tk < tickets) {
+            t.n = tk / batches_per_cell;
+            t.byte0 = (int32_t)(tk - t.n * batches_per_cell) * 512 + lane * 8;   // 8 flag bytes per lane
+            t.row = row_of_cell[t.n];
+            if (t.byte0 < bytes_per_cell)
+                t.bits = *reinterpret_cast<const unsigned long long*>(flags + t.n * bytes_per_cell + t.byte0);
+        }
+        return t;
+    };
+    auto expand = [&](const Ticket& t) {
+        unsigned long long bits = t.bits;
+        while (__builtin_amdgcn_ballot_w64(bits != 0ull) != 0ull) {
+            const bool has = bits != 0ull;
+            const int b = has ? __builtin_ctzll(bits) : 0;
+            bits &= bits - 1ull;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(has);
+            if (has) {
+                const int32_t byte = t.byte0 + (b >> 3);   // = tile*64 + lane-in-tile
+                HGEntry e;
+                e.n = (int32_t)t.n; e.g = byte * 4 + (b & 7); e.attempt = 0; e.row = t.row;
+                L.hg[hg_top + lane_rank(m)] = e;
+            }
+            hg_top += __popcll(m);
+            while (hg_top >= 64) gamma_pass();
+        }
+    };
+
+    {
+        Ticket cur = fetch(wave < static_tickets ? wave : tickets);
+        for (int64_t tk = wave; tk < static_tickets; tk += n_waves) {
+            const Ticket nxt = fetch(tk + n_waves < static_tickets ? tk + n_waves : tickets);
+            expand(cur);
+            cur = nxt;
+        }
+    }
+    const int64_t dyn = tickets - static_tickets;
+    for (int turn = 0; turn < 8; ++turn) {
+        const int head = (int)((blockIdx.x + turn) & 7);
+        const int64_t mine = (dyn - head + 7) / 8;          // tickets static_tickets + head + 8*i, i < mine
+        for (;;) {
+            unsigned long long got = 0ull;
+            if (lane == 0) got = atomicAdd(next_ticket + head * 16, 1ull);   // heads 128 B apart
+            const int64_t i = (int64_t)__builtin_amdgcn_readfirstlane((uint32_t)got) |
+                              ((int64_t)__builtin_amdgcn_readfirstlane((uint32_t)(got >> 32)) << 32);
+            if (i >= mine) break;
+            expand(fetch(static_tickets + head + 8 * i));
+        }
+    }
+    while (hg_top > 0) gamma_pass();
+    while (hp_top > 0) poisson_pass();
+}
+
+}  // namespace k3

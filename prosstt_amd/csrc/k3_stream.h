@@ -10,13 +10,13 @@
 // Run lane-per-sample, every wave pays for its slowest lane in every one of these.  Here
 //   stage 1 (uniform)   one count-matrix row segment per wave pass: 16-B mean load, one
 //                       Philox call per lane, bound test; the row is stored as zeros (one
-//                       coalesced 1 KiB store); survivors are pushed on stack S1, samples of
-//                       the gamma-Poisson path on SH;
+//                       coalesced 1 KiB store); survivors are pushed on stack S1;
 //   stage 2 (64 of S1)  exact P(X = 0); survivors (k >= 1) are pushed on S2 with the pmf
 //                       state at k = 1;
 //   stage 3 (lanes pull from S2)  one pmf step per lane per pass; a lane that finishes stores
 //                       its count (a 4-B store over the zero) and pulls the next entry;
-//   heavy  (64 of SH)   gamma-Poisson.
+//   samples of the gamma-Poisson path are only FLAGGED here (4 bits per lane and pass);
+//   sample_counts_heavy_kernel (k3_heavy.h) draws them afterwards.
 // Results are pure functions of (sample parameters, seed, global cell id, gene), so the
 // order in which the stacks are drained cannot change them.
 #pragma once
@@ -32,17 +32,16 @@ constexpr int kBlock = 256;        // 4 waves
 constexpr int kTileG = 256;        // genes per wave pass: 64 lanes x 4
 constexpr int kStripCells = 128;   // cells per wave: long strips amortise the drain of stage 3
 constexpr int kS1Cap = 320;        // < 64 left over + 256 pushed by one pass
-constexpr int kS2Cap = 128;        // < 64 left over + 64 pushed by one stage-2 pass
-constexpr int kSHCap = 320;
+constexpr int kS2Cap = 96;         // < 32 left over + 64 pushed by one stage-2 pass
+constexpr int kS2Run = 32;         // stage 3 runs while S2 holds at least this many entries
 
-struct S1Entry { float m, theta; uint32_t w, pos; };
+struct S1Entry { float m, theta; uint32_t w, pos; };   // theta = a*m + b - 1, not yet clamped
 struct S2Entry { float ps, num, q; uint32_t rem; };   // pmf (x 2^32) and numerator at k = 1
 
 struct WaveLds {
     S1Entry s1[kS1Cap];
     S2Entry s2[kS2Cap];
     uint32_t s2pos[kS2Cap];
-    uint32_t sh[kSHCap];
 };
 
 // rank of this lane among the lanes whose bit is set in `mask`
@@ -57,7 +56,8 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
     const float* __restrict__ means, int32_t G, const int32_t* __restrict__ row_of_cell,
     const float* __restrict__ scal, const float* __restrict__ ga, const float* __restrict__ gbm1,
     int64_t N, uint32_t k0, uint32_t k1, uint64_t cell_offset, const int64_t* __restrict__ cell_index,
-    int32_t* __restrict__ out, int64_t ld, int64_t* __restrict__ domain_flag, int32_t strips)
+    int32_t* __restrict__ out, int64_t ld, int32_t strips,
+    uint8_t* __restrict__ heavy_flags, int32_t tiles_g)
 {
     __shared__ float inv_k[prnb::kKTab + 4];          // 0 from the sentinel (k = KTAB-1) on
     __shared__ WaveLds lds_all[kBlock / 64];
@@ -88,8 +88,7 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
         bm1[j] = in ? gbm1[g0 + j] : 0.0f;
     }
 
-    int s1_top = 0, s2_top = 0, sh_top = 0;          // wave-uniform
-    bool bad = false;
+    int s1_top = 0, s2_top = 0;                      // wave-uniform
     // stage-3 lane state
     bool active = false;
     float ps = 0.0f, num = 0.0f, q = 0.0f;
@@ -159,12 +158,13 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
         e2.ps = 0.0f; e2.num = 0.0f; e2.q = 0.0f; e2.rem = 0u;
         if (mine) {
             const S1Entry e = L.s1[s1_top - 1 - lane];
-            const float u1 = 1.0f + e.theta;
-            const float d = prnb::det_rcp(e.theta * u1);
-            const float inv_th = d * u1, inv_u1 = d * e.theta;
-            const float qq = e.theta * inv_u1;
+            const float theta = __builtin_fminf(__builtin_fmaxf(e.theta, prnb::kThetaMin), prnb::kThetaMax);
+            const float u1 = 1.0f + theta;
+            const float d = prnb::det_rcp(theta * u1);
+            const float inv_th = d * u1, inv_u1 = d * theta;
+            const float qq = theta * inv_u1;
             const float mpp = e.m * inv_u1;
-            const float t = e.m * (prnb::det_log1p(e.theta) * inv_th);
+            const float t = e.m * (prnb::det_log1p(theta) * inv_th);
             const float p0 = __builtin_fminf(prnb::det_exp(-t), 0.99999994f);
             const float ps0 = p0 * 4294967296.0f;
             const uint32_t pf = (uint32_t)ps0;
@@ -187,54 +187,57 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
         s2_top += __popcll(m2);
     };
 
-    // ---- heavy: gamma-Poisson for up to 64 entries of SH -------------------------------------
-    auto heavy_pass = [&]() {
-        const int cnt = sh_top < 64 ? sh_top : 64;
-        if (lane < cnt) {
-            const uint32_t p = L.sh[sh_top - 1 - lane];
-            const int64_t n = n0 + (int64_t)(p >> 8);
-            const int32_t g = gbase + (int32_t)(p & 255u);
-            const uint64_t cell = cell_index ? (uint64_t)cell_index[n] : cell_offset + (uint64_t)n;
-            const prnb::Params P =
-                prnb::make_params(means[(int64_t)row_of_cell[n] * G + g], scal[n], ga[g], gbm1[g]);
-            const int32_t x = prnb::heavy_draw(P, (uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)g,
-                                               k0, k1, inv_k);
-            if (x != 0) strip_out[(p >> 8) * ld32 + (p & 255u)] = x;
-        }
-        sh_top -= cnt;
-    };
-
     // ---- stage 1 over the strip ----------------------------------------------------------------
-    // the row index, scaling and mean segment of the NEXT cell are loaded while this one is
-    // processed (their latency would otherwise sit in front of every pass)
-    struct Row { int64_t row; float s; uint64_t cell; float M[4]; };
-    auto load_row = [&](int cl) -> Row {
-        Row r;
-        const int64_t n = n0 + cl;
-        r.row = row_of_cell[n];
-        r.s = scal[n];
-        r.cell = cell_index ? (uint64_t)cell_index[n] : cell_offset + (uint64_t)n;
+    // Row index, scaling and global id of all 128 cells of the strip are fetched once (lane l
+    // holds cells l and l+64) and handed out by v_readlane; the mean segments are loaded two
+    // cells ahead.  Nothing a pass needs is waited for inside the pass.
+    static_assert(kStripCells == 128, "two cells per lane");
+    int32_t rowv[2];
+    float sv[2];
+    uint64_t cellv[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int c = lane + 64 * h;
+        const int64_t n = n0 + (c < cells ? c : 0);
+        rowv[h] = row_of_cell[n];
+        sv[h] = scal[n];
+        cellv[h] = cell_index ? (uint64_t)cell_index[n] : cell_offset + (uint64_t)n;
+    }
+    auto cell_row = [&](int cl) -> int64_t {
+        const int src = cl & 63;
+        return (int64_t)((cl < 64) ? __builtin_amdgcn_readlane(rowv[0], src) : __builtin_amdgcn_readlane(rowv[1], src));
+    };
+    struct Seg { float M[4]; };
+    auto load_seg = [&](int cl) -> Seg {
+        Seg r;
         r.M[0] = r.M[1] = r.M[2] = r.M[3] = 0.0f;
-        if (g0 < G) {
+        if (cl < cells && g0 < G) {
+            const int64_t row = cell_row(cl);
             if (VEC) {
-                const float4 v = *reinterpret_cast<const float4*>(means + r.row * G + g0);
+                const float4 v = *reinterpret_cast<const float4*>(means + row * G + g0);
                 r.M[0] = v.x; r.M[1] = v.y; r.M[2] = v.z; r.M[3] = v.w;
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (g0 + j < G) r.M[j] = means[r.row * G + g0 + j];
+                    if (g0 + j < G) r.M[j] = means[row * G + g0 + j];
             }
         }
         return r;
     };
-    Row cur = load_row(0);
+    Seg cur = load_seg(0), nxt = load_seg(1);
 #pragma unroll 1
     for (int cl = 0; cl < cells; ++cl) {
-        const Row nxt = load_row(cl + 1 < cells ? cl + 1 : cl);
+        const Seg nn = load_seg(cl + 2);
+        const int src = cl & 63;
+        const float s = __uint_as_float((cl < 64) ? __builtin_amdgcn_readlane(__float_as_uint(sv[0]), src)
+                                                  : __builtin_amdgcn_readlane(__float_as_uint(sv[1]), src));
+        const uint32_t c_lo = (cl < 64) ? __builtin_amdgcn_readlane((uint32_t)cellv[0], src)
+                                        : __builtin_amdgcn_readlane((uint32_t)cellv[1], src);
+        const uint32_t c_hi = (cl < 64) ? __builtin_amdgcn_readlane((uint32_t)(cellv[0] >> 32), src)
+                                        : __builtin_amdgcn_readlane((uint32_t)(cellv[1] >> 32), src);
+        const uint64_t cell = ((uint64_t)c_hi << 32) | c_lo;
         // every lane runs the whole pass (lanes beyond G just never qualify): the stack tops
         // must stay wave-uniform, so no ballot may sit under a divergent branch
-        const float s = cur.s;
-        const uint64_t cell = cur.cell;
         const float M[4] = {cur.M[0], cur.M[1], cur.M[2], cur.M[3]};
         if (g0 < G) {
             int32_t* dst = strip_out + (int64_t)cl * ld + lane * 4;
@@ -254,23 +257,22 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
         const prnb::Words W =
             prnb::philox4x32_10((uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)g0 >> 2, 0u, k0, k1);
 #endif
+        uint32_t hflag = 0u;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            // genes beyond G carry M = 0 and so never qualify; no lane-dependent branch here
             const float m = M[j] * s;
-            const float th_raw = PRNB_FMA(a[j], m, bm1[j]);
-            const bool in = g0 + j < G;
-            const bool valid = in && (m > 0.0f) && (th_raw > 0.0f);
-            bad = bad || (in && (!(m > 0.0f) || th_raw < 0.0f));
-            const float theta = __builtin_fminf(__builtin_fmaxf(th_raw, prnb::kThetaMin), prnb::kThetaMax);
+            const float theta = PRNB_FMA(a[j], m, bm1[j]);
+            const bool valid = (m > 0.0f) && (theta > 0.0f);
             const bool light = (m <= prnb::kLightM) && (theta <= prnb::kLightTheta);
-            // P(X=0) = exp(-m*log1p(theta)/theta) >= exp(-m) >= 1 - m + m^2/2 - m^3/6; the 1e-5
-            // margin covers every rounding of the exact evaluation, so a sample settled here
-            // is one the exact path would also call 0.
-            const float bound = PRNB_FMA(PRNB_FMA(PRNB_FMA(-0.16666667f, m, 0.5f), m, -1.0f), m, 1.0f) - 1.0e-5f;
-            const bool zero = (float)W.w[j] < bound * 4294967296.0f;
+            // P(X=0) = exp(-m*log1p(theta)/theta) >= exp(-m) >= 1 - m + m^2/2 - m^3/6.  The
+            // polynomial is evaluated times 2^32 with 1e-5 taken off the constant term: far more
+            // than every rounding of the exact evaluation, so a sample settled here is one the
+            // exact path would also call 0.
+            const float bound32 = PRNB_FMA(PRNB_FMA(PRNB_FMA(-715827882.7f, m, 2147483648.0f), m, -4294967296.0f),
+                                           m, 4294924346.0f);
+            const bool zero = (float)W.w[j] < bound32;
             const bool to_s1 = valid && light && !zero;
-            const bool to_sh = valid && !light;
-            const uint32_t p = ((uint32_t)cl << 8) | (uint32_t)(lane * 4 + j);
             const unsigned long long m1 = __builtin_amdgcn_ballot_w64(to_s1);
             if (to_s1) {
                 S1Entry e;
@@ -278,41 +280,30 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
                 L.s1[s1_top + lane_rank(m1)] = e;
             }
             s1_top += __popcll(m1);
-            const unsigned long long mh = __builtin_amdgcn_ballot_w64(to_sh);
-            if (mh != 0ull) {
-                if (to_sh) L.sh[sh_top + lane_rank(mh)] = p;
-                sh_top += __popcll(mh);
-            }
+            hflag |= (valid && !light) ? (1u << j) : 0u;
         }
+        // gamma-Poisson samples are only flagged: 4 bits per lane, one byte per (cell, tile, lane)
+        heavy_flags[(((n0 + cl) * tiles_g + tile_g) << 6) + lane] = (uint8_t)hflag;
 #if K3_ABLATE == 2      // stage 1 only
-        s1_top = 0; sh_top = 0;
+        s1_top = 0;
 #elif K3_ABLATE == 1    // no stage 3
         while (s1_top >= 64) { stage2_pass(); s2_top = 0; }
-        while (sh_top >= 64) heavy_pass();
-#elif K3_ABLATE == 4    // no heavy
-        while (s1_top >= 64) {
-            stage2_pass();
-            while (s2_top >= 64) stage3_pass();
-        }
-        sh_top = 0;
 #else
         while (s1_top >= 64) {
             stage2_pass();
-            while (s2_top >= 64) stage3_pass();
+            while (s2_top >= kS2Run) stage3_pass();
         }
-        while (sh_top >= 64) heavy_pass();
 #endif
         cur = nxt;
+        nxt = nn;
     }
 
     // ---- drain ------------------------------------------------------------------------------------
     while (s1_top > 0) {
         stage2_pass();
-        while (s2_top >= 64) stage3_pass();
+        while (s2_top >= kS2Run) stage3_pass();
     }
     while (s2_top > 0 || __builtin_amdgcn_ballot_w64(active) != 0ull) stage3_pass();
-    while (sh_top > 0) heavy_pass();
-    if (bad) *domain_flag = 1;
 }
 
 }  // namespace k3

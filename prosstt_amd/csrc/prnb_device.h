@@ -15,7 +15,7 @@
 
 namespace prnb {
 
-constexpr float kLightM = 12.0f;       // light path iff m <= 12 and theta <= 16
+constexpr float kLightM = 19.0f;       // light path iff m <= 19 and theta <= 16 (P0 >= e^-19 > 2^-28)
 constexpr float kLightTheta = 16.0f;
 constexpr float kThetaMin = 8.6736174e-19f;  // 2^-60
 constexpr float kThetaMax = 1.0e18f;
@@ -240,12 +240,18 @@ __device__ __forceinline__ float gamma_scaled(float r, float theta, uint32_t c0,
     float v = 1.0f;
     Words w;
     for (int i = 0; i < kMaxTries; ++i) {
+        const bool last = (i == kMaxTries - 1);
         w = philox4x32_10(c0, c1, gene, 1u + (uint32_t)i, k0, k1);
         const float x = det_sqrt(-2.0f * det_log(unif(w.w[0]))) * det_cos2pi(w.w[1]);
         const float t = cc * x;
         const float v1 = 1.0f + t;
-        if (!(v1 > 0.0f)) continue;
+        if (!(v1 > 0.0f)) {
+            v = 1.0f;
+            if (last) break;
+            continue;
+        }
         v = (v1 * v1) * v1;
+        if (last) break;
         const float u = unif(w.w[2]);
         const float x2 = x * x;
         if (u < PRNB_FMA(-0.0331f, x2 * x2, 1.0f)) break;

@@ -22,6 +22,7 @@
 #include "../../include/prosstt_amd.h"
 #include "prnb_device.h"
 #include "k3_stream.h"
+#include "k3_heavy.h"
 
 #define PA_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -72,7 +73,7 @@ static int next_event_pair(prosstt_amd_ctx* c, hipEvent_t* a, hipEvent_t* b)
     c->events_used += 2;
     return 0;
 }
-constexpr int kScratchWords = 64;
+constexpr int kScratchWords = 256;     // [0] domain flag, [1..] lineage results, [128..255] ticket heads
 
 static int ws_reserve(prosstt_amd_ctx* c, size_t bytes)
 {
@@ -359,6 +360,50 @@ __global__ __launch_bounds__(256) void means_from_rel_kernel(const double* __res
     }
 }
 
+// ---- domain check of the streaming path (PROSSTT_AMD_CHECK_DOMAIN) ----------------------------
+// scipy's argument check in the reference fails iff some mean m = M*s is <= 0 (or NaN) or some
+// theta = a*m + b - 1 is < 0.  With every scaling > 0 the first holds iff a USED row of the mean
+// tensor has an entry <= 0; with every a >= 0 and b >= 1 the second cannot happen.  Only when a
+// gene has a < 0 or b < 1 is the full N x G test needed.
+__global__ void domain_rows_kernel(const int32_t* __restrict__ row_of_cell, const float* __restrict__ scal,
+                                   int64_t N, const float* __restrict__ ga, const float* __restrict__ gbm1,
+                                   int32_t G, uint8_t* __restrict__ rows_used, int64_t* __restrict__ flagp)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) {
+        rows_used[row_of_cell[i]] = 1;
+        if (!(scal[i] > 0.0f)) flagp[0] = 1;
+    }
+    if (i < G && (!(ga[i] >= 0.0f) || !(gbm1[i] >= 0.0f))) flagp[2] = 1;     // needs the full test
+}
+
+__global__ void domain_means_kernel(const float* __restrict__ means, int64_t rows, int64_t G,
+                                    const uint8_t* __restrict__ rows_used, int64_t* __restrict__ flagp)
+{
+    const int64_t total = rows * G;
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        bad = bad || (rows_used[i / G] && !(means[i] > 0.0f));
+    if (bad) flagp[0] = 1;
+}
+
+__global__ void domain_full_kernel(const float* __restrict__ means, int32_t G,
+                                   const int32_t* __restrict__ row_of_cell, const float* __restrict__ scal,
+                                   const float* __restrict__ ga, const float* __restrict__ gbm1, int64_t N,
+                                   int64_t* __restrict__ flagp)
+{
+    if (flagp[2] == 0) return;
+    const int64_t total = N * (int64_t)G;
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / G;
+        const int32_t g = (int32_t)(i - n * G);
+        const float m = means[(int64_t)row_of_cell[n] * G + g] * scal[n];
+        bad = bad || !(m > 0.0f) || (__builtin_fmaf(ga[g], m, gbm1[g]) < 0.0f);
+    }
+    if (bad) flagp[0] = 1;
+}
+
 // ------------------------------------------------------------------ ABI
 
 PA_EXPORT int prosstt_amd_version(void) { return PROSSTT_AMD_VERSION; }
@@ -445,11 +490,13 @@ PA_EXPORT int prosstt_amd_last_kernel_ms(prosstt_amd_ctx* c, float* ms)
 struct SamplerArgs {
     const float* means; const int32_t* row_of_cell;
     float *scal, *ga, *gbm1;
+    void* extra;     // `extra_bytes` of workspace behind the parameter vectors (256-B aligned)
 };
 
 static int sampler_setup(prosstt_amd_ctx* c, Staging& st, const float* means, int64_t rows, int32_t G,
                          const int32_t* row_of_cell, const double* scaling, const double* alpha,
-                         const double* beta, int64_t N, uint32_t flags, SamplerArgs* A)
+                         const double* beta, int64_t N, uint32_t flags, SamplerArgs* A,
+                         size_t extra_bytes = 0)
 {
     if (!c) return fail(PROSSTT_AMD_EINVAL, "ctx is NULL");
     if (N < 0 || G < 0 || rows < 0) return fail(PROSSTT_AMD_EINVAL, "negative size");
@@ -478,13 +525,15 @@ static int sampler_setup(prosstt_amd_ctx* c, Staging& st, const float* means, in
         beta = (const double*)d;
     }
     const int64_t n_pad = (N + 15) & ~(int64_t)15;
-    int rc = ws_reserve(c, ((size_t)n_pad + 2 * (size_t)G) * sizeof(float));
+    const size_t vec_bytes = ((((size_t)n_pad + 2 * (size_t)G) * sizeof(float)) + 255) & ~(size_t)255;
+    int rc = ws_reserve(c, vec_bytes + extra_bytes);
     if (rc) return rc;
     A->means = means;
     A->row_of_cell = row_of_cell;
     A->scal = (float*)c->ws;
     A->ga = A->scal + n_pad;
     A->gbm1 = A->ga + G;
+    A->extra = (char*)c->ws + vec_bytes;
     const int64_t span = N > G ? N : G;
     prep_params_kernel<<<dim3((unsigned)((span + 255) / 256)), dim3(256), 0, c->stream>>>(
         scaling, N, alpha, beta, G, A->scal, A->ga, A->gbm1);
@@ -500,10 +549,17 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
 {
     Staging st;
     SamplerArgs A{};
-    int rc = sampler_setup(c, st, means, rows, G, row_of_cell, scaling, alpha, beta, N, flags, &A);
+    // one flag byte per (cell, 256-gene tile, lane) for the gamma-Poisson samples, then one byte
+    // per row of the mean tensor for the domain check
+    const size_t flag_bytes = (flags & PROSSTT_AMD_KERNEL_TILED) ? 0
+        : (size_t)(N > 0 ? N : 0) * (size_t)(((int64_t)(G > 0 ? G : 0) + kTileG - 1) / kTileG) * 64;
+    const size_t word_bytes = ((flag_bytes + 255) & ~(size_t)255) + (size_t)(rows > 0 ? rows : 0) + 256;
+    int rc = sampler_setup(c, st, means, rows, G, row_of_cell, scaling, alpha, beta, N, flags, &A, word_bytes);
     if (rc) return rc;
     if (N == 0 || G == 0) return 0;
     if (!out) return fail(PROSSTT_AMD_EINVAL, "out is NULL");
+    uint8_t* heavy_flags = (uint8_t*)A.extra;
+    uint8_t* rows_used = heavy_flags + ((flag_bytes + 255) & ~(size_t)255);
     if (ld_out < G) return fail(PROSSTT_AMD_EINVAL, "ld_out %lld < G %d", (long long)ld_out, G);
 
     if (cell_index && (flags & PROSSTT_AMD_HOST_INPUTS)) {
@@ -517,7 +573,7 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
         if ((rc = st.alloc(&p, (size_t)N * ld_out * 4))) return rc;
         d_out = (int32_t*)p;
     }
-    HIP_TRY(hipMemsetAsync(c->scratch, 0, 8, c->stream));
+    HIP_TRY(hipMemsetAsync(c->scratch, 0, 32, c->stream));   // [0] domain flag, [2] full-test request
 
     const int64_t tiles_g = ((int64_t)G + kTileG - 1) / kTileG;
     const bool vec = (G % 4 == 0) && (ld_out % 4 == 0) && (((uintptr_t)A.means & 15) == 0) &&
@@ -545,19 +601,41 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
             return fail(PROSSTT_AMD_EINVAL, "ld_out too large for 32-bit strip offsets");
         const int64_t strips = (N + k3::kStripCells - 1) / k3::kStripCells;
         const int64_t groups = (strips + 3) / 4;
-        if (groups * tiles_g > 0x7fffffffll) return fail(PROSSTT_AMD_EINVAL, "too many tiles; chunk the cells");
+        if (groups * tiles_g > 0x7fffffffll || N > 0x7fffffffll)
+            return fail(PROSSTT_AMD_EINVAL, "too many tiles; chunk the cells");
         const dim3 grid((unsigned)(groups * tiles_g)), block(k3::kBlock);
         if (vec)
             k3::sample_counts_stream_kernel<true><<<grid, block, 0, c->stream>>>(
                 A.means, G, A.row_of_cell, A.scal, A.ga, A.gbm1, N, k0, k1, cell_offset, cell_index, d_out,
-                ld_out, c->scratch, (int32_t)strips);
+                ld_out, (int32_t)strips, heavy_flags, (int32_t)tiles_g);
         else
             k3::sample_counts_stream_kernel<false><<<grid, block, 0, c->stream>>>(
                 A.means, G, A.row_of_cell, A.scal, A.ga, A.gbm1, N, k0, k1, cell_offset, cell_index, d_out,
-                ld_out, c->scratch, (int32_t)strips);
+                ld_out, (int32_t)strips, heavy_flags, (int32_t)tiles_g);
+        HIP_TRY(hipGetLastError());
+        if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, c->stream));   // the dominant kernel is timed alone
+        int64_t hblocks = (N + 3) / 4;
+        if (hblocks > 256 * 6) hblocks = 256 * 6;      // one resident round; cells are handed out dynamically
+        HIP_TRY(hipMemsetAsync(c->scratch + 128, 0, 128 * 8, c->stream));
+#if K3_ABLATE != 4
+        k3::sample_counts_heavy_kernel<<<dim3((unsigned)hblocks), block, 0, c->stream>>>(
+            heavy_flags, (int32_t)tiles_g, A.means, G, A.row_of_cell, A.scal, A.ga, A.gbm1, N, k0, k1, cell_offset,
+            cell_index, d_out, ld_out, (unsigned long long*)(c->scratch + 128));
+#endif
+        ev_stop = nullptr;
+        if (flags & PROSSTT_AMD_CHECK_DOMAIN) {
+            HIP_TRY(hipMemsetAsync(rows_used, 0, (size_t)rows, c->stream));
+            const int64_t span = N > G ? N : G;
+            domain_rows_kernel<<<dim3((unsigned)((span + 255) / 256)), dim3(256), 0, c->stream>>>(
+                A.row_of_cell, A.scal, N, A.ga, A.gbm1, G, rows_used, c->scratch);
+            domain_means_kernel<<<dim3(2048), dim3(256), 0, c->stream>>>(A.means, rows, G, rows_used, c->scratch);
+            domain_full_kernel<<<dim3(8192), dim3(256), 0, c->stream>>>(A.means, G, A.row_of_cell, A.scal, A.ga,
+                                                                      A.gbm1, N, c->scratch);
+            HIP_TRY(hipGetLastError());
+        }
     }
     HIP_TRY(hipGetLastError());
-    if (flags & PROSSTT_AMD_TIME_KERNEL) HIP_TRY(hipEventRecord(ev_stop, c->stream));
+    if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, c->stream));
     if (flags & PROSSTT_AMD_HOST_OUTPUT)
         HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)N * ld_out * 4, hipMemcpyDeviceToHost, c->stream));
     if (flags & PROSSTT_AMD_CHECK_DOMAIN) {
@@ -617,7 +695,7 @@ PA_EXPORT int prosstt_amd_lineage_attempt(prosstt_amd_ctx* c, const double* prog
 {
     if (!c || !programs || !H || !out_max) return fail(PROSSTT_AMD_EINVAL, "NULL argument");
     if (T <= 0 || K <= 0 || G <= 0 || n_sib < 0) return fail(PROSSTT_AMD_EINVAL, "bad size");
-    if (n_sib > kScratchWords - 2) return fail(PROSSTT_AMD_EINVAL, "more than %d siblings", kScratchWords - 2);
+    if (n_sib > 64) return fail(PROSSTT_AMD_EINVAL, "more than 64 siblings");
     if (n_sib && (!sib_programs || !sib_T || !out_anticorr)) return fail(PROSSTT_AMD_EINVAL, "NULL sibling argument");
     HIP_TRY(hipSetDevice(c->device));
 
@@ -641,7 +719,7 @@ PA_EXPORT int prosstt_amd_lineage_attempt(prosstt_amd_ctx* c, const double* prog
     int32_t* d_meta = (int32_t*)((char*)c->ws + prog_bytes);
     HIP_TRY(hipMemcpyAsync(d_prog, host.data(), prog_bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_meta, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemsetAsync(c->scratch, 0, kScratchWords * 8, c->stream));   // ordered_bits(x) > 0 for every x
+    HIP_TRY(hipMemsetAsync(c->scratch, 0, 128 * 8, c->stream));   // ordered_bits(x) > 0 for every x
     lineage_attempt_kernel<<<dim3((unsigned)((G + 255) / 256)), dim3(256), 0, c->stream>>>(
         d_prog, d_meta, T, K, H, G, (unsigned long long*)c->scratch + 1,
         (unsigned long long*)c->scratch + 2);
