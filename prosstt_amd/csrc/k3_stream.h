@@ -30,7 +30,7 @@ namespace k3 {
 
 constexpr int kBlock = 256;        // 4 waves
 constexpr int kTileG = 256;        // genes per wave pass: 64 lanes x 4
-constexpr int kStripCells = 128;   // cells per wave: long strips amortise the drain of stage 3
+constexpr int kStripCells = 128;   // most cells per wave: long strips amortise the drain of stage 3
 constexpr int kS1Cap = 320;        // < 64 left over + 256 pushed by one pass
 constexpr int kS2Cap = 96;         // < 32 left over + 64 pushed by one stage-2 pass
 constexpr int kS2Run = 32;         // stage 3 runs while S2 holds at least this many entries
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
     const float* __restrict__ means, int32_t G, const int32_t* __restrict__ row_of_cell,
     const float* __restrict__ scal, const float* __restrict__ ga, const float* __restrict__ gbm1,
     int64_t N, uint32_t k0, uint32_t k1, uint64_t cell_offset, const int64_t* __restrict__ cell_index,
-    int32_t* __restrict__ out, int64_t ld, int32_t strips,
+    int32_t* __restrict__ out, int64_t ld, int32_t strips, int32_t strip_cells,
     uint8_t* __restrict__ heavy_flags, int32_t tiles_g)
 {
     __shared__ float inv_k[prnb::kKTab + 4];          // 0 from the sentinel (k = KTAB-1) on
@@ -76,9 +76,9 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
     const int32_t strip = (blockIdx.x - tile_g * groups) * 4 + wv;
     const int32_t gbase = tile_g * kTileG;
     const int32_t g0 = gbase + lane * 4;
-    const int64_t n0 = (int64_t)strip * kStripCells;
+    const int64_t n0 = (int64_t)strip * strip_cells;
     if (strip >= strips || n0 >= N) return;          // whole wave leaves together (no barrier below)
-    const int cells = (int)((N - n0 < kStripCells) ? (N - n0) : kStripCells);
+    const int cells = (int)((N - n0 < strip_cells) ? (N - n0) : strip_cells);
 
     float a[4], bm1[4];
 #pragma unroll
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
     // Row index, scaling and global id of all 128 cells of the strip are fetched once (lane l
     // holds cells l and l+64) and handed out by v_readlane; the mean segments are loaded two
     // cells ahead.  Nothing a pass needs is waited for inside the pass.
-    static_assert(kStripCells == 128, "two cells per lane");
+    static_assert(kStripCells == 128, "two cells per lane");   // strip_cells <= kStripCells
     int32_t rowv[2];
     float sv[2];
     uint64_t cellv[2];

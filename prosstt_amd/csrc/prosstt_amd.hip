@@ -599,7 +599,11 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
     } else {
         if (ld_out * k3::kStripCells >= ((int64_t)1 << 32))
             return fail(PROSSTT_AMD_EINVAL, "ld_out too large for 32-bit strip offsets");
-        const int64_t strips = (N + k3::kStripCells - 1) / k3::kStripCells;
+        // strips of up to 128 cells per wave; shorter ones when the problem is too small to give
+        // every SIMD of the chip a few waves
+        int64_t strip_cells = k3::kStripCells;
+        while (strip_cells > 8 && ((N + strip_cells - 1) / strip_cells) * tiles_g < 4 * 5 * 1024) strip_cells /= 2;
+        const int64_t strips = (N + strip_cells - 1) / strip_cells;
         const int64_t groups = (strips + 3) / 4;
         if (groups * tiles_g > 0x7fffffffll || N > 0x7fffffffll)
             return fail(PROSSTT_AMD_EINVAL, "too many tiles; chunk the cells");
@@ -607,11 +611,11 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
         if (vec)
             k3::sample_counts_stream_kernel<true><<<grid, block, 0, c->stream>>>(
                 A.means, G, A.row_of_cell, A.scal, A.ga, A.gbm1, N, k0, k1, cell_offset, cell_index, d_out,
-                ld_out, (int32_t)strips, heavy_flags, (int32_t)tiles_g);
+                ld_out, (int32_t)strips, (int32_t)strip_cells, heavy_flags, (int32_t)tiles_g);
         else
             k3::sample_counts_stream_kernel<false><<<grid, block, 0, c->stream>>>(
                 A.means, G, A.row_of_cell, A.scal, A.ga, A.gbm1, N, k0, k1, cell_offset, cell_index, d_out,
-                ld_out, (int32_t)strips, heavy_flags, (int32_t)tiles_g);
+                ld_out, (int32_t)strips, (int32_t)strip_cells, heavy_flags, (int32_t)tiles_g);
         HIP_TRY(hipGetLastError());
         if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, c->stream));   // the dominant kernel is timed alone
         int64_t hblocks = (N + 3) / 4;

@@ -225,7 +225,8 @@ def g7_nb_tables():
     """Analytic NB law for a grid of (m, a, b): pmf[0..kmax], mean, variance
     (scipy.stats.nbinom with the reference's parametrisation n=r, p=1-p)."""
     grid = [(0.05, 0.2, 2.0), (0.5, 0.2, 2.0), (1.5, 0.15, 2.2), (1.5, 1e-4, 1.5), (4.0, 0.3, 3.0),
-            (9.0, 0.2, 2.0), (11.9, 1.0, 1.3), (12.1, 0.2, 2.0), (30.0, 0.2, 2.0), (30.0, 2.0, 2.0),
+            (9.0, 0.2, 2.0), (11.9, 1.0, 1.3), (12.1, 0.2, 2.0), (18.9, 0.2, 2.0), (18.9, 0.0, 1.0 + 1e-8),
+            (19.1, 0.2, 2.0), (15.0, 0.9, 2.4), (15.0, 1.1, 2.4), (30.0, 0.2, 2.0), (30.0, 2.0, 2.0),
             (100.0, 0.05, 1.5), (100.0, 1.2, 4.0), (400.0, 0.2, 2.0), (3000.0, 0.25, 2.0),
             (3.0, 5.0, 2.0), (20.0, 0.0, 1.0 + 1e-8), (0.7, 0.0, 1.0 + 1e-8), (2.0, 0.0, 7.0),
             (8.0, 3.0, 1.0), (50.0, 1e-4, 1.2)]
@@ -265,6 +266,10 @@ def g8_end_to_end():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                      # regenerate selected fixtures only, e.g. `make_golden.py g7_nb_tables`
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     g1_get_pr_umi()
     g2_walks()
     g3_lineage()
