@@ -272,26 +272,45 @@ static double from_ordered_bits(unsigned long long o)
 // progs: [0] current programs raw [T][K]; then for each sibling j two blocks, both
 // truncated to common_j = min(T, T_j) steps and centred over them:
 // current [common_j][K], sibling [common_j][K].   meta: n_sib, then common_j.
-// Thread = gene.  x_t = sum_k P[t][k] H[k][g]; all program reads are wave-uniform.
+// Block = 64 genes x 4 time chunks: wave c covers steps [c*T/4, (c+1)*T/4) of every series for
+// the block's 64 genes (x_t = sum_k P[t][k] H[k][g]; program reads are wave-uniform, the H
+// column of a gene sits in registers when K <= 32); the chunks' partial sums meet in LDS.
+constexpr int kLinChunks = 4;
+
+template <bool HREG>
 __global__ __launch_bounds__(256) void lineage_attempt_kernel(
     const double* __restrict__ progs, const int32_t* __restrict__ meta, int32_t T, int32_t K,
     const double* __restrict__ H, int64_t G, unsigned long long* __restrict__ max_bits,
     unsigned long long* __restrict__ anticorr)
 {
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ double part[kLinChunks][64][3];
+    const int gl = threadIdx.x & 63, c = threadIdx.x >> 6;
+    const int64_t g = (int64_t)blockIdx.x * 64 + gl;
     const bool live = g < G;
     const double* h = H + (live ? g : 0);
     const int n_sib = meta[0];
+    double hreg[HREG ? 32 : 1];
+    if (HREG) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) hreg[k] = k < K ? h[(int64_t)k * G] : 0.0;
+    }
+    auto dot = [&](const double* row) -> double {
+        double acc = 0.0;
+        if (HREG) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k)
+                if (k < K) acc = fma(row[k], hreg[k], acc);
+        } else {
+            for (int k = 0; k < K; ++k) acc = fma(row[k], h[(int64_t)k * G], acc);
+        }
+        return acc;
+    };
 
     double mx = -std::numeric_limits<double>::infinity();
-    for (int t = 0; t < T; ++t) {
-        double acc = 0.0;
-        for (int k = 0; k < K; ++k) acc = fma(progs[t * K + k], h[(int64_t)k * G], acc);
-        mx = fmax(mx, acc);
-    }
+    for (int t = (c * T) / kLinChunks; t < ((c + 1) * T) / kLinChunks; ++t) mx = fmax(mx, dot(progs + (int64_t)t * K));
     if (!live) mx = -std::numeric_limits<double>::infinity();
     for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
-    if ((threadIdx.x & 63) == 0) atomicMax(max_bits, ordered_bits(mx));
+    if (gl == 0) atomicMax(max_bits, ordered_bits(mx));
 
     const double* blk = progs + (int64_t)T * K;
     for (int j = 0; j < n_sib; ++j) {
@@ -300,21 +319,22 @@ __global__ __launch_bounds__(256) void lineage_attempt_kernel(
         const double* ps = blk + (int64_t)common * K;
         blk += 2 * (int64_t)common * K;
         double cov = 0.0, vx = 0.0, vy = 0.0;
-        for (int t = 0; t < common; ++t) {
-            double x = 0.0, y = 0.0;
-            for (int k = 0; k < K; ++k) {
-                const double hk = h[(int64_t)k * G];
-                x = fma(pc[t * K + k], hk, x);
-                y = fma(ps[t * K + k], hk, y);
-            }
+        for (int t = (c * common) / kLinChunks; t < ((c + 1) * common) / kLinChunks; ++t) {
+            const double x = dot(pc + (int64_t)t * K), y = dot(ps + (int64_t)t * K);
             cov = fma(x, y, cov);
             vx = fma(x, x, vx);
             vy = fma(y, y, vy);
         }
-        // Pearson r < 0  <=>  cov < 0 with both series non-constant (scipy returns NaN otherwise)
-        const bool neg = live && cov < 0.0 && vx > 0.0 && vy > 0.0;
-        const unsigned long long votes = __ballot(neg);
-        if ((threadIdx.x & 63) == 0 && votes) atomicAdd(&anticorr[j], (unsigned long long)__popcll(votes));
+        part[c][gl][0] = cov; part[c][gl][1] = vx; part[c][gl][2] = vy;
+        __syncthreads();
+        if (c == 0) {
+            for (int o = 1; o < kLinChunks; ++o) { cov += part[o][gl][0]; vx += part[o][gl][1]; vy += part[o][gl][2]; }
+            // Pearson r < 0  <=>  cov < 0 with both series non-constant (scipy returns NaN otherwise)
+            const bool neg = live && cov < 0.0 && vx > 0.0 && vy > 0.0;
+            const unsigned long long votes = __ballot(neg);
+            if (gl == 0 && votes) atomicAdd(&anticorr[j], (unsigned long long)__popcll(votes));
+        }
+        __syncthreads();
     }
 }
 
@@ -724,9 +744,12 @@ PA_EXPORT int prosstt_amd_lineage_attempt(prosstt_amd_ctx* c, const double* prog
     HIP_TRY(hipMemcpyAsync(d_prog, host.data(), prog_bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_meta, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->scratch, 0, 128 * 8, c->stream));   // ordered_bits(x) > 0 for every x
-    lineage_attempt_kernel<<<dim3((unsigned)((G + 255) / 256)), dim3(256), 0, c->stream>>>(
-        d_prog, d_meta, T, K, H, G, (unsigned long long*)c->scratch + 1,
-        (unsigned long long*)c->scratch + 2);
+    if (K <= 32)
+        lineage_attempt_kernel<true><<<dim3((unsigned)((G + 63) / 64)), dim3(256), 0, c->stream>>>(
+            d_prog, d_meta, T, K, H, G, (unsigned long long*)c->scratch + 1, (unsigned long long*)c->scratch + 2);
+    else
+        lineage_attempt_kernel<false><<<dim3((unsigned)((G + 63) / 64)), dim3(256), 0, c->stream>>>(
+            d_prog, d_meta, T, K, H, G, (unsigned long long*)c->scratch + 1, (unsigned long long*)c->scratch + 2);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(c->h_scratch, c->scratch, (2 + n_sib) * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));   // also keeps `host` alive until the H2D copies are done

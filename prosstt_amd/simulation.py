@@ -28,6 +28,41 @@ from . import sim_utils as sut
 # expression programs and coefficients (host draws)
 # ----------------------------------------------------------------------------------
 
+def _walk_loop(log_start, vel0, eta, eps):
+    """The reference's recurrence, step by step (simulation.py:114-121)."""
+    steps = len(eps) + 1
+    walk = np.zeros(steps)
+    velocity = np.zeros(steps)
+    walk[0] = log_start
+    velocity[0] = vel0
+    for t in range(steps - 1):
+        walk[t + 1] = walk[t] + velocity[t]
+        velocity[t + 1] = eta * velocity[t] + eps[t]
+    return walk
+
+
+def _walk_filter(log_start, vel0, eta, eps):
+    """Same binary64 operations in the same order, without the Python loop: the velocity
+    is the IIR filter y[n] = x[n] + eta*y[n-1] and the walk a left-to-right cumulative sum."""
+    from scipy.signal import lfilter
+    velocity = lfilter([1.0], [1.0, -eta], np.concatenate(([vel0], eps)))
+    return np.cumsum(np.concatenate(([log_start], velocity[:-1])))
+
+
+_WALK = None
+
+
+def _walk(log_start, vel0, eta, eps):
+    """Pick the filter form once, after checking on this machine that it reproduces the
+    loop bit for bit (it does wherever scipy's lfilter is built without fused multiply-add)."""
+    global _WALK
+    if _WALK is None:
+        probe = np.sin(np.arange(1, 64)) * 0.04
+        same = np.array_equal(_walk_loop(-0.3, 0.11, 0.73, probe), _walk_filter(-0.3, 0.11, 0.73, probe))
+        _WALK = _walk_filter if same else _walk_loop
+    return _WALK(log_start, vel0, eta, eps)
+
+
 def diffusion(steps):
     """Random walk with momentum (simulation.py:89-124).  Variates are drawn in the
     reference's order -- U, N, U, then (steps-1) x N -- so the walk is the same
@@ -37,14 +72,7 @@ def diffusion(steps):
     s_eps = 2 / steps
     eta = random.random_sample() * 1 + 0
     eps = random.standard_normal(steps - 1) * s_eps + 0 if steps > 1 else np.zeros(0)
-    walk = np.zeros(steps)
-    velocity = np.zeros(steps)
-    walk[0] = np.log(start)
-    velocity[0] = vel0
-    for t in range(steps - 1):
-        walk[t + 1] = walk[t] + velocity[t]
-        velocity[t + 1] = eta * velocity[t] + eps[t]
-    return walk
+    return _walk(np.log(start), vel0, eta, eps)
 
 
 def sim_expr_branch(branch_length, expr_progr, cutoff=0.2, max_loops=100):

@@ -18,7 +18,7 @@ def walk(rng, T, K):
     return rng.normal(0, 0.1, (T, K)).cumsum(axis=0) + np.log(rng.uniform(0, 1.5, K))
 
 
-@pytest.mark.parametrize("T,K,G,sib_T", [(50, 25, 20000, [50]), (40, 5, 64, []), (33, 7, 1001, [25, 60, 33]),
+@pytest.mark.parametrize("T,K,G,sib_T", [(50, 25, 20000, [50]), (40, 5, 64, []), (33, 7, 1001, [25, 60, 33]), (50, 40, 3000, [50, 20]), (3, 70, 130, [1]),
                                          (2, 2, 5, [2])])
 def test_attempt_matches_numpy(ctx, T, K, G, sib_T):
     import torch
