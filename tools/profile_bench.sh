@@ -4,7 +4,7 @@
 TAG=${1:-r01}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
-mkdir -p $O
+rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 cd $R
 ARGS="bench.py --steps 10 --warmup 2 --cpu-cells 0"
