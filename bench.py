@@ -82,10 +82,17 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
                      "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d" % (args.gpus, args.gpus))
+    # functional test of the N > 1 path on a 1-GPU box: PROSSTT_BENCH_BACKEND=gloo PROSSTT_BENCH_ONE_GPU=1
+    backend = os.environ.get("PROSSTT_BENCH_BACKEND", "nccl")
+    if os.environ.get("PROSSTT_BENCH_ONE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     from prosstt_amd import device, parallel, workloads
     ctx = device.get_context(local)
@@ -125,8 +132,9 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms = [ctx.last_kernel_ms()]         # mean over the K launches of the timed region
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device=ctx.torch_device)
-    k_max = torch.tensor([float(np.mean(kernel_ms))], dtype=torch.float64, device=ctx.torch_device)
+    red_dev = ctx.torch_device if backend == "nccl" else torch.device("cpu")
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    k_max = torch.tensor([float(np.mean(kernel_ms))], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         dist.all_reduce(k_max, op=dist.ReduceOp.MAX)

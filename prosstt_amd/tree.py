@@ -84,12 +84,12 @@ class Tree(object):
 
     @classmethod
     def from_newick(cls, newick_tree, modules=None, genes=def_genes, density=None):
-        """Lineage tree from a Newick string (tree.py:115-126); needs the optional
-        ``newick`` package."""
+        """Lineage tree from a Newick string (tree.py:115-126).  Uses the ``newick`` package
+        the reference depends on when it is installed, the built-in reader otherwise."""
         try:
             import newick
-        except ImportError as exc:
-            raise ImportError("Tree.from_newick needs the 'newick' package") from exc
+        except ImportError:
+            from . import _newick as newick
         from . import tree_utils as tu
         parsed = newick.loads(newick_tree)
         top, time, branches, br_points, root = tu.parse_newick(parsed, cls.def_time)

@@ -260,3 +260,16 @@ def test_install_as_prosstt():
         for k in [k for k in sys.modules if k == "prosstt" or k.startswith("prosstt.")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_from_newick():
+    """Tree.from_newick (tree.py:115-126, tree_utils.py:10-56): pre-order topology, lengths as
+    branch times (0 / missing -> def_time), root = the node without ancestor."""
+    t = ptree.Tree.from_newick("((C:30,D:20)B:50,E)A:40;", modules=4, genes=12)
+    assert t.topology == [["A", "B"], ["A", "E"], ["B", "C"], ["B", "D"]]
+    assert dict(t.time) == {"A": 40, "B": 50, "C": 30, "D": 20, "E": 40}
+    assert t.root == "A" and t.num_branches == 5 and t.branch_points == 2 and t.G == 12
+    assert dict(t.branch_times()) == {"A": [0, 39], "B": [40, 89], "E": [40, 79], "C": [90, 119], "D": [90, 109]}
+    assert [str(b) for b in sut.breadth_first_branches(t)] == ["A", "B", "E", "C", "D"]
+    with pytest.raises(ValueError):
+        ptree.Tree.from_newick("((C,D)B,E;")
