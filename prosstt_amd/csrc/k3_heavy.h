@@ -185,18 +185,15 @@ __global__ __launch_bounds__(kBlock) void sample_counts_heavy_kernel(
 
     // ---- scan the flags in tickets of 512 bytes (one 8-byte load per lane) ----------------------
     // The number of flagged genes of a cell grows steeply with its library-size factor, so the
-    // work per ticket is very uneven.  The first 15/16 of the tickets are dealt round-robin
-    // (consecutive tickets of a cell land on different waves); the last sixteenth is handed out
-    // dynamically to level the tail.  One atomic head saturates near 90 tickets/us on this
-    // chip, so there are eight heads (tickets t with t % 8 == s belong to head s) and a wave
-    // starts at the head of its block's slot (blocks b and b+8 share an XCD) and moves on
-    // when a head runs dry.
+    // work per ticket is very uneven and any static split leaves a long tail (measured: the
+    // slowest wave ran 2x the mean).  Tickets are therefore handed out dynamically, in chunks
+    // of kChunk, through kHeads atomic counters (one counter saturates near 90 grabs/us on this
+    // chip): chunk q belongs to head q % kHeads; a wave starts at its own head and moves to the
+    // next when one runs dry.
     const int32_t bytes_per_cell = tiles_g * 64;          // a multiple of 8
     const int32_t batches_per_cell = (bytes_per_cell + 511) / 512;
     const int64_t tickets = N * batches_per_cell;
-    const int64_t static_tickets = tickets - tickets / 16;
     const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + wv;
-    const int64_t n_waves = (int64_t)gridDim.x * (kBlock / 64);
 
     // a ticket's flag bytes and row index are requested one ticket ahead of their use
     struct Ticket { int64_t n; int32_t byte0, row; unsigned long long bits; };
@@ -230,25 +227,25 @@ __global__ __launch_bounds__(kBlock) void sample_counts_heavy_kernel(
         }
     };
 
-    {
-        Ticket cur = fetch(wave < static_tickets ? wave : tickets);
-        for (int64_t tk = wave; tk < static_tickets; tk += n_waves) {
-            const Ticket nxt = fetch(tk + n_waves < static_tickets ? tk + n_waves : tickets);
-            expand(cur);
-            cur = nxt;
-        }
-    }
-    const int64_t dyn = tickets - static_tickets;
-    for (int turn = 0; turn < 8; ++turn) {
-        const int head = (int)((blockIdx.x + turn) & 7);
-        const int64_t mine = (dyn - head + 7) / 8;          // tickets static_tickets + head + 8*i, i < mine
+    constexpr int kHeads = 32, kChunk = 4;
+    const int64_t chunks = (tickets + kChunk - 1) / kChunk;
+    for (int turn = 0; turn < kHeads; ++turn) {
+        const int head = (int)((wave + turn) % kHeads);
+        const int64_t mine = (chunks - head + kHeads - 1) / kHeads;     // chunks head + kHeads*i, i < mine
         for (;;) {
             unsigned long long got = 0ull;
             if (lane == 0) got = atomicAdd(next_ticket + head * 16, 1ull);   // heads 128 B apart
             const int64_t i = (int64_t)__builtin_amdgcn_readfirstlane((uint32_t)got) |
                               ((int64_t)__builtin_amdgcn_readfirstlane((uint32_t)(got >> 32)) << 32);
             if (i >= mine) break;
-            expand(fetch(static_tickets + head + 8 * i));
+            const int64_t first = (head + kHeads * i) * kChunk;
+            Ticket cur = fetch(first);
+#pragma unroll 1
+            for (int c = 0; c < kChunk; ++c) {
+                const Ticket nxt = fetch(c + 1 < kChunk ? first + c + 1 : tickets);
+                expand(cur);
+                cur = nxt;
+            }
         }
     }
     while (hg_top > 0) gamma_pass();

@@ -13,8 +13,12 @@
 //                       coalesced 1 KiB store); survivors are pushed on stack S1;
 //   stage 2 (64 of S1)  exact P(X = 0); survivors (k >= 1) are pushed on S2 with the pmf
 //                       state at k = 1;
-//   stage 3 (lanes pull from S2)  one pmf step per lane per pass; a lane that finishes stores
-//                       its count (a 4-B store over the zero) and pulls the next entry;
+//   stage 3 (lanes pull from S2)  two pmf steps per lane per pass; a lane that finishes writes
+//                       its count into the LDS row ring and pulls the next entry;
+//   output              the last kRing rows of the strip live in LDS, 16 bits per count; a row
+//                       is stored (one coalesced 1 KiB store per wave) kRing cells after stage 1
+//                       started it.  The few counts that arrive later than that are written
+//                       directly (4-B store, after the row's own store);
 //   samples of the gamma-Poisson path are only FLAGGED here (4 bits per lane and pass);
 //   sample_counts_heavy_kernel (k3_heavy.h) draws them afterwards.
 // Results are pure functions of (sample parameters, seed, global cell id, gene), so the
@@ -33,7 +37,8 @@ constexpr int kTileG = 256;        // genes per wave pass: 64 lanes x 4
 constexpr int kStripCells = 128;   // most cells per wave: long strips amortise the drain of stage 3
 constexpr int kS1Cap = 320;        // < 64 left over + 256 pushed by one pass
 constexpr int kS2Cap = 96;         // < 32 left over + 64 pushed by one stage-2 pass
-constexpr int kS2Run = 32;         // stage 3 runs while S2 holds at least this many entries
+constexpr int kS2Run = 32;
+constexpr int kRing = 4;           // rows of the strip kept in LDS (16 bits per count) before they are stored; a power of 2         // stage 3 runs while S2 holds at least this many entries
 
 struct S1Entry { float m, theta; uint32_t w, pos; };   // theta = a*m + b - 1, not yet clamped
 struct S2Entry { float ps, num, q; uint32_t rem; };   // pmf (x 2^32) and numerator at k = 1
@@ -42,6 +47,7 @@ struct WaveLds {
     S1Entry s1[kS1Cap];
     S2Entry s2[kS2Cap];
     uint32_t s2pos[kS2Cap];
+    uint16_t ring[kRing * 256];    // [row slot][gene-in-tile]: a walk ends below the 1/k table's 1023 entries
 };
 
 // rank of this lane among the lanes whose bit is set in `mask`
@@ -96,10 +102,40 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
     int k = 0;
     float inv1 = 0.0f, inv2 = 0.0f;                  // 1/(k+1), 1/(k+2): read one pass ahead
 
-    // S1/S2 carry the element offset of a sample from the strip's first output element
-    // (cl*ld + gene-in-tile < 2^32, checked by the host); SH carries (cl << 8 | gene-in-tile).
+    // S1/S2 entries carry pos = (cell-in-strip << 8) | gene-in-tile
     int32_t* const strip_out = out + n0 * ld + gbase;
-    const uint32_t ld32 = (uint32_t)ld;
+    const uint32_t ld32 = (uint32_t)ld;              // strip rows * ld < 2^32, checked by the host
+    // pos of the last sample whose row has already left the ring (wave-uniform; -1: none)
+    int32_t flushed_pos = -1;
+    for (int i = lane; i < kRing * 128; i += 64) reinterpret_cast<uint32_t*>(L.ring)[i] = 0u;
+
+    // a finished count: into the row ring while its row is still there, else straight to memory
+    auto deliver = [&](uint32_t p, int32_t res) {
+        if ((int32_t)p > flushed_pos) {
+            L.ring[p & (kRing * 256 - 1)] = (uint16_t)res;       // slot = cell % kRing, then gene-in-tile
+        } else {
+            strip_out[(p >> 8) * ld32 + (p & 255u)] = res;
+        }
+    };
+    // store row `cl` of the strip from ring slot cl % kRing and clear the slot
+    auto flush_row = [&](int cl) {
+        uint2* slot = reinterpret_cast<uint2*>(L.ring + (cl & (kRing - 1)) * 256) + lane;
+        const uint2 packed = *slot;
+        *slot = make_uint2(0u, 0u);
+        const int32_t v[4] = {(int32_t)(packed.x & 0xffffu), (int32_t)(packed.x >> 16),
+                              (int32_t)(packed.y & 0xffffu), (int32_t)(packed.y >> 16)};
+        int32_t* dst = strip_out + (int64_t)cl * ld + lane * 4;
+        if (g0 < G) {
+            if (VEC) {
+                *reinterpret_cast<int4*>(dst) = make_int4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (g0 + j < G) dst[j] = v[j];
+            }
+        }
+        flushed_pos = (cl << 8) | 255;
+    };
 
     // ---- stage 3: one pmf step for every busy lane; idle lanes pull from S2 -------------------
     auto stage3_pass = [&]() {
@@ -133,11 +169,7 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
         const bool done = active && (end_a || end_b);
         if (done) {
             const int32_t res = end_a ? (hit_a ? k : 0) : (hit_b ? k + 1 : 0);
-#if K3_ABLATE == 5      // no scattered store of the walk's result
-            if (res == 0x7fffffff) strip_out[pos] = res;
-#else
-            if (res != 0) strip_out[pos] = res;
-#endif
+            if (res != 0) deliver(pos, res);
             active = false;
         }
         rem = rem_b - pfb;
@@ -239,16 +271,7 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
         // every lane runs the whole pass (lanes beyond G just never qualify): the stack tops
         // must stay wave-uniform, so no ballot may sit under a divergent branch
         const float M[4] = {cur.M[0], cur.M[1], cur.M[2], cur.M[3]};
-        if (g0 < G) {
-            int32_t* dst = strip_out + (int64_t)cl * ld + lane * 4;
-            if (VEC) {
-                *reinterpret_cast<int4*>(dst) = make_int4(0, 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (g0 + j < G) dst[j] = 0;
-            }
-        }
+        if (cl >= kRing) flush_row(cl - kRing);
 #if K3_ABLATE == 3     // no Philox: a 2-instruction hash stands in
         prnb::Words W;
         W.w[0] = ((uint32_t)cell * 2654435761u) ^ ((uint32_t)g0 * 40503u); W.w[1] = W.w[0] * 3u + k0;
@@ -276,7 +299,7 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
             const unsigned long long m1 = __builtin_amdgcn_ballot_w64(to_s1);
             if (to_s1) {
                 S1Entry e;
-                e.m = m; e.theta = theta; e.w = W.w[j]; e.pos = (uint32_t)cl * ld32 + (uint32_t)(lane * 4 + j);
+                e.m = m; e.theta = theta; e.w = W.w[j]; e.pos = ((uint32_t)cl << 8) | (uint32_t)(lane * 4 + j);
                 L.s1[s1_top + lane_rank(m1)] = e;
             }
             s1_top += __popcll(m1);
@@ -304,6 +327,7 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
         while (s2_top >= kS2Run) stage3_pass();
     }
     while (s2_top > 0 || __builtin_amdgcn_ballot_w64(active) != 0ull) stage3_pass();
+    for (int cl = (cells > kRing ? cells - kRing : 0); cl < cells; ++cl) flush_row(cl);
 }
 
 }  // namespace k3

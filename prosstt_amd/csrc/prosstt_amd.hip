@@ -73,7 +73,7 @@ static int next_event_pair(prosstt_amd_ctx* c, hipEvent_t* a, hipEvent_t* b)
     c->events_used += 2;
     return 0;
 }
-constexpr int kScratchWords = 256;     // [0] domain flag, [1..] lineage results, [128..255] ticket heads
+constexpr int kScratchWords = 128 + 32 * 16;   // [0] domain flag, [1..] lineage results, [128..] 32 ticket heads, 128 B apart
 
 static int ws_reserve(prosstt_amd_ctx* c, size_t bytes)
 {
@@ -640,7 +640,7 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
         if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, c->stream));   // the dominant kernel is timed alone
         int64_t hblocks = (N + 3) / 4;
         if (hblocks > 256 * 6) hblocks = 256 * 6;      // one resident round; cells are handed out dynamically
-        HIP_TRY(hipMemsetAsync(c->scratch + 128, 0, 128 * 8, c->stream));
+        HIP_TRY(hipMemsetAsync(c->scratch + 128, 0, 32 * 16 * 8, c->stream));
 #if K3_ABLATE != 4
         k3::sample_counts_heavy_kernel<<<dim3((unsigned)hblocks), block, 0, c->stream>>>(
             heavy_flags, (int32_t)tiles_g, A.means, G, A.row_of_cell, A.scal, A.ga, A.gbm1, N, k0, k1, cell_offset,
