@@ -13,6 +13,7 @@ import numpy as np
 from numpy import random
 
 from . import device as _device
+from .device import to_host_int64 as _to_host_int64
 
 
 def generate_negbin_params(tree, mean_alpha=0.2, mean_beta=2, a_scale=1.5, b_scale=1.5):
@@ -55,4 +56,4 @@ def sample_counts(mu, alpha, beta, *, seed=None, out="numpy", strict=True):
                                seed=seed, check_domain=strict)
     if out == "torch":
         return counts
-    return counts.cpu().numpy().astype(np.int64)
+    return _to_host_int64(counts)

@@ -163,6 +163,13 @@ class Context:
         return out
 
 
+def to_host_int64(counts):
+    """int32 device counts -> the reference's int64 ndarray.  Widening on the device and copying
+    8 B per count is several times faster than a host-side ``astype`` of a multi-GB matrix."""
+    torch = _torch()
+    return counts.to(torch.int64).cpu().numpy()
+
+
 _contexts = {}
 
 

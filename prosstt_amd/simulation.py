@@ -22,6 +22,7 @@ import pandas as pd
 from . import count_model as cm
 from . import device as _device
 from . import sim_utils as sut
+from .device import to_host_int64 as _to_host_int64
 
 
 # ----------------------------------------------------------------------------------
@@ -352,7 +353,7 @@ def draw_counts(tree, pseudotime, branches, scalings, alpha, beta, *, seed=None,
         return counts
     if out != "numpy":
         raise ValueError("out must be 'numpy' or 'torch'")
-    return counts.cpu().numpy().astype(np.int64)
+    return _to_host_int64(counts)
 
 
 def add_non_diff_genes(inform_expr_matrix, genes, gene_params, cell_scalings, *, seed=None):
