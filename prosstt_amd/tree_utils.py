@@ -26,42 +26,49 @@ def parse_newick(newick_tree, def_time):
     return topology, time, branches, branch_points, root
 
 
+def _labels(prefix, count):
+    return ["%s_%d" % (prefix, i) for i in range(count)]
+
+
+def _write_table(path, columns, index):
+    """Tab-separated table with a header row and an index column (pandas' to_csv layout,
+    which is what the reference's readers expect)."""
+    pd.DataFrame(columns, index=index, columns=list(columns)).to_csv(path, sep="\t")
+
+
 def save_cell_params(job_id, save_dir, labs, brns, scalings):
-    """<save_dir>/<job_id>_cellparams.txt (tree_utils.py:59-83)."""
-    names = ["cell_" + str(i) for i in range(len(labs))]
-    frame = pd.DataFrame({"pseudotime": labs, "branches": brns, "scalings": scalings},
-                         index=names, columns=["pseudotime", "branches", "scalings"])
-    frame.to_csv(save_dir + "/" + job_id + "_cellparams.txt", sep="\t")
+    """<save_dir>/<job_id>_cellparams.txt: pseudotime, branch and library size of every cell
+    (tree_utils.py:59-83)."""
+    _write_table("%s/%s_cellparams.txt" % (save_dir, job_id),
+                 {"pseudotime": labs, "branches": brns, "scalings": scalings}, _labels("cell", len(labs)))
 
 
 def save_gene_params(job_id, save_dir, gene_scale, alpha, beta):
-    """<save_dir>/<job_id>_geneparams.txt (tree_utils.py:86-110)."""
-    names = ["gene_" + str(i) for i in range(len(alpha))]
-    frame = pd.DataFrame({"alpha": alpha, "beta": beta, "genescale": gene_scale},
-                         index=names, columns=["alpha", "beta", "genescale"])
-    frame.to_csv(save_dir + "/" + job_id + "_geneparams.txt", sep="\t")
+    """<save_dir>/<job_id>_geneparams.txt: alpha, beta and base expression of every gene
+    (tree_utils.py:86-110)."""
+    _write_table("%s/%s_geneparams.txt" % (save_dir, job_id),
+                 {"alpha": alpha, "beta": beta, "genescale": gene_scale}, _labels("gene", len(alpha)))
 
 
 def save_matrices(job_id, save_dir, X, uMs, H):
-    """Count matrix, relative means per branch and coefficients as text
-    (tree_utils.py:113-145): _simulation.txt, _ums<branch>.txt, _h.txt."""
-    cells = ["cell_" + str(i) for i in range(X.shape[0])]
-    genes = ["gene_" + str(i) for i in range(X.shape[1])]
-    pd.DataFrame(X, columns=genes, index=cells).astype(int).to_csv(
-        save_dir + "/" + job_id + "_simulation.txt", sep="\t")
-    np.savetxt(fname=save_dir + "/" + job_id + "_h.txt", X=H)
+    """Count matrix (<job>_simulation.txt, integers, tab-separated with cell/gene labels),
+    coefficients (<job>_h.txt) and relative means per branch (<job>_ums<branch>.txt), the
+    last two in numpy's savetxt format (tree_utils.py:113-145)."""
+    stem = "%s/%s" % (save_dir, job_id)
+    counts = pd.DataFrame(np.asarray(X), index=_labels("cell", X.shape[0]), columns=_labels("gene", X.shape[1]))
+    counts.astype(int).to_csv(stem + "_simulation.txt", sep="\t")
+    np.savetxt(stem + "_h.txt", H)
     for branch in uMs.keys():
-        np.savetxt(fname=save_dir + "/" + job_id + "_ums" + str(branch) + ".txt", X=uMs[branch])
+        np.savetxt("%s_ums%s.txt" % (stem, branch), uMs[branch])
 
 
 def save_params(job_id, save_dir, lineage_tree, rseed):
-    """<save_dir>/<job_id>_params.txt (tree_utils.py:148-173)."""
-    with open(save_dir + "/" + job_id + "_params.txt", 'w') as out:
-        out.write("Genes: " + str(lineage_tree.G) + "\n")
-        out.write("pseudotimes: " + str(list(lineage_tree.time.values)) + "\n")
-        out.write("topology: " + str(lineage_tree.topology) + "\n")
-        out.write("#modules: " + str(lineage_tree.modules) + "\n")
-        out.write("random seed: " + str(rseed))
+    """<save_dir>/<job_id>_params.txt: genes, branch lengths, topology, #programs, seed
+    (tree_utils.py:148-173)."""
+    fields = [("Genes", lineage_tree.G), ("pseudotimes", list(lineage_tree.time.values)),
+              ("topology", lineage_tree.topology), ("#modules", lineage_tree.modules), ("random seed", rseed)]
+    with open("%s/%s_params.txt" % (save_dir, job_id), "w") as out:
+        out.write("\n".join("%s: %s" % kv for kv in fields))
 
 
 def sanitize_velocity(velocity, minimum_velocity=0.1):
