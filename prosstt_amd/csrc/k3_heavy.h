@@ -13,7 +13,8 @@
 
 namespace k3 {
 
-constexpr int kHCap = 192;     // < 64 left over + 64 new + 64 pushed back
+constexpr int kHeavyBlock = 1024;   // 16 waves share one LDS ticket counter
+constexpr int kHCap = 128;     // < 64 left over + 64 pushed (new entries, or re-pushed ones after 64 were popped)
 
 struct HGEntry { int32_t n, g, attempt, row; };   // row = row_of_cell[n], looked up once per ticket
 struct HPEntry { int32_t n, g; float lam; int32_t attempt; };
@@ -25,18 +26,19 @@ struct HeavyLds {
 
 // flags: [N][tiles_g][64] bytes written by the streaming kernel; bit j (< 4) of byte
 // (n, t, l) flags gene t*256 + 4*l + j of cell n.
-__global__ __launch_bounds__(kBlock) void sample_counts_heavy_kernel(
+__global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
     const uint8_t* __restrict__ flags, int32_t tiles_g, const float* __restrict__ means,
     int32_t G, const int32_t* __restrict__ row_of_cell, const float* __restrict__ scal,
     const float* __restrict__ ga, const float* __restrict__ gbm1, int64_t N, uint32_t k0, uint32_t k1,
-    uint64_t cell_offset, const int64_t* __restrict__ cell_index, int32_t* __restrict__ out, int64_t ld,
-    unsigned long long* __restrict__ next_ticket)
+    uint64_t cell_offset, const int64_t* __restrict__ cell_index, int32_t* __restrict__ out, int64_t ld)
 {
     __shared__ float inv_k[prnb::kKTab];
-    __shared__ HeavyLds lds_all[kBlock / 64];
+    __shared__ HeavyLds lds_all[kHeavyBlock / 64];
+    __shared__ unsigned int next_local;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     HeavyLds& L = lds_all[wv];
-    for (int k = tid; k < prnb::kKTab; k += kBlock) inv_k[k] = (k && k < prnb::kKTab - 1) ? 1.0f / (float)k : 0.0f;
+    for (int k = tid; k < prnb::kKTab; k += kHeavyBlock) inv_k[k] = (k && k < prnb::kKTab - 1) ? 1.0f / (float)k : 0.0f;
+    if (tid == 0) next_local = 0u;
     __syncthreads();
 
     int hg_top = 0, hp_top = 0;      // wave-uniform
@@ -185,17 +187,14 @@ __global__ __launch_bounds__(kBlock) void sample_counts_heavy_kernel(
 
     // ---- scan the flags in tickets of 512 bytes (one 8-byte load per lane) ----------------------
     // The number of flagged genes of a cell grows steeply with its library-size factor, so the
-    // work per ticket is very uneven and any static split leaves a long tail (measured: the
-    // slowest wave ran 2x the mean).  Tickets are therefore handed out dynamically, in chunks
-    // of kChunk, through kHeads atomic counters (one counter saturates near 90 grabs/us on this
-    // chip): chunk q belongs to head q % kHeads; a wave starts at its own head and moves to the
-    // next when one runs dry.
+    // work per ticket is very uneven: a static split over waves left the slowest wave at 2x the
+    // mean, and global atomic ticket heads cost more than they saved (~8 grabs/us per address
+    // under 8192 contending waves).  So: blocks get a strided, static share of the tickets
+    // (~1000 each, which averages the unevenness out to a few per cent) and the 16 waves of a
+    // block hand them out among themselves through a counter in LDS.
     const int32_t bytes_per_cell = tiles_g * 64;          // a multiple of 8
     const int32_t batches_per_cell = (bytes_per_cell + 511) / 512;
     const int64_t tickets = N * batches_per_cell;
-    const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + wv;
-
-    // a ticket's flag bytes and row index are requested one ticket ahead of their use
     struct Ticket { int64_t n; int32_t byte0, row; unsigned long long bits; };
     auto fetch = [&](int64_t tk) -> Ticket {
         Ticket t;
@@ -227,26 +226,20 @@ __global__ __launch_bounds__(kBlock) void sample_counts_heavy_kernel(
         }
     };
 
-    constexpr int kHeads = 32, kChunk = 4;
-    const int64_t chunks = (tickets + kChunk - 1) / kChunk;
-    for (int turn = 0; turn < kHeads; ++turn) {
-        const int head = (int)((wave + turn) % kHeads);
-        const int64_t mine = (chunks - head + kHeads - 1) / kHeads;     // chunks head + kHeads*i, i < mine
-        for (;;) {
-            unsigned long long got = 0ull;
-            if (lane == 0) got = atomicAdd(next_ticket + head * 16, 1ull);   // heads 128 B apart
-            const int64_t i = (int64_t)__builtin_amdgcn_readfirstlane((uint32_t)got) |
-                              ((int64_t)__builtin_amdgcn_readfirstlane((uint32_t)(got >> 32)) << 32);
-            if (i >= mine) break;
-            const int64_t first = (head + kHeads * i) * kChunk;
-            Ticket cur = fetch(first);
-#pragma unroll 1
-            for (int c = 0; c < kChunk; ++c) {
-                const Ticket nxt = fetch(c + 1 < kChunk ? first + c + 1 : tickets);
-                expand(cur);
-                cur = nxt;
-            }
-        }
+    constexpr int kChunk = 4;
+    // tickets of this block: blockIdx.x + gridDim.x * i, i < mine
+    const int64_t mine = (tickets - (int64_t)blockIdx.x + (int64_t)gridDim.x - 1) / (int64_t)gridDim.x;
+    for (;;) {
+        unsigned int got = 0u;
+        if (lane == 0) got = atomicAdd(&next_local, (unsigned int)kChunk);
+        const int64_t i0 = (int64_t)__builtin_amdgcn_readfirstlane(got);
+        if (i0 >= mine) break;
+        Ticket t[kChunk];                           // all loads of the chunk are in flight together
+#pragma unroll
+        for (int c = 0; c < kChunk; ++c)
+            t[c] = fetch(i0 + c < mine ? (int64_t)blockIdx.x + (int64_t)gridDim.x * (i0 + c) : tickets);
+#pragma unroll
+        for (int c = 0; c < kChunk; ++c) expand(t[c]);
     }
     while (hg_top > 0) gamma_pass();
     while (hp_top > 0) poisson_pass();

@@ -73,7 +73,7 @@ static int next_event_pair(prosstt_amd_ctx* c, hipEvent_t* a, hipEvent_t* b)
     c->events_used += 2;
     return 0;
 }
-constexpr int kScratchWords = 128 + 32 * 16;   // [0] domain flag, [1..] lineage results, [128..] 32 ticket heads, 128 B apart
+constexpr int kScratchWords = 128 + 32 * 16;   // [0] domain flag, [1..] lineage results, [128..] ticket heads, 128 B apart
 
 static int ws_reserve(prosstt_amd_ctx* c, size_t bytes)
 {
@@ -638,13 +638,15 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
                 ld_out, (int32_t)strips, (int32_t)strip_cells, heavy_flags, (int32_t)tiles_g);
         HIP_TRY(hipGetLastError());
         if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, c->stream));   // the dominant kernel is timed alone
-        int64_t hblocks = (N + 3) / 4;
-        if (hblocks > 256 * 6) hblocks = 256 * 6;      // one resident round; cells are handed out dynamically
-        HIP_TRY(hipMemsetAsync(c->scratch + 128, 0, 32 * 16 * 8, c->stream));
+        // 16-wave blocks, two per CU; each gets a strided share of the flag tickets
+        const int64_t tickets = N * ((tiles_g * 64 + 511) / 512);
+        int64_t hblocks = (tickets + 255) / 256;
+        if (hblocks > 256 * 2) hblocks = 256 * 2;
+        if (hblocks < 1) hblocks = 1;
 #if K3_ABLATE != 4
-        k3::sample_counts_heavy_kernel<<<dim3((unsigned)hblocks), block, 0, c->stream>>>(
+        k3::sample_counts_heavy_kernel<<<dim3((unsigned)hblocks), dim3(k3::kHeavyBlock), 0, c->stream>>>(
             heavy_flags, (int32_t)tiles_g, A.means, G, A.row_of_cell, A.scal, A.ga, A.gbm1, N, k0, k1, cell_offset,
-            cell_index, d_out, ld_out, (unsigned long long*)(c->scratch + 128));
+            cell_index, d_out, ld_out);
 #endif
         ev_stop = nullptr;
         if (flags & PROSSTT_AMD_CHECK_DOMAIN) {

@@ -7,6 +7,7 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
 ctx = device.get_context()
 w = workloads.build(cfg)
 pt, br, sc, rows = w.plan()
+sc = sc * float(os.environ.get('KBENCH_SCALE', '1'))
 G = w.tree.G
 dm = w.tree.device_means(); dr = ctx.tensor(rows, torch.int32); ds = ctx.tensor(sc, torch.float64)
 da = ctx.tensor(w.alpha, torch.float64); db = ctx.tensor(w.beta, torch.float64)
