@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4", "C5"])
     ap.add_argument("--cells-per-gpu", type=int, default=None)
-    ap.add_argument("--cpu-cells", type=int, default=1500, help="cells timed by the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-cells", type=int, default=10000, help="cells timed by the CPU baseline (0 = skip)")
     ap.add_argument("--gather", action="store_true", help="also time the optional row gather to rank 0")
     args = ap.parse_args()
 
