@@ -114,6 +114,16 @@ int prosstt_amd_lineage_attempt(prosstt_amd_ctx* ctx, const double* programs, in
                                 double* out_max, int64_t* out_anticorr);
 
 /*
+ * Device-mode expression programs (K1): the K random walks of one branch attempt,
+ * simulation.sim_expr_branch / diffusion (simulation.py:21-124), drawn on the device from
+ * Philox streams instead of numpy's global stream (walk definition PRLW-1).
+ * One lane per program, T sequential steps in binary64.  programs_out: HOST [T][K].
+ * stream_id distinguishes walks drawn with the same seed (branch and attempt number).
+ */
+int prosstt_amd_lineage_walk(prosstt_amd_ctx* ctx, uint64_t seed, uint64_t stream_id, int32_t T,
+                             int32_t K, double* programs_out);
+
+/*
  * Materialise an accepted branch: rel_out[t][g] = sum_k programs[t][k]*H[k][g]
  * (binary64; simulation.py:269) and fold max_t rel into gene_max[g] (the log of
  * sim_utils.max_relat_exp, sim_utils.py:406-426).

@@ -391,6 +391,39 @@ PRNB_EXPORT PRNB_CLONES void prnb_nb_params(const float* means, int64_t rows, in
     }
 }
 
+/*
+ * Device-mode expression programs ("PRLW-1"): the walk of simulation.diffusion
+ * (/root/reference/prosstt/simulation.py:89-124) with counter-based variates instead of numpy's
+ * stream.  Program k of walk stream `sid` draws from Philox4x32-10 with key
+ * (seed_lo ^ 0x57414C4B, seed_hi) and counter (k, j, sid_lo, sid_hi):
+ *   call j = 0:  w0 -> start = log(1.5*U),  (w1, w2) -> vel0 = 0.2*N,  w3 -> eta = U
+ *   call j >= 1: (w0, w1) -> N for step 2(j-1),  (w2, w3) -> N for step 2(j-1)+1,  eps = (2/T)*N
+ * U = unif(w), N = sqrt(-2 log U) cos(2 pi w') in the deterministic binary32 math above; the
+ * recurrence  walk[t+1] = walk[t] + vel[t],  vel[t+1] = eta*vel[t] + eps[t]  runs in binary64.
+ * out[t*K + k] = walk_k[t]  (the (T, K) layout sim_expr_branch returns).
+ */
+PRNB_EXPORT PRNB_CLONES void prnb_lineage_walk(uint64_t seed, uint64_t sid, int32_t T, int32_t K, double* out)
+{
+    const uint32_t k0 = (uint32_t)seed ^ 0x57414C4Bu, k1 = (uint32_t)(seed >> 32);
+    for (int32_t k = 0; k < K; ++k) {
+        uint32_t w[4];
+        philox4x32_10((uint32_t)k, 0u, (uint32_t)sid, (uint32_t)(sid >> 32), k0, k1, w);
+        double walk = (double)det_log(1.5f * unif(w[0]));
+        double vel = 0.2 * (double)(sqrtf(-2.0f * det_log(unif(w[1]))) * det_cos2pi(w[2]));
+        const double eta = (double)unif(w[3]);
+        const double s_eps = 2.0 / (double)T;
+        out[k] = walk;
+        for (int32_t t = 0; t + 1 < T; ++t) {
+            if ((t & 1) == 0) philox4x32_10((uint32_t)k, 1u + (uint32_t)(t >> 1), (uint32_t)sid, (uint32_t)(sid >> 32), k0, k1, w);
+            const uint32_t wa = (t & 1) ? w[2] : w[0], wb = (t & 1) ? w[3] : w[1];
+            const double eps = s_eps * (double)(sqrtf(-2.0f * det_log(unif(wa))) * det_cos2pi(wb));
+            walk = walk + vel;
+            vel = eta * vel + eps;
+            out[(int64_t)(t + 1) * K + k] = walk;
+        }
+    }
+}
+
 /* n draws from one parameter set (law tests): cell = first_cell + i, gene fixed. */
 PRNB_EXPORT PRNB_CLONES void prnb_sample_iid(float m, double a, double b, uint64_t seed,
                                              uint64_t first_cell, uint32_t gene, int64_t n,

@@ -37,6 +37,8 @@ def lib():
                                      ctypes.c_int64, _f32p, _f32p, _f32p, _i32p]
         L.prnb_sample_iid.argtypes = [ctypes.c_float, ctypes.c_double, ctypes.c_double, ctypes.c_uint64,
                                       ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int64, _i32p]
+        L.prnb_lineage_walk.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, _f64p]
+        L.prnb_lineage_walk.restype = None
         for f in (L.prnb_philox, L.prnb_math, L.prnb_sample_counts, L.prnb_nb_params, L.prnb_sample_iid):
             f.restype = None
         _LIB = L
@@ -92,4 +94,10 @@ def nb_params(means, row_of_cell, scaling, alpha, beta):
 def sample_iid(m, a, b, n, seed=0, first_cell=0, gene=0):
     out = np.empty(n, np.int32)
     lib().prnb_sample_iid(m, a, b, seed, first_cell, gene, n, out)
+    return out
+
+
+def lineage_walk(seed, sid, T, K):
+    out = np.empty((T, K), np.float64)
+    lib().prnb_lineage_walk(seed, sid, T, K, out)
     return out

@@ -338,6 +338,28 @@ __global__ __launch_bounds__(256) void lineage_attempt_kernel(
     }
 }
 
+// K1: one lane per expression program, T sequential steps (walk definition PRLW-1)
+__global__ void lineage_walk_kernel(uint32_t k0, uint32_t k1, uint32_t sid_lo, uint32_t sid_hi, int32_t T,
+                                    int32_t K, double* __restrict__ out)
+{
+    const int32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    prnb::Words w = prnb::philox4x32_10((uint32_t)k, 0u, sid_lo, sid_hi, k0, k1);
+    double walk = (double)prnb::det_log(1.5f * prnb::unif(w.w[0]));
+    double vel = 0.2 * (double)(prnb::det_sqrt(-2.0f * prnb::det_log(prnb::unif(w.w[1]))) * prnb::det_cos2pi(w.w[2]));
+    const double eta = (double)prnb::unif(w.w[3]);
+    const double s_eps = 2.0 / (double)T;
+    out[k] = walk;
+    for (int32_t t = 0; t + 1 < T; ++t) {
+        if ((t & 1) == 0) w = prnb::philox4x32_10((uint32_t)k, 1u + (uint32_t)(t >> 1), sid_lo, sid_hi, k0, k1);
+        const uint32_t wa = (t & 1) ? w.w[2] : w.w[0], wb = (t & 1) ? w.w[3] : w.w[1];
+        const double eps = s_eps * (double)(prnb::det_sqrt(-2.0f * prnb::det_log(prnb::unif(wa))) * prnb::det_cos2pi(wb));
+        walk = walk + vel;
+        vel = eta * vel + eps;
+        out[(int64_t)(t + 1) * K + k] = walk;
+    }
+}
+
 __global__ __launch_bounds__(256) void lineage_commit_kernel(const double* __restrict__ progs,
                                                              int32_t T, int32_t K,
                                                              const double* __restrict__ H, int64_t G,
@@ -757,6 +779,24 @@ PA_EXPORT int prosstt_amd_lineage_attempt(prosstt_amd_ctx* c, const double* prog
     HIP_TRY(hipStreamSynchronize(c->stream));   // also keeps `host` alive until the H2D copies are done
     *out_max = from_ordered_bits((unsigned long long)c->h_scratch[1]);
     for (int j = 0; j < n_sib; ++j) out_anticorr[j] = c->h_scratch[2 + j];
+    return 0;
+}
+
+PA_EXPORT int prosstt_amd_lineage_walk(prosstt_amd_ctx* c, uint64_t seed, uint64_t stream_id, int32_t T,
+                                       int32_t K, double* programs_out)
+{
+    if (!c || !programs_out) return fail(PROSSTT_AMD_EINVAL, "NULL argument");
+    if (T <= 0 || K <= 0) return fail(PROSSTT_AMD_EINVAL, "bad size");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t bytes = (size_t)T * K * 8;
+    int rc = ws_reserve(c, bytes);
+    if (rc) return rc;
+    lineage_walk_kernel<<<dim3((unsigned)((K + 63) / 64)), dim3(64), 0, c->stream>>>(
+        (uint32_t)seed ^ 0x57414C4Bu, (uint32_t)(seed >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32), T, K,
+        (double*)c->ws);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(programs_out, c->ws, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
 

@@ -141,6 +141,14 @@ class Context:
             ctypes.cast(ctypes.byref(mx), ctypes.c_void_p), ctypes.cast(counts, ctypes.c_void_p)))
         return mx.value, [int(counts[j]) for j in range(n)]
 
+    def lineage_walk(self, seed, stream_id, T, K):
+        """(T, K) float64 expression programs drawn on the device (K1, PRLW-1)."""
+        out = np.empty((T, K), np.float64)
+        _native.check(self._lib.prosstt_amd_lineage_walk(
+            self._h, ctypes.c_uint64(seed & (2 ** 64 - 1)), ctypes.c_uint64(stream_id), T, K,
+            out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
     def lineage_commit(self, programs, H, rel_out=None, gene_max=None):
         programs = np.ascontiguousarray(programs, np.float64)
         T, K = programs.shape

@@ -149,7 +149,7 @@ def _device_gene_max(tree, relative_means):
 
 
 def simulate_lineage(tree, rel_exp_cutoff=8, intra_branch_tol=0.5, inter_branch_tol=0,
-                     *, max_attempts=None, stats=None, **kwargs):
+                     *, max_attempts=None, stats=None, rng="numpy", seed=None, **kwargs):
     """Relative mean expression of every gene at every point of the tree
     (simulation.py:215-286).
 
@@ -162,7 +162,10 @@ def simulate_lineage(tree, rel_exp_cutoff=8, intra_branch_tol=0.5, inter_branch_
 
     New keyword-only options: ``max_attempts`` bounds the redraws per branch
     (default unlimited, like the reference); ``stats`` (a list) receives one
-    ``(branch, max, [anticorrelated counts])`` record per attempt.
+    ``(branch, max, [anticorrelated counts])`` record per attempt; ``rng="device"``
+    draws the random walks on the device (``lineage_walk`` kernel, one lane per program,
+    Philox streams keyed by ``seed``, branch and attempt) instead of numpy's global stream --
+    same walk law, different numbers (``seed`` defaults to two draws of numpy's stream).
     """
     import torch
     if not len(tree.time) == tree.num_branches:
@@ -174,12 +177,23 @@ def simulate_lineage(tree, rel_exp_cutoff=8, intra_branch_tol=0.5, inter_branch_
     offsets, rows = tree.row_offsets()
     rel = torch.empty((rows, tree.G), dtype=torch.float64, device=ctx.torch_device)
     gene_max = torch.full((tree.G,), -np.inf, dtype=torch.float64, device=ctx.torch_device)
+    if rng not in ("numpy", "device"):
+        raise ValueError("rng must be 'numpy' or 'device'")
+    if rng == "device" and seed is None:
+        lo, hi = random.randint(0, 2 ** 32, size=2, dtype=np.uint64)
+        seed = int(lo) | (int(hi) << 32)
     programs = {}
-    for branch in sut.breadth_first_branches(tree):
+    for ordinal, branch in enumerate(sut.breadth_first_branches(tree)):
         tries = 0
         while True:
             tries += 1
-            programs[branch] = sim_expr_branch(tree.time[branch], tree.modules, cutoff=intra_branch_tol)
+            if rng == "device":
+                if tree.modules < 2:
+                    raise ValueError("at least 2 expression programs are needed")
+                programs[branch] = ctx.lineage_walk(seed, (ordinal << 32) | (tries - 1),
+                                                    int(tree.time[branch]), int(tree.modules))
+            else:
+                programs[branch] = sim_expr_branch(tree.time[branch], tree.modules, cutoff=intra_branch_tol)
             programs[branch] = sut.adjust_to_parent(programs, branch, topology)
             siblings = [b for b in sut.find_parallel(tree, programs, branch)
                         if b is not None and b != branch]

@@ -61,3 +61,30 @@ def test_commit_and_means(ctx):
     want = np.exp(rel) * base                      # tree.py:181-182 in float64
     assert means.dtype == np.float32
     np.testing.assert_allclose(means, want, rtol=1.2e-7)   # one binary32 rounding
+
+
+def test_device_mode_walk_bit_exact_and_usable(ctx):
+    """K1 against the C model (bit-exact), and simulate_lineage(rng='device') end to end."""
+    from oracle import nb_model
+    for T, K, seed, sid in ((50, 25, 7, 0), (2, 3, 8, (5 << 32) | 9), (41, 70, 2 ** 63 + 5, 1)):
+        got = ctx.lineage_walk(seed, sid, T, K)
+        np.testing.assert_array_equal(got, nb_model.lineage_walk(seed, sid, T, K))
+    from prosstt_amd import simulation as sim
+    from prosstt_amd import tree as ptree
+    np.random.seed(3)
+    t = ptree.Tree(G=300, modules=6)
+    stats = []
+    rel, prog, H = sim.simulate_lineage(t, a=0.05, rng="device", seed=11, stats=stats)
+    assert [str(b) for b in rel.index] == ["A", "B", "C"] and rel["B"].shape == (40, 300)
+    # the accepted programs are the model's walks for (branch ordinal, attempt), shifted onto the parent
+    tries = {}
+    for b, _, _ in stats:
+        tries[str(b)] = tries.get(str(b), 0) + 1
+    root = nb_model.lineage_walk(11, (0 << 32) | (tries["A"] - 1), 40, 6)
+    np.testing.assert_array_equal(prog["A"], root)
+    child = nb_model.lineage_walk(11, (1 << 32) | (tries["B"] - 1), 40, 6)
+    np.testing.assert_array_equal(prog["B"], child - (child[0] - root[-1]))
+    np.testing.assert_allclose(rel["C"], prog["C"] @ H, rtol=1e-12, atol=1e-13)
+    np.random.seed(3)                                                # same coefficients -> same accepted attempts
+    again = sim.simulate_lineage(t, a=0.05, rng="device", seed=11)
+    np.testing.assert_array_equal(again[1]["A"], prog["A"])

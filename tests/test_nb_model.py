@@ -131,3 +131,27 @@ def test_degenerate_parameters():
     assert not nm.sample_iid(3.0, 0.0, 0.5, 100).any()          # theta < 0: 0 (the wrapper raises ValueError)
     big = nm.sample_iid(3.0e5, 0.3, 2.0, 2000, seed=1)           # far beyond abs_max=5000 x scaling
     assert abs(big.mean() / 3.0e5 - 1) < 0.05 and big.min() >= 0
+
+
+def test_device_mode_walk_law():
+    """PRLW-1 (device-mode expression programs) follows simulation.diffusion's law
+    (simulation.py:104-121): start = log(1.5 U), vel0 ~ N(0, 0.2^2), eta ~ U(0,1),
+    increments eta*vel + N(0, (2/T)^2); and it is a pure function of (seed, stream, k)."""
+    T, K = 50, 4000
+    w = nm.lineage_walk(123, (3 << 32) | 7, T, K)
+    assert w.shape == (T, K) and np.isfinite(w).all()
+    start = w[0]
+    u = np.exp(start) / 1.5
+    assert stats.kstest(u, "uniform").pvalue > 1e-4
+    vel0 = w[1] - w[0]
+    assert abs(vel0.mean()) < 5 * 0.2 / np.sqrt(K) and abs(vel0.std() / 0.2 - 1) < 0.05
+    assert stats.kstest(vel0 / 0.2, "norm").pvalue > 1e-4
+    v = np.diff(w, axis=0)                                  # velocities vel[0..T-2]
+    # regress vel[t+1] on vel[t] per walk: slope = eta in (0,1), residual sd = 2/T
+    eta = (v[1:] * v[:-1]).sum(axis=0) / (v[:-1] ** 2).sum(axis=0)
+    assert 0.35 < np.median(eta) < 0.65
+    resid = v[1:] - eta * v[:-1]
+    assert abs(resid.std() / (2 / T) - 1) < 0.05
+    np.testing.assert_array_equal(w[:, :7], nm.lineage_walk(123, (3 << 32) | 7, T, 7))     # independent of K
+    assert not np.array_equal(w[:, :7], nm.lineage_walk(123, (3 << 32) | 8, T, 7))
+    assert not np.array_equal(w[:, :7], nm.lineage_walk(124, (3 << 32) | 7, T, 7))
