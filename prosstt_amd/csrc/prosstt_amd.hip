@@ -684,8 +684,9 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
     }
     HIP_TRY(hipGetLastError());
     if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, c->stream));
-    if (flags & PROSSTT_AMD_HOST_OUTPUT)
-        HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)N * ld_out * 4, hipMemcpyDeviceToHost, c->stream));
+    if (flags & PROSSTT_AMD_HOST_OUTPUT)   // G columns of every row; the caller's padding beyond G is left alone
+        HIP_TRY(hipMemcpy2DAsync(out, (size_t)ld_out * 4, d_out, (size_t)ld_out * 4, (size_t)G * 4, (size_t)N,
+                                 hipMemcpyDeviceToHost, c->stream));
     if (flags & PROSSTT_AMD_CHECK_DOMAIN) {
         HIP_TRY(hipMemcpyAsync(c->h_scratch, c->scratch, 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));

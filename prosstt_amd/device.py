@@ -61,7 +61,10 @@ class Context:
         torch = _torch()
         if isinstance(array, torch.Tensor):
             return array.to(device=self.torch_device, dtype=dtype).contiguous()
-        return torch.as_tensor(np.ascontiguousarray(array), dtype=dtype).to(self.torch_device)
+        host = np.ascontiguousarray(array)
+        if not host.flags.writeable:               # e.g. a broadcast view: torch wants an owned buffer
+            host = host.copy()
+        return torch.as_tensor(host, dtype=dtype).to(self.torch_device)
 
     def synchronize(self):
         _native.check(self._lib.prosstt_amd_ctx_synchronize(self._h))

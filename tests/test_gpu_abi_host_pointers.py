@@ -37,6 +37,7 @@ def test_sample_counts_and_params_with_host_buffers():
         assert rc == 0, L.prosstt_amd_last_error()
         want = nb_model.sample_counts(means, roc, sc, al, be, 99, cell_index=idx)
         np.testing.assert_array_equal(out[:, :G], want)
+        assert (out[:, G:] == -7).all()
         # staged output copies whole rows of ld_out elements; only the first G of each are defined
         mu = np.empty((N, G), np.float32)
         p = np.empty((N, G), np.float32)
