@@ -398,7 +398,10 @@ __global__ __launch_bounds__(256) void means_from_rel_kernel(const double* __res
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t g = i % G;
-        out[i] = (float)(exp(rel[i]) * base[g]);
+        const double v = exp(rel[i]) * base[g];
+        // a positive binary64 mean must stay positive in binary32: the reference never sees the zero
+        // (and the ValueError that goes with it) that an underflow below 1e-38 would fake
+        out[i] = (v > 0.0 && v < 1.17549435e-38) ? 1.17549435e-38f : (float)v;
     }
 }
 

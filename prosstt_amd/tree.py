@@ -165,7 +165,10 @@ class Tree(object):
             import torch
             stacked = np.concatenate([np.asarray(self._host_means[b], dtype=np.float64)
                                       for b in self.branches], axis=0)
-            self._dev_means = ctx.tensor(stacked.astype(np.float32), torch.float32)
+            as32 = stacked.astype(np.float32)
+            tiny = np.float32(1.17549435e-38)      # positive means stay positive in binary32 (see means_from_rel)
+            as32[(stacked > 0) & (as32 < tiny)] = tiny
+            self._dev_means = ctx.tensor(as32, torch.float32)
         return self._dev_means
 
     def add_genes(self, *args):

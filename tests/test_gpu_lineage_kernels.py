@@ -60,7 +60,7 @@ def test_commit_and_means(ctx):
     means = ctx.means_from_rel(rel_d, torch.as_tensor(base, device=ctx.torch_device)).cpu().numpy()
     want = np.exp(rel) * base                      # tree.py:181-182 in float64
     assert means.dtype == np.float32
-    np.testing.assert_allclose(means, want, rtol=1.2e-7)   # one binary32 rounding
+    np.testing.assert_allclose(means, want, rtol=1.2e-7, atol=1.2e-38)   # one binary32 rounding
 
 
 def test_device_mode_walk_bit_exact_and_usable(ctx):
@@ -88,3 +88,17 @@ def test_device_mode_walk_bit_exact_and_usable(ctx):
     np.random.seed(3)                                                # same coefficients -> same accepted attempts
     again = sim.simulate_lineage(t, a=0.05, rng="device", seed=11)
     np.testing.assert_array_equal(again[1]["A"], prog["A"])
+
+
+def test_means_underflow_stays_positive(ctx):
+    """exp(rel)*base far below binary32's range: the reference's float64 mean is positive, so the
+    stored mean must be too (an exact 0 would raise the reference's ValueError in strict mode)."""
+    import torch
+    rel = torch.tensor([[-200.0, -80.0, 0.0, -800.0]], dtype=torch.float64, device=ctx.torch_device)
+    base = torch.tensor([1.0, 1.0, 2.0, 1.0], dtype=torch.float64, device=ctx.torch_device)
+    m = ctx.means_from_rel(rel, base).cpu().numpy()[0]
+    assert m[0] == np.float32(1.17549435e-38) and m[1] == np.float32(np.exp(-80.0)) and m[2] == 2.0
+    assert m[3] == 0.0            # exp(-800) is 0 in binary64 as well: a true zero stays zero
+    X = ctx.sample_counts(m[None, :3].copy(), np.zeros(5, np.int32), np.ones(5), np.full(3, 0.2), np.full(3, 2.0), seed=1)
+    assert X.shape == (5, 3)      # strict mode accepts it; the tiny means just give zeros
+    assert int(X[:, :2].sum()) == 0

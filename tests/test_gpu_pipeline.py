@@ -75,7 +75,7 @@ def test_full_pipeline_vs_reference(name):
     np.testing.assert_array_equal(base, g["base"])            # same draws, same accept decisions
     t.add_genes(rel, base)
     for b in t.branches:
-        np.testing.assert_allclose(t.means[b], g["means_%s" % b], rtol=1.2e-7)
+        np.testing.assert_allclose(t.means[b], g["means_%s" % b], rtol=1.2e-7, atol=1.2e-38)
     alpha = np.exp(np.random.normal(np.log(0.2), np.log(1.5), spec["G"]))
     beta = np.exp(np.random.normal(np.log(1), np.log(1.5), spec["G"])) + 1
     np.testing.assert_array_equal(alpha, g["alpha"])
