@@ -39,6 +39,28 @@ def algorithmic_bytes(n_cells, G, rows):
     return 4 * n_cells * G + 4 * rows * G + 8 * G + 8 * n_cells
 
 
+def profiled_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS
+    command (profiles/rNN_summary.txt, written by tools/profile_bench.sh: separate --pmc runs for
+    FETCH_SIZE and WRITE_SIZE).  Units and corrections as MI355X_MICROARCH.md prescribes: both
+    counters are KiB; WRITE_SIZE is exact for 16-B/lane stores, FETCH_SIZE reads half of a wide
+    coalesced stream on gfx950 and is doubled.  bench.py cannot run the profiler on itself, so
+    this is the last profiled value, not a live one; None when no profile is committed."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.txt")))
+    if not files:
+        return None, None
+    text = open(files[-1]).read()
+    vals = {}
+    for name in ("FETCH_SIZE", "WRITE_SIZE"):
+        m = re.search(r"sample_counts_stream_kernel<true>\s+%s\s+([0-9.e+]+)" % name, text)
+        if not m:
+            return None, None
+        vals[name] = float(m.group(1)) * 1024.0
+    return vals["WRITE_SIZE"] + 2.0 * vals["FETCH_SIZE"], os.path.relpath(files[-1], ROOT)
+
+
 def cpu_baseline(work, pt, br, sc, cells):
     """Reference-equivalent CPU path: oracle/ref_numpy.draw_counts (bit-identical to the real
     reference at equal seed, tests/test_oracle_golden.py) on the first `cells` cells, 1 core."""
@@ -160,6 +182,7 @@ def main():
         kms = float(np.mean(kernel_ms))
         abytes = algorithmic_bytes(len(mine), G, rows_total)
         achieved = abytes / (kms * 1e-3)
+        traffic, traffic_src = profiled_traffic() if (args.config == "C3" and args.cells_per_gpu is None) else (None, None)
         line = {
             "metric": "simulated cells*genes per second (count sampling: sample_density -> draw_counts)",
             "value": value, "unit": "cells*genes/s", "n_gpus": world, "steps": args.steps,
@@ -172,7 +195,7 @@ def main():
                        "lineage_attempts": work.info["attempts"], "lineage_s": round(work.info["lineage_s"], 3),
                        "sum_counts_over_sum_means": round(ratio, 5)},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": None,
+                         "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k3::sample_counts_stream_kernel<true>", "kernel_ms": kms,
                          "algorithmic_bytes_per_launch": abytes,
                          "note": "VALU-bound exact sampler: see DESIGN.md section 6 and profiles/"},
