@@ -109,7 +109,8 @@ def main():
     if os.environ.get("PROSSTT_BENCH_ONE_GPU") == "1":
         local = 0
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("PROSSTT_BENCH_FORCE_DIST") == "1"   # the latter: RCCL path on 1 GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -141,7 +142,7 @@ def main():
                           check_domain=False, time_kernel=timed)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -157,7 +158,7 @@ def main():
     red_dev = ctx.torch_device if backend == "nccl" else torch.device("cpu")
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     k_max = torch.tensor([float(np.mean(kernel_ms))], dtype=torch.float64, device=red_dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         dist.all_reduce(k_max, op=dist.ReduceOp.MAX)
     elapsed = float(t_max.item())
@@ -206,7 +207,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(work, pt, br, sc, min(args.cpu_cells, n_total))
             line["speedup_vs_cpu_1core"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
