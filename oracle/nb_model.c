@@ -37,7 +37,7 @@
 #endif
 
 /* ---- sampler constants (part of the PRNB-1 definition) ------------------ */
-#define PRNB_LIGHT_M      19.0f        /* light path iff m <= 19 and theta <= 16 (P0 >= e^-19 > 2^-28) */
+#define PRNB_LIGHT_M      19.0f        /* inversion iff m <= min(19, largest m with theta <= 16): P0 >= e^-19 > 2^-28 */
 #define PRNB_LIGHT_THETA  16.0f
 #define PRNB_THETA_MIN    8.6736174e-19f /* 2^-60: below this NB == Poisson in binary32 */
 #define PRNB_THETA_MAX    1.0e18f
@@ -287,6 +287,15 @@ static inline float gamma_scaled(float r, float theta, uint32_t c0, uint32_t c1,
     return theta * g;
 }
 
+/* Largest mean of gene (a, b - 1) that is sampled by inversion: theta = a*m + b - 1 stays <= 16
+ * (up to one rounding) for every m in (0, limit].  One IEEE division per gene. */
+static inline float light_limit(float a, float bm1)
+{
+    if (!(bm1 <= PRNB_LIGHT_THETA)) return -INFINITY;      /* also NaN */
+    if (!(a > 0.0f)) return PRNB_LIGHT_M;
+    return fminf(PRNB_LIGHT_M, (PRNB_LIGHT_THETA - bm1) / a);
+}
+
 typedef struct { float m, theta, p, r; int32_t path; } prnb_detail;
 
 /* One count.  path: 0 = degenerate (returns 0), 1 = light NB inversion, 2 = gamma-Poisson. */
@@ -305,7 +314,7 @@ static inline int32_t prnb_one(float M, float s, float a, float bm1, uint32_t k0
     float q = theta * inv_u1;
     float r = m * inv_th;
     if (det) { det->p = q; det->r = r; }
-    if (m <= PRNB_LIGHT_M && theta <= PRNB_LIGHT_THETA) {
+    if (m <= light_limit(a, bm1)) {
         uint32_t w[4];
         if (det) det->path = 1;
         philox4x32_10(c0, c1, gene >> 2, 0u, k0, k1, w);

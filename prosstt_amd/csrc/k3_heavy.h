@@ -24,7 +24,7 @@ struct HeavyLds {
     HPEntry hp[kHCap];
 };
 
-// flags: [N][tiles_g][64] bytes written by the streaming kernel; bit j (< 4) of byte
+// flags: [N][tiles_g][64] bytes written by the streaming kernel; bit 3 - j (j < 4) of byte
 // (n, t, l) flags gene t*256 + 4*l + j of cell n.
 __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
     const uint8_t* __restrict__ flags, int32_t tiles_g, const float* __restrict__ means,
@@ -125,9 +125,11 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
         if (lane < cnt) {
             e = L.hg[hg_top - 1 - lane];
             const prnb::Params P = prnb::make_params(means[(int64_t)e.row * G + e.g], scal[e.n],
-                                                     ga[e.g], gbm1[e.g]);
+                                                     ga[e.g], gbm1[e.g], 0.0f);
             const float r = P.m * P.inv_th;
-            if (r >= prnb::kRMin) {             // else P(X > 0) < 2^-32: the count stays 0
+            // the flag only says "not the inversion class": m <= 0 or theta <= 0 is a count of 0,
+            // and so is r under 2^-40 (P(X > 0) < 2^-32)
+            if (P.valid && r >= prnb::kRMin) {
                 const uint64_t cell = cell_id(e.n);
                 const bool boost = r < 1.0f;
                 const float rr = boost ? r + 1.0f : r;
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
             if (has) {
                 const int32_t byte = t.byte0 + (b >> 3);   // = tile*64 + lane-in-tile
                 HGEntry e;
-                e.n = (int32_t)t.n; e.g = byte * 4 + (b & 7); e.attempt = 0; e.row = t.row;
+                e.n = (int32_t)t.n; e.g = byte * 4 + 3 - (b & 7); e.attempt = 0; e.row = t.row;
                 L.hg[hg_top + lane_rank(m)] = e;
             }
             hg_top += __popcll(m);

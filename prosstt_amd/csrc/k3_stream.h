@@ -37,11 +37,17 @@ constexpr int kTileG = 256;        // genes per wave pass: 64 lanes x 4
 constexpr int kStripCells = 128;   // most cells per wave: long strips amortise the drain of stage 3
 constexpr int kS1Cap = 320;        // < 64 left over + 256 pushed by one pass
 constexpr int kS2Cap = 96;         // < 32 left over + 64 pushed by one stage-2 pass
-constexpr int kS2Run = 32;
-constexpr int kRing = 4;           // rows of the strip kept in LDS (16 bits per count) before they are stored; a power of 2         // stage 3 runs while S2 holds at least this many entries
+constexpr int kS2Run = 32;         // stage 3 runs while S2 holds at least this many entries
+constexpr int kRing = 4;           // rows of the strip kept in LDS (16 bits per count) before they are stored; a power of 2
+
+// What stage 1 needs to know about a cell, packed by cellinfo_kernel so that one scalar load
+// fetches it: byte offset of the cell's row in the mean tensor, library-size factor, global id.
+// The array holds N + 4 entries (the last cell repeated) so that prefetches need no clamp.
+struct CellInfo { uint64_t row_bytes; float s; uint32_t cell_lo, cell_hi, pad0, pad1, pad2; };
+static_assert(sizeof(CellInfo) == 32, "one s_load_dwordx8");
 
 struct S1Entry { float m, theta; uint32_t w, pos; };   // theta = a*m + b - 1, not yet clamped
-struct S2Entry { float ps, num, q; uint32_t rem; };   // pmf (x 2^32) and numerator at k = 1
+struct S2Entry { float ps, num, q; uint32_t rem; };   // pmf (x 2^32) and numerator at k = 3
 
 struct WaveLds {
     S1Entry s1[kS1Cap];
@@ -59,20 +65,19 @@ __device__ __forceinline__ int lane_rank(unsigned long long mask)
 
 template <bool VEC>
 __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
-    const float* __restrict__ means, int32_t G, const int32_t* __restrict__ row_of_cell,
-    const float* __restrict__ scal, const float* __restrict__ ga, const float* __restrict__ gbm1,
-    int64_t N, uint32_t k0, uint32_t k1, uint64_t cell_offset, const int64_t* __restrict__ cell_index,
-    int32_t* __restrict__ out, int64_t ld, int32_t strips, int32_t strip_cells,
-    uint8_t* __restrict__ heavy_flags, int32_t tiles_g)
+    const float* __restrict__ means, int32_t G, const CellInfo* __restrict__ cellinfo,
+    const float* __restrict__ ga, const float* __restrict__ gbm1, const float* __restrict__ glim,
+    int64_t N, uint32_t k0, uint32_t k1, int32_t* __restrict__ out, int64_t ld, int32_t strips,
+    int32_t strip_cells, uint8_t* __restrict__ heavy_flags, int32_t tiles_g)
 {
-    __shared__ float inv_k[prnb::kKTab + 4];          // 0 from the sentinel (k = KTAB-1) on
+    __shared__ __attribute__((aligned(16))) float inv_k[prnb::kKTab + 8];   // 0 from the sentinel (k = KTAB-1) on
     __shared__ WaveLds lds_all[kBlock / 64];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wv = tid >> 6;
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     WaveLds& L = lds_all[wv];
 
-    for (int k = tid; k < prnb::kKTab + 4; k += kBlock) inv_k[k] = (k && k < prnb::kKTab - 1) ? 1.0f / (float)k : 0.0f;
+    for (int k = tid; k < prnb::kKTab + 8; k += kBlock) inv_k[k] = (k && k < prnb::kKTab - 1) ? 1.0f / (float)k : 0.0f;
     __syncthreads();
 
     // block -> (gene tile, group of 4 strips); adjacent blocks share the gene tile (L2 reuse of
@@ -86,21 +91,24 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
     if (strip >= strips || n0 >= N) return;          // whole wave leaves together (no barrier below)
     const int cells = (int)((N - n0 < strip_cells) ? (N - n0) : strip_cells);
 
-    float a[4], bm1[4];
+    // lanes beyond G read some valid mean (see load_seg); a = b - 1 = 0 makes theta = 0, which
+    // stage 2 drops, and the huge limit keeps them out of the gamma-Poisson flags
+    float a[4], bm1[4], lim[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const bool in = g0 + j < G;
         a[j] = in ? ga[g0 + j] : 0.0f;
         bm1[j] = in ? gbm1[g0 + j] : 0.0f;
+        lim[j] = in ? glim[g0 + j] : 3.0e38f;
     }
 
     int s1_top = 0, s2_top = 0;                      // wave-uniform
     // stage-3 lane state
-    bool active = false;
     float ps = 0.0f, num = 0.0f, q = 0.0f;
     uint32_t rem = 0u, pos = 0u;
-    int k = 0;
-    float inv1 = 0.0f, inv2 = 0.0f;                  // 1/(k+1), 1/(k+2): read one pass ahead
+    constexpr int kIdle = -1;
+    int k = kIdle;
+    float4 inv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // 1/(k+1) .. 1/(k+4): read one pass ahead
 
     // S1/S2 entries carry pos = (cell-in-strip << 8) | gene-in-tile
     int32_t* const strip_out = out + n0 * ld + gbase;
@@ -109,22 +117,14 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
     int32_t flushed_pos = -1;
     for (int i = lane; i < kRing * 128; i += 64) reinterpret_cast<uint32_t*>(L.ring)[i] = 0u;
 
-    // a finished count: into the row ring while its row is still there, else straight to memory
-    auto deliver = [&](uint32_t p, int32_t res) {
-        if ((int32_t)p > flushed_pos) {
-            L.ring[p & (kRing * 256 - 1)] = (uint16_t)res;       // slot = cell % kRing, then gene-in-tile
-        } else {
-            strip_out[(p >> 8) * ld32 + (p & 255u)] = res;
-        }
-    };
     // store row `cl` of the strip from ring slot cl % kRing and clear the slot
-    auto flush_row = [&](int cl) {
+    auto flush_row = [&](int cl, int32_t* row_ptr) {
         uint2* slot = reinterpret_cast<uint2*>(L.ring + (cl & (kRing - 1)) * 256) + lane;
         const uint2 packed = *slot;
         *slot = make_uint2(0u, 0u);
         const int32_t v[4] = {(int32_t)(packed.x & 0xffffu), (int32_t)(packed.x >> 16),
                               (int32_t)(packed.y & 0xffffu), (int32_t)(packed.y >> 16)};
-        int32_t* dst = strip_out + (int64_t)cl * ld + lane * 4;
+        int32_t* dst = row_ptr + lane * 4;
         if (g0 < G) {
             if (VEC) {
                 *reinterpret_cast<int4*>(dst) = make_int4(v[0], v[1], v[2], v[3]);
@@ -137,54 +137,70 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
         flushed_pos = (cl << 8) | 255;
     };
 
-    // ---- stage 3: one pmf step for every busy lane; idle lanes pull from S2 -------------------
+    // a finished count goes into the row ring while its row is still there, else (rare) straight
+    // to memory, after the row's own store
+    auto deliver = [&](uint32_t p, int32_t res) {
+        const bool late = (int32_t)p <= flushed_pos;
+        if ((res != 0) & !late) L.ring[p & (kRing * 256 - 1)] = (uint16_t)res;   // slot = cell % kRing, gene-in-tile
+        if ((res != 0) & late) strip_out[(p >> 8) * ld32 + (p & 255u)] = res;
+    };
+
+    // ---- stage 3: four pmf steps for every busy lane; idle lanes pull from S2 ------------------
+    // A lane is idle iff k == kIdle, and an idle lane keeps ps = 0: its steps end without a hit,
+    // so the arithmetic below never asks which lanes are busy.  The pmf falls once it is under
+    // 2^-32 (it can only get there beyond the mode), so "the first hit, else 0 when the last
+    // of the four terms is 0" is the sequential walk's answer.  A walk enters at k = 3 and
+    // advances by 4: the four reciprocals 1/(k+1)..1/(k+4) are one aligned 16-byte LDS read.
     auto stage3_pass = [&]() {
-        const unsigned long long want = __builtin_amdgcn_ballot_w64(!active);
-        if (want != 0ull && s2_top > 0) {
-            const int rank = lane_rank(want);
-            if (!active && rank < s2_top) {
+        unsigned long long idle_m;
+        asm("v_cmp_eq_u32 %0, -1, %1" : "=s"(idle_m) : "v"(k));
+        if (idle_m != 0ull && s2_top > 0) {
+            const int rank = lane_rank(idle_m);
+            if (k == kIdle && rank < s2_top) {
                 const int idx = s2_top - 1 - rank;
                 const S2Entry e = L.s2[idx];
                 ps = e.ps; num = e.num; q = e.q; rem = e.rem;
                 pos = L.s2pos[idx];
-                k = 1;
-                inv1 = 0.5f;                           // 1/2
-                inv2 = 0.33333334f;                    // 1/3 (binary32-rounded, = inv_k[3])
-                active = true;
+                k = 3;
+                inv = *reinterpret_cast<const float4*>(&inv_k[4]);
             }
-            const int taken = __popcll(want);
-            s2_top = (taken < s2_top) ? s2_top - taken : 0;
+            const int left = s2_top - __popcll(idle_m);
+            s2_top = left > 0 ? left : 0;
         }
-        // two pmf steps per pass, straight-line: lanes that are idle or finish at the first
-        // step compute garbage that nothing reads
-        const uint32_t pfa = (uint32_t)ps;
-        const bool hit_a = rem < pfa;
-        const bool end_a = hit_a || pfa == 0u;          // pmf under 2^-32 (or the table's end): 0
-        const uint32_t rem_b = rem - pfa;
-        const float ps_b = (ps * num) * inv1;
-        const float num_b = num + q;
-        const uint32_t pfb = (uint32_t)ps_b;
-        const bool hit_b = rem_b < pfb;
-        const bool end_b = hit_b || pfb == 0u;
-        const bool done = active && (end_a || end_b);
-        if (done) {
-            const int32_t res = end_a ? (hit_a ? k : 0) : (hit_b ? k + 1 : 0);
-            if (res != 0) deliver(pos, res);
-            active = false;
-        }
-        rem = rem_b - pfb;
-        ps = (ps_b * num_b) * inv2;
-        num = num_b + q;
-        k = active ? k + 2 : 0;                        // idle lanes must not walk off the table
-        inv1 = inv_k[k + 1];
-        inv2 = inv_k[k + 2];
+        const uint32_t pf0 = (uint32_t)ps;
+        const bool hit0 = rem < pf0;
+        const uint32_t rem1 = rem - pf0;
+        const float ps1 = (ps * num) * inv.x;
+        const float num1 = num + q;
+        const uint32_t pf1 = (uint32_t)ps1;
+        const bool hit1 = rem1 < pf1;
+        const uint32_t rem2 = rem1 - pf1;
+        const float ps2 = (ps1 * num1) * inv.y;
+        const float num2 = num1 + q;
+        const uint32_t pf2 = (uint32_t)ps2;
+        const bool hit2 = rem2 < pf2;
+        const uint32_t rem3 = rem2 - pf2;
+        const float ps3 = (ps2 * num2) * inv.z;
+        const float num3 = num2 + q;
+        const uint32_t pf3 = (uint32_t)ps3;
+        const bool hit3 = rem3 < pf3;
+        const bool any = hit0 | hit1 | hit2 | hit3;
+        const bool done = any | (pf3 == 0u);
+        const int32_t res = any ? k + (hit0 ? 0 : (hit1 ? 1 : (hit2 ? 2 : 3))) : 0;
+        deliver(pos, res);
+        rem = rem3 - pf3;
+        ps = done ? 0.0f : (ps3 * num3) * inv.w;
+        num = num3 + q;
+        k = done ? kIdle : k + 4;
+        inv = *reinterpret_cast<const float4*>(&inv_k[k + 1]);
     };
 
-    // ---- stage 2: exact P(X = 0) for up to 64 entries of S1 ----------------------------------
+    // ---- stage 2: exact P(X = 0), then the terms k = 1, 2, for up to 64 entries of S1 ----------
     auto stage2_pass = [&]() {
         const int cnt = s1_top < 64 ? s1_top : 64;
         const bool mine = lane < cnt;
         bool push = false;
+        int32_t res = 0;
         S2Entry e2;
         uint32_t p2 = 0u;
         e2.ps = 0.0f; e2.num = 0.0f; e2.q = 0.0f; e2.rem = 0u;
@@ -198,16 +214,29 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
             const float mpp = e.m * inv_u1;
             const float t = e.m * (prnb::det_log1p(theta) * inv_th);
             const float p0 = __builtin_fminf(prnb::det_exp(-t), 0.99999994f);
-            const float ps0 = p0 * 4294967296.0f;
-            const uint32_t pf = (uint32_t)ps0;
-            if (e.w >= pf) {                      // k >= 1 (pf > 0 on the light path: P0 >= e^-12)
-                e2.rem = e.w - pf;
-                e2.num = mpp + qq;                // numerator of the step 1 -> 2
-                e2.q = qq;
-                e2.ps = (ps0 * mpp) * inv_k[1];   // pmf at k = 1, scaled by 2^32 (exact scaling)
+            const float ps0 = p0 * 4294967296.0f;       // pmf scaled by 2^32 (exact scaling)
+            const uint32_t pf0 = (uint32_t)ps0;
+            // (m <= 0 or theta <= 0: the count is 0 by definition; stage 1 does not test that)
+            if ((e.w >= pf0) & (e.m > 0.0f) & (e.theta > 0.0f)) {   // k >= 1
                 p2 = e.pos;
-                push = true;
+                const uint32_t rem1 = e.w - pf0;
+                const float ps1 = ps0 * mpp;              // (* 1/1)
+                const float num1 = mpp + qq;
+                const uint32_t pf1 = (uint32_t)ps1;
+                const bool hit1 = rem1 < pf1;
+                const uint32_t rem2 = rem1 - pf1;
+                const float ps2 = (ps1 * num1) * 0.5f;
+                const float num2 = num1 + qq;
+                const uint32_t pf2 = (uint32_t)ps2;
+                const bool hit2 = rem2 < pf2;
+                res = hit1 ? 1 : (hit2 ? 2 : 0);
+                push = !(hit1 | hit2) & (pf2 != 0u);
+                e2.rem = rem2 - pf2;
+                e2.ps = (ps2 * num2) * 0.33333334f;       // pmf at k = 3 (the 1/k table's 1/3)
+                e2.num = num2 + qq;                       // numerator of the step 3 -> 4
+                e2.q = qq;
             }
+            deliver(p2, res);
         }
         s1_top -= cnt;
         const unsigned long long m2 = __builtin_amdgcn_ballot_w64(push);
@@ -220,93 +249,88 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
     };
 
     // ---- stage 1 over the strip ----------------------------------------------------------------
-    // Row index, scaling and global id of all 128 cells of the strip are fetched once (lane l
-    // holds cells l and l+64) and handed out by v_readlane; the mean segments are loaded two
-    // cells ahead.  Nothing a pass needs is waited for inside the pass.
-    static_assert(kStripCells == 128, "two cells per lane");   // strip_cells <= kStripCells
-    int32_t rowv[2];
-    float sv[2];
-    uint64_t cellv[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int c = lane + 64 * h;
-        const int64_t n = n0 + (c < cells ? c : 0);
-        rowv[h] = row_of_cell[n];
-        sv[h] = scal[n];
-        cellv[h] = cell_index ? (uint64_t)cell_index[n] : cell_offset + (uint64_t)n;
-    }
-    auto cell_row = [&](int cl) -> int64_t {
-        const int src = cl & 63;
-        return (int64_t)((cl < 64) ? __builtin_amdgcn_readlane(rowv[0], src) : __builtin_amdgcn_readlane(rowv[1], src));
-    };
+    // What a pass needs per cell is wave-uniform and arrives by scalar loads issued one pass (the
+    // row offset: three passes) earlier; the mean segments are loaded two cells ahead.  Nothing
+    // is waited for inside the pass that needs it.
+    static_assert(kStripCells == 128, "pos keeps the cell in 7 bits above the gene's 8");
+    const CellInfo* cinfo = cellinfo + n0;                   // wave-uniform running pointers
+    int32_t* flush_ptr = strip_out;                          // row cl - kRing of the strip
+    uint8_t* flag_ptr = heavy_flags + ((n0 * tiles_g + tile_g) << 6);
+    const int64_t flag_step = (int64_t)tiles_g << 6;
+    const uint32_t lane4 = (uint32_t)lane * 4u;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t s1_lds = (uint32_t)(uintptr_t)&L.s1[0];     // LDS byte address of the stack
+    const int32_t gload = VEC ? (g0 < G ? g0 : G - 4) - gbase : 0;
+    const float* const mcol = means + gbase;
     struct Seg { float M[4]; };
-    auto load_seg = [&](int cl) -> Seg {
+    auto load_seg = [&](uint64_t row_bytes) -> Seg {
         Seg r;
-        r.M[0] = r.M[1] = r.M[2] = r.M[3] = 0.0f;
-        if (cl < cells && g0 < G) {
-            const int64_t row = cell_row(cl);
-            if (VEC) {
-                const float4 v = *reinterpret_cast<const float4*>(means + row * G + g0);
-                r.M[0] = v.x; r.M[1] = v.y; r.M[2] = v.z; r.M[3] = v.w;
-            } else {
+        const float* rowp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(mcol) + row_bytes);
+        if (VEC) {
+            const float4 v = *reinterpret_cast<const float4*>(rowp + gload);
+            r.M[0] = v.x; r.M[1] = v.y; r.M[2] = v.z; r.M[3] = v.w;
+        } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (g0 + j < G) r.M[j] = means[row * G + g0 + j];
-            }
+            for (int j = 0; j < 4; ++j) r.M[j] = (g0 + j < G) ? rowp[lane4 + j] : 0.0f;
         }
         return r;
     };
-    Seg cur = load_seg(0), nxt = load_seg(1);
+    Seg cur = load_seg(cinfo[0].row_bytes), nxt = load_seg(cinfo[1].row_bytes);
+    uint64_t row2 = cinfo[2].row_bytes;
+    float s = cinfo[0].s;
+    uint32_t c_lo = cinfo[0].cell_lo, c_hi = cinfo[0].cell_hi;
 #pragma unroll 1
     for (int cl = 0; cl < cells; ++cl) {
-        const Seg nn = load_seg(cl + 2);
-        const int src = cl & 63;
-        const float s = __uint_as_float((cl < 64) ? __builtin_amdgcn_readlane(__float_as_uint(sv[0]), src)
-                                                  : __builtin_amdgcn_readlane(__float_as_uint(sv[1]), src));
-        const uint32_t c_lo = (cl < 64) ? __builtin_amdgcn_readlane((uint32_t)cellv[0], src)
-                                        : __builtin_amdgcn_readlane((uint32_t)cellv[1], src);
-        const uint32_t c_hi = (cl < 64) ? __builtin_amdgcn_readlane((uint32_t)(cellv[0] >> 32), src)
-                                        : __builtin_amdgcn_readlane((uint32_t)(cellv[1] >> 32), src);
-        const uint64_t cell = ((uint64_t)c_hi << 32) | c_lo;
-        // every lane runs the whole pass (lanes beyond G just never qualify): the stack tops
-        // must stay wave-uniform, so no ballot may sit under a divergent branch
+        const Seg nn = load_seg(row2);
+        const uint64_t row3 = cinfo[3].row_bytes;
+        const float s_next = cinfo[1].s;
+        const uint32_t c_lo_next = cinfo[1].cell_lo, c_hi_next = cinfo[1].cell_hi;
+        ++cinfo;
+        // every lane runs the whole pass: the stack tops must stay wave-uniform, so no ballot
+        // may sit under a divergent branch
         const float M[4] = {cur.M[0], cur.M[1], cur.M[2], cur.M[3]};
-        if (cl >= kRing) flush_row(cl - kRing);
+        if (cl >= kRing) {
+            flush_row(cl - kRing, flush_ptr);
+            flush_ptr += ld;
+        }
 #if K3_ABLATE == 3     // no Philox: a 2-instruction hash stands in
         prnb::Words W;
-        W.w[0] = ((uint32_t)cell * 2654435761u) ^ ((uint32_t)g0 * 40503u); W.w[1] = W.w[0] * 3u + k0;
+        W.w[0] = (c_lo * 2654435761u) ^ ((uint32_t)g0 * 40503u); W.w[1] = W.w[0] * 3u + k0;
         W.w[2] = W.w[1] ^ 0x9E3779B9u; W.w[3] = W.w[2] + W.w[0];
 #else
-        const prnb::Words W =
-            prnb::philox4x32_10((uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)g0 >> 2, 0u, k0, k1);
+        const prnb::Words W = prnb::philox4x32_10<2>(c_lo, c_hi, (uint32_t)g0 >> 2, 0u, k0, k1);
 #endif
         uint32_t hflag = 0u;
+        const uint32_t posbase = (uint32_t)cl << 8;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            // genes beyond G carry M = 0 and so never qualify; no lane-dependent branch here
             const float m = M[j] * s;
-            const float theta = PRNB_FMA(a[j], m, bm1[j]);
-            const bool valid = (m > 0.0f) && (theta > 0.0f);
-            const bool light = (m <= prnb::kLightM) && (theta <= prnb::kLightTheta);
-            // P(X=0) = exp(-m*log1p(theta)/theta) >= exp(-m) >= 1 - m + m^2/2 - m^3/6.  The
-            // polynomial is evaluated times 2^32 with 1e-5 taken off the constant term: far more
-            // than every rounding of the exact evaluation, so a sample settled here is one the
-            // exact path would also call 0.
+            // P(X=0) = exp(-m*log1p(theta)/theta) >= exp(-m) >= 1 - m + m^2/2 - m^3/6 for theta > 0.
+            // The polynomial is evaluated times 2^32 with 1e-5 taken off the constant term: far
+            // more than every rounding of the exact evaluation, so a sample settled here is one
+            // the exact path would also call 0 (and a sample with theta <= 0 is 0 by definition).
             const float bound32 = PRNB_FMA(PRNB_FMA(PRNB_FMA(-715827882.7f, m, 2147483648.0f), m, -4294967296.0f),
                                            m, 4294924346.0f);
-            const bool zero = (float)W.w[j] < bound32;
-            const bool to_s1 = valid && light && !zero;
-            const unsigned long long m1 = __builtin_amdgcn_ballot_w64(to_s1);
-            if (to_s1) {
-                S1Entry e;
-                e.m = m; e.theta = theta; e.w = W.w[j]; e.pos = ((uint32_t)cl << 8) | (uint32_t)(lane * 4 + j);
-                L.s1[s1_top + lane_rank(m1)] = e;
-            }
-            s1_top += __popcll(m1);
-            hflag |= (valid && !light) ? (1u << j) : 0u;
+            // Compare masks straight into SGPR pairs (every lane is active here, so they are the
+            // ballots), the push as one LDS store under exec = mask: no branch, no exec save.
+            unsigned long long hv_m, nlt_m, carry;
+            asm("v_cmp_nle_f32 %0, %1, %2" : "=s"(hv_m) : "v"(m), "v"(lim[j]));         // not the inversion class (or NaN)
+            asm("v_cmp_nlt_f32 %0, %1, %2" : "=s"(nlt_m) : "v"((float)W.w[j]), "v"(bound32));   // not settled as 0
+            const unsigned long long push_m = nlt_m & ~hv_m;
+            u32x4 e;                                           // S1Entry {m, theta, w, pos}
+            e.x = __float_as_uint(m);
+            e.y = __float_as_uint(PRNB_FMA(a[j], m, bm1[j]));
+            e.z = W.w[j];
+            e.w = posbase | (lane4 + j);
+            const uint32_t slot = (s1_lds + ((uint32_t)s1_top << 4)) + ((uint32_t)lane_rank(push_m) << 4);
+            asm volatile("s_mov_b64 exec, %0\n\tds_write_b128 %1, %2\n\ts_mov_b64 exec, -1"
+                         :: "s"(push_m), "v"(slot), "v"(e) : "memory");
+            s1_top += __popcll(push_m);
+            // gamma-Poisson samples are only flagged: hflag = 2 * hflag + bit, i.e. gene j -> bit 3 - j
+            asm("v_addc_co_u32 %0, %1, %0, %0, %2" : "+v"(hflag), "=s"(carry) : "s"(hv_m));
         }
-        // gamma-Poisson samples are only flagged: 4 bits per lane, one byte per (cell, tile, lane)
-        heavy_flags[(((n0 + cl) * tiles_g + tile_g) << 6) + lane] = (uint8_t)hflag;
+        *(flag_ptr + lane) = (uint8_t)hflag;                   // one byte per (cell, tile, lane)
+        flag_ptr += flag_step;
 #if K3_ABLATE == 2      // stage 1 only
         s1_top = 0;
 #elif K3_ABLATE == 1    // no stage 3
@@ -319,6 +343,10 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
 #endif
         cur = nxt;
         nxt = nn;
+        row2 = row3;
+        s = s_next;
+        c_lo = c_lo_next;
+        c_hi = c_hi_next;
     }
 
     // ---- drain ------------------------------------------------------------------------------------
@@ -326,8 +354,8 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
         stage2_pass();
         while (s2_top >= kS2Run) stage3_pass();
     }
-    while (s2_top > 0 || __builtin_amdgcn_ballot_w64(active) != 0ull) stage3_pass();
-    for (int cl = (cells > kRing ? cells - kRing : 0); cl < cells; ++cl) flush_row(cl);
+    while (s2_top > 0 || __builtin_amdgcn_ballot_w64(k != kIdle) != 0ull) stage3_pass();
+    for (int cl = (cells > kRing ? cells - kRing : 0); cl < cells; ++cl) flush_row(cl, strip_out + (int64_t)cl * ld);
 }
 
 }  // namespace k3

@@ -15,7 +15,7 @@
 
 namespace prnb {
 
-constexpr float kLightM = 19.0f;       // light path iff m <= 19 and theta <= 16 (P0 >= e^-19 > 2^-28)
+constexpr float kLightM = 19.0f;       // inversion iff m <= min(19, largest m with theta <= 16): P0 >= e^-19 > 2^-28
 constexpr float kLightTheta = 16.0f;
 constexpr float kThetaMin = 8.6736174e-19f;  // 2^-60
 constexpr float kThetaMax = 1.0e18f;
@@ -32,7 +32,10 @@ __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
 
 struct Words { uint32_t w[4]; };
 
-// Philox4x32-10 (Salmon, Moraes, Dror, Shaw 2011)
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw 2011).  Rounds from kXor3From on spell the two
+// 3-input xors as one v_bitop3_b32 each (gfx950); callers whose counter is partly wave-uniform
+// leave the first two rounds to the compiler, which moves their uniform halves to the scalar unit.
+template <int kXor3From = 10>
 __device__ __forceinline__ Words philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                uint32_t k0, uint32_t k1)
 {
@@ -41,9 +44,14 @@ __device__ __forceinline__ Words philox4x32_10(uint32_t c0, uint32_t c1, uint32_
         // one 32x32->64 product per multiplier (v_mad_u64_u32) instead of separate hi and lo multiplies
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        c0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        if (round >= kXor3From) {
+            c0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96);
+            c2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, k1, 0x96);
+        } else {
+            c0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+            c2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        }
         c1 = (uint32_t)p1;
-        c2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
         c3 = (uint32_t)p0;
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
@@ -272,7 +280,16 @@ struct Params {
     bool light;
 };
 
-__device__ __forceinline__ Params make_params(float M, float s, float a, float bm1)
+// Largest mean of gene (a, b - 1) that is sampled by inversion: theta = a*m + b - 1 stays <= 16
+// (up to one rounding) for every m in (0, limit].  One IEEE division per gene, done once.
+__device__ __forceinline__ float light_limit(float a, float bm1)
+{
+    if (!(bm1 <= kLightTheta)) return -__builtin_inff();      // also NaN
+    if (!(a > 0.0f)) return kLightM;
+    return __builtin_fminf(kLightM, (kLightTheta - bm1) / a);
+}
+
+__device__ __forceinline__ Params make_params(float M, float s, float a, float bm1, float lim)
 {
     Params P;
     P.m = M * s;
@@ -284,7 +301,7 @@ __device__ __forceinline__ Params make_params(float M, float s, float a, float b
     P.theta = theta;
     P.inv_th = d * u1;
     P.inv_u1 = d * theta;
-    P.light = (P.m <= kLightM) && (theta <= kLightTheta);
+    P.light = P.m <= lim;
     return P;
 }
 

@@ -117,14 +117,35 @@ __global__ void prep_params_kernel(const double* __restrict__ scaling, int64_t N
                                    const double* __restrict__ alpha,
                                    const double* __restrict__ beta, int32_t G,
                                    float* __restrict__ scal_f, float* __restrict__ a_f,
-                                   float* __restrict__ bm1_f)
+                                   float* __restrict__ bm1_f, float* __restrict__ lim_f)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < N) scal_f[i] = (float)scaling[i];
     if (i < G) {
-        a_f[i] = (float)alpha[i];
-        bm1_f[i] = (float)(beta[i] - 1.0);   // binary64 subtraction: beta = 1 + 1e-8 must survive
+        const float a = (float)alpha[i];
+        const float bm1 = (float)(beta[i] - 1.0);   // binary64 subtraction: beta = 1 + 1e-8 must survive
+        a_f[i] = a;
+        bm1_f[i] = bm1;
+        lim_f[i] = prnb::light_limit(a, bm1);
     }
+}
+
+// Per-cell record of the streaming kernel (k3::CellInfo); N + 4 entries, the last cell repeated.
+__global__ void cellinfo_kernel(const int32_t* __restrict__ row_of_cell, const float* __restrict__ scal,
+                                int64_t N, int32_t G, uint64_t cell_offset,
+                                const int64_t* __restrict__ cell_index, k3::CellInfo* __restrict__ info)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N + 4) return;
+    const int64_t n = i < N ? i : N - 1;
+    const uint64_t cell = cell_index ? (uint64_t)cell_index[n] : cell_offset + (uint64_t)n;
+    k3::CellInfo c;
+    c.row_bytes = (uint64_t)row_of_cell[n] * (uint64_t)G * 4u;
+    c.s = scal[n];
+    c.cell_lo = (uint32_t)cell;
+    c.cell_hi = (uint32_t)(cell >> 32);
+    c.pad0 = c.pad1 = c.pad2 = 0u;
+    info[i] = c;
 }
 
 constexpr int kTileG = 256;   // genes per tile = 64 lanes x 4
@@ -159,12 +180,13 @@ __global__ __launch_bounds__(kBlock) void sample_counts_kernel(
     if (tid == 0) q_count = 0;
     __syncthreads();
 
-    float a[4], bm1[4];
+    float a[4], bm1[4], lim[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const bool in = g0 + j < G;
         a[j] = in ? ga[g0 + j] : 0.0f;
         bm1[j] = in ? gbm1[g0 + j] : 0.0f;
+        lim[j] = prnb::light_limit(a[j], bm1[j]);
     }
 
     bool bad = false;
@@ -190,7 +212,7 @@ __global__ __launch_bounds__(kBlock) void sample_counts_kernel(
         for (int j = 0; j < 4; ++j) {
             int32_t res = 0;
             if (g0 + j < G) {
-                const prnb::Params P = prnb::make_params(M[j], s, a[j], bm1[j]);
+                const prnb::Params P = prnb::make_params(M[j], s, a[j], bm1[j], lim[j]);
                 if (!P.valid) {
                     bad = bad || !(P.m > 0.0f) || (__builtin_fmaf(a[j], P.m, bm1[j]) < 0.0f);
                 } else if (P.light) {
@@ -213,7 +235,8 @@ __global__ __launch_bounds__(kBlock) void sample_counts_kernel(
         const int32_t g = tile_g * kTileG + gl;
         const uint64_t cell = cell_index ? (uint64_t)cell_index[n] : cell_offset + (uint64_t)n;
         const prnb::Params P =
-            prnb::make_params(means[(int64_t)row_of_cell[n] * G + g], scal[n], ga[g], gbm1[g]);
+            prnb::make_params(means[(int64_t)row_of_cell[n] * G + g], scal[n], ga[g], gbm1[g],
+                          prnb::light_limit(ga[g], gbm1[g]));
         tile[cl][gl] = prnb::heavy_draw(P, (uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)g, k0,
                                         k1, inv_k);
     }
@@ -248,7 +271,8 @@ __global__ void nb_params_kernel(const float* __restrict__ means, int32_t G,
     const int64_t n = i / G;
     const int32_t g = (int32_t)(i - n * G);
     const prnb::Params P =
-        prnb::make_params(means[(int64_t)row_of_cell[n] * G + g], scal[n], ga[g], gbm1[g]);
+        prnb::make_params(means[(int64_t)row_of_cell[n] * G + g], scal[n], ga[g], gbm1[g],
+                          prnb::light_limit(ga[g], gbm1[g]));
     if (mu) mu[i] = P.m;
     if (p) p[i] = P.valid ? P.theta * P.inv_u1 : 0.0f;
     if (r) r[i] = P.valid ? P.m * P.inv_th : 0.0f;
@@ -534,7 +558,7 @@ PA_EXPORT int prosstt_amd_last_kernel_ms(prosstt_amd_ctx* c, float* ms)
 // converts the binary64 per-cell / per-gene parameters into the workspace.
 struct SamplerArgs {
     const float* means; const int32_t* row_of_cell;
-    float *scal, *ga, *gbm1;
+    float *scal, *ga, *gbm1, *glim;
     void* extra;     // `extra_bytes` of workspace behind the parameter vectors (256-B aligned)
 };
 
@@ -570,7 +594,7 @@ static int sampler_setup(prosstt_amd_ctx* c, Staging& st, const float* means, in
         beta = (const double*)d;
     }
     const int64_t n_pad = (N + 15) & ~(int64_t)15;
-    const size_t vec_bytes = ((((size_t)n_pad + 2 * (size_t)G) * sizeof(float)) + 255) & ~(size_t)255;
+    const size_t vec_bytes = ((((size_t)n_pad + 3 * (size_t)G) * sizeof(float)) + 255) & ~(size_t)255;
     int rc = ws_reserve(c, vec_bytes + extra_bytes);
     if (rc) return rc;
     A->means = means;
@@ -578,10 +602,11 @@ static int sampler_setup(prosstt_amd_ctx* c, Staging& st, const float* means, in
     A->scal = (float*)c->ws;
     A->ga = A->scal + n_pad;
     A->gbm1 = A->ga + G;
+    A->glim = A->gbm1 + G;
     A->extra = (char*)c->ws + vec_bytes;
     const int64_t span = N > G ? N : G;
     prep_params_kernel<<<dim3((unsigned)((span + 255) / 256)), dim3(256), 0, c->stream>>>(
-        scaling, N, alpha, beta, G, A->scal, A->ga, A->gbm1);
+        scaling, N, alpha, beta, G, A->scal, A->ga, A->gbm1, A->glim);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -598,13 +623,16 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
     // per row of the mean tensor for the domain check
     const size_t flag_bytes = (flags & PROSSTT_AMD_KERNEL_TILED) ? 0
         : (size_t)(N > 0 ? N : 0) * (size_t)(((int64_t)(G > 0 ? G : 0) + kTileG - 1) / kTileG) * 64;
-    const size_t word_bytes = ((flag_bytes + 255) & ~(size_t)255) + (size_t)(rows > 0 ? rows : 0) + 256;
+    const size_t rows_bytes = (((size_t)(rows > 0 ? rows : 0)) + 255) & ~(size_t)255;
+    const size_t info_bytes = (flags & PROSSTT_AMD_KERNEL_TILED) ? 0 : ((size_t)(N > 0 ? N : 0) + 4) * sizeof(k3::CellInfo);
+    const size_t word_bytes = ((flag_bytes + 255) & ~(size_t)255) + rows_bytes + info_bytes + 256;
     int rc = sampler_setup(c, st, means, rows, G, row_of_cell, scaling, alpha, beta, N, flags, &A, word_bytes);
     if (rc) return rc;
     if (N == 0 || G == 0) return 0;
     if (!out) return fail(PROSSTT_AMD_EINVAL, "out is NULL");
     uint8_t* heavy_flags = (uint8_t*)A.extra;
     uint8_t* rows_used = heavy_flags + ((flag_bytes + 255) & ~(size_t)255);
+    k3::CellInfo* cellinfo = (k3::CellInfo*)(rows_used + rows_bytes);
     if (ld_out < G) return fail(PROSSTT_AMD_EINVAL, "ld_out %lld < G %d", (long long)ld_out, G);
 
     if (cell_index && (flags & PROSSTT_AMD_HOST_INPUTS)) {
@@ -627,11 +655,11 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     if (flags & PROSSTT_AMD_TIME_KERNEL) {
         if ((rc = next_event_pair(c, &ev_start, &ev_stop))) return rc;
-        HIP_TRY(hipEventRecord(ev_start, c->stream));
     }
     if (flags & PROSSTT_AMD_KERNEL_TILED) {
         const int64_t tiles_c = (N + kTileC - 1) / kTileC;
         if (tiles_c * tiles_g > 0x7fffffffll) return fail(PROSSTT_AMD_EINVAL, "too many tiles; chunk the cells");
+        if (ev_start) HIP_TRY(hipEventRecord(ev_start, c->stream));
         const dim3 grid((unsigned)(tiles_c * tiles_g)), block(kBlock);
         if (vec)
             sample_counts_kernel<true><<<grid, block, 0, c->stream>>>(A.means, G, A.row_of_cell, A.scal, A.ga,
@@ -652,15 +680,19 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
         const int64_t groups = (strips + 3) / 4;
         if (groups * tiles_g > 0x7fffffffll || N > 0x7fffffffll)
             return fail(PROSSTT_AMD_EINVAL, "too many tiles; chunk the cells");
+        if ((uint64_t)rows * (uint64_t)G >= ((uint64_t)1 << 61)) return fail(PROSSTT_AMD_EINVAL, "mean tensor too large");
+        cellinfo_kernel<<<dim3((unsigned)((N + 4 + 255) / 256)), dim3(256), 0, c->stream>>>(
+            A.row_of_cell, A.scal, N, G, cell_offset, cell_index, cellinfo);
         const dim3 grid((unsigned)(groups * tiles_g)), block(k3::kBlock);
+        if (ev_start) HIP_TRY(hipEventRecord(ev_start, c->stream));    // the dominant kernel is timed alone
         if (vec)
             k3::sample_counts_stream_kernel<true><<<grid, block, 0, c->stream>>>(
-                A.means, G, A.row_of_cell, A.scal, A.ga, A.gbm1, N, k0, k1, cell_offset, cell_index, d_out,
-                ld_out, (int32_t)strips, (int32_t)strip_cells, heavy_flags, (int32_t)tiles_g);
+                A.means, G, cellinfo, A.ga, A.gbm1, A.glim, N, k0, k1, d_out, ld_out, (int32_t)strips,
+                (int32_t)strip_cells, heavy_flags, (int32_t)tiles_g);
         else
             k3::sample_counts_stream_kernel<false><<<grid, block, 0, c->stream>>>(
-                A.means, G, A.row_of_cell, A.scal, A.ga, A.gbm1, N, k0, k1, cell_offset, cell_index, d_out,
-                ld_out, (int32_t)strips, (int32_t)strip_cells, heavy_flags, (int32_t)tiles_g);
+                A.means, G, cellinfo, A.ga, A.gbm1, A.glim, N, k0, k1, d_out, ld_out, (int32_t)strips,
+                (int32_t)strip_cells, heavy_flags, (int32_t)tiles_g);
         HIP_TRY(hipGetLastError());
         if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, c->stream));   // the dominant kernel is timed alone
         // 16-wave blocks, two per CU; each gets a strided share of the flag tickets
