@@ -213,14 +213,17 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
     auto expand = [&](const Ticket& t) {
         unsigned long long bits = t.bits;
         while (__builtin_amdgcn_ballot_w64(bits != 0ull) != 0ull) {
-            const bool has = bits != 0ull;
-            const int b = has ? __builtin_ctzll(bits) : 0;
+            const bool any = bits != 0ull;
+            const int b = any ? __builtin_ctzll(bits) : 0;
             bits &= bits - 1ull;
+            const int32_t byte = t.byte0 + (b >> 3);       // = tile*64 + lane-in-tile
+            const int32_t gene = byte * 4 + 3 - (b & 7);
+            // (lanes of the last tile beyond G flag whatever NaN or infinite mean they happened to read)
+            const bool has = any && gene < G;
             const unsigned long long m = __builtin_amdgcn_ballot_w64(has);
             if (has) {
-                const int32_t byte = t.byte0 + (b >> 3);   // = tile*64 + lane-in-tile
                 HGEntry e;
-                e.n = (int32_t)t.n; e.g = byte * 4 + 3 - (b & 7); e.attempt = 0; e.row = t.row;
+                e.n = (int32_t)t.n; e.g = gene; e.attempt = 0; e.row = t.row;
                 L.hg[hg_top + lane_rank(m)] = e;
             }
             hg_top += __popcll(m);

@@ -43,7 +43,9 @@ constexpr int kRing = 4;           // rows of the strip kept in LDS (16 bits per
 // What stage 1 needs to know about a cell, packed by cellinfo_kernel so that one scalar load
 // fetches it: byte offset of the cell's row in the mean tensor, library-size factor, global id.
 // The array holds N + 4 entries (the last cell repeated) so that prefetches need no clamp.
-struct CellInfo { uint64_t row_bytes; float s; uint32_t cell_lo, cell_hi, pad0, pad1, pad2; };
+// (pos_base = (cell index within its strip) << 8 rides along so that the 16-byte scalar load has
+// no dead destination register for the allocator to reuse while the load is in flight.)
+struct CellInfo { uint64_t row_bytes; float s; uint32_t cell_lo, cell_hi, pos_base, pad1, pad2; };
 static_assert(sizeof(CellInfo) == 32, "one s_load_dwordx8");
 
 struct S1Entry { float m, theta; uint32_t w, pos; };   // theta = a*m + b - 1, not yet clamped
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
         const int32_t v[4] = {(int32_t)(packed.x & 0xffffu), (int32_t)(packed.x >> 16),
                               (int32_t)(packed.y & 0xffffu), (int32_t)(packed.y >> 16)};
         int32_t* dst = row_ptr + lane * 4;
-        if (g0 < G) {
+        if (g0 < G && (K3_ABLATE != 5 || v[0] == 12345)) {
             if (VEC) {
                 *reinterpret_cast<int4*>(dst) = make_int4(v[0], v[1], v[2], v[3]);
             } else {
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
         ps = done ? 0.0f : (ps3 * num3) * inv.w;
         num = num3 + q;
         k = done ? kIdle : k + 4;
-        inv = *reinterpret_cast<const float4*>(&inv_k[k + 1]);
+        inv = *reinterpret_cast<const float4*>(__builtin_assume_aligned(&inv_k[k + 1], 16));   // k + 1 = 0 mod 4
     };
 
     // ---- stage 2: exact P(X = 0), then the terms k = 1, 2, for up to 64 entries of S1 ----------
@@ -206,14 +208,15 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
         e2.ps = 0.0f; e2.num = 0.0f; e2.q = 0.0f; e2.rem = 0u;
         if (mine) {
             const S1Entry e = L.s1[s1_top - 1 - lane];
-            const float theta = __builtin_fminf(__builtin_fmaxf(e.theta, prnb::kThetaMin), prnb::kThetaMax);
+            // (the clamp to kThetaMax of the general path cannot bind: theta <= 16 in this class)
+            const float theta = __builtin_fmaxf(e.theta, prnb::kThetaMin);
             const float u1 = 1.0f + theta;
             const float d = prnb::det_rcp(theta * u1);
             const float inv_th = d * u1, inv_u1 = d * theta;
             const float qq = theta * inv_u1;
             const float mpp = e.m * inv_u1;
             const float t = e.m * (prnb::det_log1p(theta) * inv_th);
-            const float p0 = __builtin_fminf(prnb::det_exp(-t), 0.99999994f);
+            const float p0 = __builtin_fminf(prnb::det_exp_small(-t), 0.99999994f);   // t <= 19
             const float ps0 = p0 * 4294967296.0f;       // pmf scaled by 2^32 (exact scaling)
             const uint32_t pf0 = (uint32_t)ps0;
             // (m <= 0 or theta <= 0: the count is 0 by definition; stage 1 does not test that)
@@ -278,14 +281,9 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
     Seg cur = load_seg(cinfo[0].row_bytes), nxt = load_seg(cinfo[1].row_bytes);
     uint64_t row2 = cinfo[2].row_bytes;
     float s = cinfo[0].s;
-    uint32_t c_lo = cinfo[0].cell_lo, c_hi = cinfo[0].cell_hi;
+    uint32_t c_lo = cinfo[0].cell_lo, c_hi = cinfo[0].cell_hi, posbase = cinfo[0].pos_base;
 #pragma unroll 1
     for (int cl = 0; cl < cells; ++cl) {
-        const Seg nn = load_seg(row2);
-        const uint64_t row3 = cinfo[3].row_bytes;
-        const float s_next = cinfo[1].s;
-        const uint32_t c_lo_next = cinfo[1].cell_lo, c_hi_next = cinfo[1].cell_hi;
-        ++cinfo;
         // every lane runs the whole pass: the stack tops must stay wave-uniform, so no ballot
         // may sit under a divergent branch
         const float M[4] = {cur.M[0], cur.M[1], cur.M[2], cur.M[3]};
@@ -293,6 +291,16 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
             flush_row(cl - kRing, flush_ptr);
             flush_ptr += ld;
         }
+        // The scalar loads go out only now, behind the flush's LDS read: scalar and LDS returns
+        // share one counter that can only be waited down to zero, and the next LDS read is a
+        // whole Philox call away.
+        __builtin_amdgcn_sched_barrier(0);
+        const Seg nn = load_seg(row2);
+        const uint64_t row3 = cinfo[3].row_bytes;
+        const float s_next = cinfo[1].s;
+        const uint32_t c_lo_next = cinfo[1].cell_lo, c_hi_next = cinfo[1].cell_hi, posbase_next = cinfo[1].pos_base;
+        ++cinfo;
+        __builtin_amdgcn_sched_barrier(0);
 #if K3_ABLATE == 3     // no Philox: a 2-instruction hash stands in
         prnb::Words W;
         W.w[0] = (c_lo * 2654435761u) ^ ((uint32_t)g0 * 40503u); W.w[1] = W.w[0] * 3u + k0;
@@ -301,7 +309,6 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
         const prnb::Words W = prnb::philox4x32_10<2>(c_lo, c_hi, (uint32_t)g0 >> 2, 0u, k0, k1);
 #endif
         uint32_t hflag = 0u;
-        const uint32_t posbase = (uint32_t)cl << 8;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float m = M[j] * s;
@@ -323,15 +330,23 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
             e.z = W.w[j];
             e.w = posbase | (lane4 + j);
             const uint32_t slot = (s1_lds + ((uint32_t)s1_top << 4)) + ((uint32_t)lane_rank(push_m) << 4);
+#if K3_ABLATE != 6
             asm volatile("s_mov_b64 exec, %0\n\tds_write_b128 %1, %2\n\ts_mov_b64 exec, -1"
                          :: "s"(push_m), "v"(slot), "v"(e) : "memory");
+#else
+            asm volatile("" :: "s"(push_m), "v"(slot), "v"(e));
+#endif
             s1_top += __popcll(push_m);
             // gamma-Poisson samples are only flagged: hflag = 2 * hflag + bit, i.e. gene j -> bit 3 - j
             asm("v_addc_co_u32 %0, %1, %0, %0, %2" : "+v"(hflag), "=s"(carry) : "s"(hv_m));
         }
+#if K3_ABLATE != 7
         *(flag_ptr + lane) = (uint8_t)hflag;                   // one byte per (cell, tile, lane)
+#else
+        asm volatile("" :: "v"(hflag));
+#endif
         flag_ptr += flag_step;
-#if K3_ABLATE == 2      // stage 1 only
+#if K3_ABLATE == 2 || K3_ABLATE >= 5      // stage 1 only (5: no row store, 6: no S1 push, 7: no flag store)
         s1_top = 0;
 #elif K3_ABLATE == 1    // no stage 3
         while (s1_top >= 64) { stage2_pass(); s2_top = 0; }
@@ -347,6 +362,7 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
         s = s_next;
         c_lo = c_lo_next;
         c_hi = c_hi_next;
+        posbase = posbase_next;
     }
 
     // ---- drain ------------------------------------------------------------------------------------

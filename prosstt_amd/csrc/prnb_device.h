@@ -115,9 +115,9 @@ __device__ __forceinline__ float det_log1pmx(float d, float rho)
     return det_log(rho) - d;
 }
 
-__device__ __forceinline__ float det_exp(float x)
+// det_exp without the underflow guard: the same value for every x > -87
+__device__ __forceinline__ float det_exp_small(float x)
 {
-    if (!(x > -87.0f)) return 0.0f;
     const float z = __builtin_floorf(PRNB_FMA(x, 1.44269504088896341f, 0.5f));
     float r = PRNB_FMA(z, -0.693359375f, x);
     r = PRNB_FMA(z, 2.12194440e-4f, r);
@@ -131,6 +131,11 @@ __device__ __forceinline__ float det_exp(float x)
     return y * u2f((uint32_t)((int32_t)z + 127) << 23);
 }
 
+__device__ __forceinline__ float det_exp(float x)
+{
+    if (!(x > -87.0f)) return 0.0f;
+    return det_exp_small(x);
+}
 __device__ __forceinline__ float det_cos2pi(uint32_t w)
 {
     const uint32_t j = w >> 29;

@@ -90,6 +90,44 @@ def test_edge_parameters_bit_exact(ctx):
         assert got.max() > 0
 
 
+def test_inversion_class_limit_and_invalid_inputs_bit_exact(ctx, monkeypatch):
+    """The inversion class is `m <= light_limit(gene)`; everything else -- including
+    non-positive, infinite and NaN means, alpha < 0, beta < 1, beta - 1 > 16 -- takes the
+    gamma-Poisson kernel or is a 0 by definition.  Unchecked mode, both kernels, bit-exact
+    against the model; the path codes of nb_params agree with the model's too."""
+    from oracle import nb_model
+    rng = np.random.default_rng(77)
+    alphas = np.array([0.0, 1e-4, 0.2, 0.79, 0.8, 1.0, 3.0, 50.0, -0.1, -2.0, np.nan, 0.3])
+    betas = np.array([1.0, 1 + 1e-8, 0.5, 2.0, 3.0, 16.9, 17.0, 17.1, 40.0, 1.5, np.nan])
+    G = len(alphas) * len(betas)                       # 132: ragged against the 256-gene tile, G % 4 == 0
+    al, be = [x.ravel() for x in np.meshgrid(alphas, betas, indexing="ij")]
+    rows = 24
+    means = np.exp(rng.normal(0.5, 2.0, (rows, G))).astype(np.float32)
+    means[0, :] = 0.0
+    means[1, ::3] = -1.0
+    means[2, ::5] = np.inf
+    means[3, ::7] = np.nan
+    means[4, :] = 1e-45                                # binary32 denormal
+    means[5, :] = 18.999
+    means[6, :] = 19.0
+    means[7, :] = 19.001
+    N = 600
+    roc = rng.integers(0, rows, N).astype(np.int32)
+    sc = np.exp(rng.normal(0, 0.5, N))
+    sc[::50] = 1.0                                     # rows 5-7 hit the limit exactly for some cells
+    want = nb_model.sample_counts(means, roc, sc, al, be, 4242, 17)
+    for kernel in ("", "tiled"):
+        monkeypatch.setenv("PROSSTT_AMD_KERNEL", kernel)
+        got = ctx.sample_counts(means, roc, sc, al, be, seed=4242, cell_offset=17, check_domain=False).cpu().numpy()
+        np.testing.assert_array_equal(got, want)
+    monkeypatch.setenv("PROSSTT_AMD_KERNEL", "")
+    assert want.max() > 0 and (want[roc == 0] == 0).all()
+    path = ctx.nb_params(means, roc, sc, al, be)[3].cpu().numpy()
+    mpath = nb_model.nb_params(means, roc, sc, al, be)[3]
+    np.testing.assert_array_equal(path, mpath)
+    assert set(np.unique(path)) == {0, 1, 2}
+
+
 def test_domain_errors_like_scipy(ctx):
     """simulation.py:647-648: an exact-zero mean, or alpha*m + beta < 1, raises ValueError;
     alpha = 0, beta = 1 silently yields zeros."""
