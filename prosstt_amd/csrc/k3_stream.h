@@ -37,7 +37,8 @@ constexpr int kTileG = 256;        // genes per wave pass: 64 lanes x 4
 constexpr int kStripCells = 128;   // most cells per wave: long strips amortise the drain of stage 3
 constexpr int kS1Cap = 320;        // < 64 left over + 256 pushed by one pass
 constexpr int kS2Cap = 96;         // < 32 left over + 64 pushed by one stage-2 pass
-constexpr int kS2Run = 32;         // stage 3 runs while S2 holds at least this many entries
+constexpr int kS2Run = 32;         // stage 3 runs while S2 holds at least this many entries (8, 16: 3-5 % slower)
+static_assert(kS2Cap >= kS2Run - 1 + 64 && kS1Cap >= 63 + 256, "a stack must take one more pass of pushes");
 constexpr int kRing = 4;           // rows of the strip kept in LDS (16 bits per count) before they are stored; a power of 2
 
 // What stage 1 needs to know about a cell, packed by cellinfo_kernel so that one scalar load
