@@ -1,7 +1,8 @@
 // K3h: the gamma-Poisson path of PRNB-1 (prnb_device.h) for the samples the streaming
-// kernel (k3_stream.h) flagged in its bit mask -- means above 12 or theta above 16, a few
-// per cent of a typical workload.  Both halves are rejection samplers; run lane-per-sample
-// they would make every wave repeat each half until its unluckiest lane is accepted.  Here
+// kernel (k3_stream.h) flagged in its bit mask -- means above the gene's inversion limit
+// (19, or where theta passes 16), about one per cent of a typical workload.  Both halves
+// are rejection samplers; run lane-per-sample they would make every wave repeat each half
+// until its unluckiest lane is accepted.  Here
 // every ATTEMPT is a stack entry: a gamma pass runs one Marsaglia-Tsang attempt for 64
 // entries of HG (accepted -> the Poisson stack HP, rejected -> back on HG with the next
 // attempt number), a Poisson pass one PTRS attempt for 64 entries of HP.  Attempts are pure

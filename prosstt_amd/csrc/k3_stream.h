@@ -2,27 +2,34 @@
 // on its own strip of the count matrix, with LDS stacks between the stages so that every
 // stage executes with (nearly) all 64 lanes busy.
 //
-// The scalar algorithm (PRNB-1, prnb_device.h) has three very different costs per sample:
+// The scalar algorithm (PRNB-1, prnb_device.h) has very different costs per sample:
 //   ~67 % of the samples of the headline workload are zeros that a 5-instruction bound
 //         settles (exp(-m) <= P(X = 0));
-//   the rest need P(X = 0) exactly (reciprocal + log1p + exp, ~60 VALU), and
-//   ~30 % then walk the pmf for k >= 1 (data-dependent length), ~2 % need gamma-Poisson.
+//   the rest need P(X = 0) exactly (reciprocal + log1p + exp, ~100 VALU), and
+//   ~30 % then walk the pmf for k >= 1 (data-dependent length, half of them end at k <= 2);
+//   ~1 % need gamma-Poisson.
 // Run lane-per-sample, every wave pays for its slowest lane in every one of these.  Here
 //   stage 1 (uniform)   one count-matrix row segment per wave pass: 16-B mean load, one
-//                       Philox call per lane, bound test; the row is stored as zeros (one
-//                       coalesced 1 KiB store); survivors are pushed on stack S1;
-//   stage 2 (64 of S1)  exact P(X = 0); survivors (k >= 1) are pushed on S2 with the pmf
-//                       state at k = 1;
-//   stage 3 (lanes pull from S2)  two pmf steps per lane per pass; a lane that finishes writes
-//                       its count into the LDS row ring and pulls the next entry;
+//                       Philox call per lane, bound test and class test as two compare
+//                       masks; survivors are pushed on stack S1 under exec = mask;
+//   stage 2 (64 of S1)  exact P(X = 0), then the terms k = 1, 2; what is still undecided is
+//                       pushed on S2 with the pmf state at k = 3;
+//   stage 3 (lanes pull from S2)  four pmf steps per lane per pass; a lane that finishes
+//                       writes its count into the LDS row ring and pulls the next entry;
 //   output              the last kRing rows of the strip live in LDS, 16 bits per count; a row
 //                       is stored (one coalesced 1 KiB store per wave) kRing cells after stage 1
 //                       started it.  The few counts that arrive later than that are written
 //                       directly (4-B store, after the row's own store);
-//   samples of the gamma-Poisson path are only FLAGGED here (4 bits per lane and pass);
+//   samples of the gamma-Poisson class are only FLAGGED here (4 bits per lane and pass);
 //   sample_counts_heavy_kernel (k3_heavy.h) draws them afterwards.
 // Results are pure functions of (sample parameters, seed, global cell id, gene), so the
 // order in which the stacks are drained cannot change them.
+//
+// Written against the issue costs measured on gfx950 (tools/microbench4.hip): a scalar
+// instruction costs a wave as much as a vector one, every VALU instruction that touches an
+// SGPR or a lane mask is ~1.7x a plain VOP2, and the kernel is VALU-issue-bound -- hence the
+// scalar per-cell loads, the compare masks written straight to SGPR pairs, and no exec
+// save/restore around the pushes.
 #pragma once
 #include "prnb_device.h"
 
@@ -34,7 +41,7 @@ namespace k3 {
 
 constexpr int kBlock = 256;        // 4 waves
 constexpr int kTileG = 256;        // genes per wave pass: 64 lanes x 4
-constexpr int kStripCells = 128;   // most cells per wave: long strips amortise the drain of stage 3
+constexpr int kStripCells = 128;   // most cells per wave (pos keeps the cell in 7 bits); the host launches 64
 constexpr int kS1Cap = 320;        // < 64 left over + 256 pushed by one pass
 constexpr int kS2Cap = 96;         // < 32 left over + 64 pushed by one stage-2 pass
 constexpr int kS2Run = 32;         // stage 3 runs while S2 holds at least this many entries (8, 16: 3-5 % slower)

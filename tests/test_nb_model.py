@@ -133,6 +133,23 @@ def test_degenerate_parameters():
     assert abs(big.mean() / 3.0e5 - 1) < 0.05 and big.min() >= 0
 
 
+def test_inversion_class_is_a_per_gene_mean_limit():
+    """PRNB-1: inversion iff m <= min(19, (16 - (b-1))/a) (a > 0), 19 (a <= 0), never when
+    b - 1 > 16; m <= 0 or theta <= 0 is the degenerate path.  Both classes follow the same
+    law, so the split must not show in the moments."""
+    means = np.array([[0.5, 18.9, 19.0, 19.1, 6.0, 8.0, 3.0, 3.0, 25.0, 2.0, 2.0, 0.0]], np.float32)
+    alpha = np.array([0.2, 0.2, 0.2, 0.2, 2.0, 2.0, 0.0, 0.0, -0.5, 0.3, np.nan, 0.2])
+    beta = np.array([2.0, 2.0, 2.0, 2.0, 2.0, 2.0, 17.0, 17.5, 30.0, 1.0, 2.0, 2.0])
+    path = nm.nb_params(means, np.zeros(1, np.int32), np.ones(1), alpha, beta)[3][0]
+    #                 m=.5 18.9 19 19.1 | a=2: limit (16-1)/2 = 7.5 | b-1 = 16, 16.5 | a<0: theta = 29-12.5 | b=1 | NaN | m=0
+    assert path.tolist() == [1, 1, 1, 2, 1, 2, 1, 2, 2, 1, 0, 0]
+    for m, a, b in ((7.4, 2.0, 2.0), (7.6, 2.0, 2.0), (18.9, 0.3, 3.0), (19.1, 0.3, 3.0)):
+        x = nm.sample_iid(m, a, b, 400000, seed=5)
+        var = a * m * m + b * m
+        assert abs(x.mean() - m) < 5 * np.sqrt(var / x.size)
+        assert abs(x.var() / var - 1) < 0.03
+
+
 def test_device_mode_walk_law():
     """PRLW-1 (device-mode expression programs) follows simulation.diffusion's law
     (simulation.py:104-121): start = log(1.5 U), vel0 ~ N(0, 0.2^2), eta ~ U(0,1),
