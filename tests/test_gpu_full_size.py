@@ -28,9 +28,9 @@ def test_c3_full_size_properties():
     X = ctx.sample_counts(means, rows, sc, work.alpha, work.beta, seed=20240)
     assert tuple(X.shape) == (N, G) and X.dtype == torch.int32
     checksum = int(X.sum(dtype=torch.int64)), int((X.to(torch.int64) * 2654435761 % 1000003).sum())
-    # row blocks against the scalar model (ragged starts, spanning strip boundaries of 128 cells)
+    # row blocks against the scalar model (ragged starts, spanning the strip boundaries at multiples of 64)
     host_means = means.cpu().numpy()
-    for start, size in ((0, 3), (125, 7), (49990, 10)):
+    for start, size in ((0, 3), (60, 10), (125, 7), (24571, 70), (49990, 10)):
         sl = slice(start, start + size)
         want = nb_model.sample_counts(host_means, rows[sl], sc[sl], work.alpha, work.beta, 20240, cell_offset=start)
         np.testing.assert_array_equal(X[sl].cpu().numpy(), want)
