@@ -84,6 +84,50 @@ def cpu_baseline(work, pt, br, sc, cells):
                 host_cpus=os.cpu_count())
 
 
+_WORKER = """
+import sys, time, numpy as np
+sys.path.insert(0, sys.argv[1])
+from oracle import ref_numpy
+d = np.load(sys.argv[2], allow_pickle=True)
+lo, hi = int(sys.argv[3]), int(sys.argv[4])
+branches = [str(b) for b in d["branches"]]
+ref = ref_numpy.RefTree([[str(a), str(b)] for a, b in d["topology"]], {b: int(t) for b, t in zip(branches, d["times"])},
+                        modules=int(d["modules"]), G=int(d["G"]))
+ref.means = {b: d["means_" + b] for b in branches}
+np.random.seed(1000 + lo)
+for a in range(lo, hi, 250):
+    b = min(a + 250, hi)
+    ref_numpy.draw_counts(ref, d["pt"][a:b], list(d["br"][a:b]), d["sc"][a:b], d["alpha"], d["beta"])
+"""
+
+
+def cpu_baseline_all_cores(work, pt, br, sc, cells, procs):
+    """The same port on `procs` host processes over disjoint cell ranges (variant 2):
+    child processes that never touch the GPU; the wall time of the slowest one counts."""
+    import subprocess
+    import tempfile
+    tree = work.tree
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "plan.npz")
+        means = tree.means
+        np.savez(path, topology=np.array([[str(a), str(b)] for a, b in tree.topology]), branches=np.array([str(b) for b in tree.branches]),
+                 times=np.array([int(tree.time[b]) for b in tree.branches]), modules=tree.modules, G=tree.G,
+                 pt=pt[:cells], br=np.array([str(b) for b in br[:cells]]), sc=sc[:cells], alpha=work.alpha,
+                 beta=work.beta, **{"means_" + str(b): means[b] for b in tree.branches})
+        edges = np.linspace(0, cells, procs + 1).astype(int)
+        t0 = time.perf_counter()
+        kids = [subprocess.Popen([sys.executable, "-c", _WORKER, ROOT, path, str(lo), str(hi)])
+                for lo, hi in zip(edges[:-1], edges[1:]) if hi > lo]
+        rcs = [k.wait() for k in kids]
+        dt = time.perf_counter() - t0
+    if any(rcs):
+        raise RuntimeError("a CPU baseline worker failed: %r" % (rcs,))
+    return dict(value=cells * tree.G / dt, unit="cells*genes/s", cores=len(kids), kind="port",
+                sample="oracle/ref_numpy.draw_counts on %d processes, %d cells x %d genes in all, %.1f s wall "
+                       "(process start-up and plan loading included)" % (len(kids), cells, tree.G, dt),
+                host_cpus=os.cpu_count())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,6 +136,8 @@ def main():
     ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4", "C5"])
     ap.add_argument("--cells-per-gpu", type=int, default=None)
     ap.add_argument("--cpu-cells", type=int, default=10000, help="cells timed by the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-procs", type=int, default=0,
+                    help="also time the CPU port on this many host processes (adds cpu_baseline_all_cores)")
     ap.add_argument("--gather", action="store_true", help="also time the optional row gather to rank 0")
     args = ap.parse_args()
 
@@ -206,6 +252,9 @@ def main():
         if world == 1 and args.cpu_cells > 0:
             line["cpu_baseline"] = cpu_baseline(work, pt, br, sc, min(args.cpu_cells, n_total))
             line["speedup_vs_cpu_1core"] = value / line["cpu_baseline"]["value"]
+        if world == 1 and args.cpu_procs > 1:
+            line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(
+                work, pt, br, sc, min(max(args.cpu_cells, 250 * args.cpu_procs), n_total), args.cpu_procs)
         print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()
