@@ -37,8 +37,8 @@
 #endif
 
 /* ---- sampler constants (part of the PRNB-1 definition) ------------------ */
-#define PRNB_LIGHT_M      19.0f        /* inversion iff m <= min(19, largest m with theta <= 16): P0 >= e^-19 > 2^-28 */
-#define PRNB_LIGHT_THETA  16.0f
+#define PRNB_LIGHT_T      19.0f        /* inversion iff theta <= 16 and t = -log P(X=0) <= 19: P0 * 2^32 >= 24 */
+#define PRNB_LIGHT_THETA  16.0f        /* tail ratio theta/(1+theta) <= 16/17: the walk ends far below the 1/k table's 1023 entries */
 #define PRNB_THETA_MIN    8.6736174e-19f /* 2^-60: below this NB == Poisson in binary32 */
 #define PRNB_THETA_MAX    1.0e18f
 #define PRNB_R_MIN        9.094947e-13f  /* 2^-40: P(X>0) < 2^-32, return 0 */
@@ -179,10 +179,12 @@ __attribute__((constructor)) static void prnb_init(void)
 
 /*
  * Inversion by chop-down in 0.32 fixed point.  pmf recurrence
- *   P(k+1) = P(k) * num_k / (k+1),   num_0 = mp,  num_(k+1) = num_k + q
+ *   P(k+1) = P(k) * num_k / (k+1),   num_k = mp + k*q
  * (NB: mp = m/(1+theta), q = theta/(1+theta);  Poisson: mp = lambda, q = 0).
  * `w` is the 32-bit uniform.  If the pmf falls below 2^-32 before w is used up -- mass lost
- * to rounding, < 1e-6, or the 0 sentinel that ends the 1/k table -- the draw is 0.
+ * to rounding, < 1e-6, or the 0 sentinel that ends the 1/k table -- the draw is the tail
+ * value at which the walk stops, counted in the groups the device walks in (k = 0..2, then
+ * four terms at a time): the last k of the group in which the pmf vanished.
  */
 static inline int32_t chop_down(uint32_t w, float p0, float mp, float q)
 {
@@ -192,11 +194,14 @@ static inline int32_t chop_down(uint32_t w, float p0, float mp, float q)
     for (int k = 0; ; ) {
         uint32_t pf = (uint32_t)(p * 4294967296.0f);
         if (rem < pf) return k;
-        if (pf == 0u) return 0;
+        if (pf == 0u) return ((k + 1) | 3) - 1;
         rem -= pf;
+        p = (p * num) * g_inv_k[k + 1];
         ++k;
-        p = (p * num) * g_inv_k[k];
-        num = num + q;
+        /* numerator mp + k*q: one fma where a group of four terms starts (k = 3, 7, ...), by addition
+         * inside a group -- summing q term after term would let its rounding errors pile up over a
+         * long walk (1e-4 of the pmf after 300 terms) */
+        num = ((k & 3) == 3) ? FMA((float)k, q, mp) : num + q;
     }
 }
 
@@ -287,15 +292,6 @@ static inline float gamma_scaled(float r, float theta, uint32_t c0, uint32_t c1,
     return theta * g;
 }
 
-/* Largest mean of gene (a, b - 1) that is sampled by inversion: theta = a*m + b - 1 stays <= 16
- * (up to one rounding) for every m in (0, limit].  One IEEE division per gene. */
-static inline float light_limit(float a, float bm1)
-{
-    if (!(bm1 <= PRNB_LIGHT_THETA)) return -INFINITY;      /* also NaN */
-    if (!(a > 0.0f)) return PRNB_LIGHT_M;
-    return fminf(PRNB_LIGHT_M, (PRNB_LIGHT_THETA - bm1) / a);
-}
-
 typedef struct { float m, theta, p, r; int32_t path; } prnb_detail;
 
 /* One count.  path: 0 = degenerate (returns 0), 1 = light NB inversion, 2 = gamma-Poisson. */
@@ -314,11 +310,12 @@ static inline int32_t prnb_one(float M, float s, float a, float bm1, uint32_t k0
     float q = theta * inv_u1;
     float r = m * inv_th;
     if (det) { det->p = q; det->r = r; }
-    if (m <= light_limit(a, bm1)) {
+    /* t = -log P(X = 0) = r * log(1 + theta) */
+    float t = m * (det_log1p(theta) * inv_th);
+    if (theta <= PRNB_LIGHT_THETA && t <= PRNB_LIGHT_T) {
         uint32_t w[4];
         if (det) det->path = 1;
         philox4x32_10(c0, c1, gene >> 2, 0u, k0, k1, w);
-        float t = m * (det_log1p(theta) * inv_th);
         return chop_down(w[gene & 3u], det_exp(-t), m * inv_u1, q);
     }
     if (det) det->path = 2;

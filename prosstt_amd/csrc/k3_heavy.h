@@ -1,8 +1,7 @@
-// K3h: the gamma-Poisson path of PRNB-1 (prnb_device.h) for the samples the streaming
-// kernel (k3_stream.h) flagged in its bit mask -- means above the gene's inversion limit
-// (19, or where theta passes 16), about one per cent of a typical workload.  Both halves
-// are rejection samplers; run lane-per-sample they would make every wave repeat each half
-// until its unluckiest lane is accepted.  Here
+// K3h: the gamma-Poisson path of PRNB-2 (prnb_device.h) for the samples the streaming
+// kernel (k3_stream.h) listed -- theta above 16 or -log P(X = 0) above 19, about one in a
+// thousand of a typical workload.  Both halves are rejection samplers; run lane-per-sample
+// they would make every wave repeat each half until its unluckiest lane is accepted.  Here
 // every ATTEMPT is a stack entry: a gamma pass runs one Marsaglia-Tsang attempt for 64
 // entries of HG (accepted -> the Poisson stack HP, rejected -> back on HG with the next
 // attempt number), a Poisson pass one PTRS attempt for 64 entries of HP.  Attempts are pure
@@ -14,7 +13,7 @@
 
 namespace k3 {
 
-constexpr int kHeavyBlock = 1024;   // 16 waves share one LDS ticket counter
+constexpr int kHeavyBlock = 256;
 constexpr int kHCap = 128;     // < 64 left over + 64 pushed (new entries, or re-pushed ones after 64 were popped)
 
 struct HGEntry { int32_t n, g, attempt, row; };   // row = row_of_cell[n], looked up once per ticket
@@ -25,21 +24,21 @@ struct HeavyLds {
     HPEntry hp[kHCap];
 };
 
-// flags: [N][tiles_g][64] bytes written by the streaming kernel; bit 3 - j (j < 4) of byte
-// (n, t, l) flags gene t*256 + 4*l + j of cell n.
+// head/list: what the streaming kernel appended (k3::HeavyEntry).  If an append did not fit
+// (head[1] != 0; more than `cap` such samples), the list is ignored and every sample of the
+// matrix is classified here instead: slow, but any parameter set stays correct.
 __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
-    const uint8_t* __restrict__ flags, int32_t tiles_g, const float* __restrict__ means,
+    const uint32_t* __restrict__ head, const HeavyEntry* __restrict__ list, uint32_t cap,
+    const float* __restrict__ means,
     int32_t G, const int32_t* __restrict__ row_of_cell, const float* __restrict__ scal,
     const float* __restrict__ ga, const float* __restrict__ gbm1, int64_t N, uint32_t k0, uint32_t k1,
     uint64_t cell_offset, const int64_t* __restrict__ cell_index, int32_t* __restrict__ out, int64_t ld)
 {
     __shared__ float inv_k[prnb::kKTab];
     __shared__ HeavyLds lds_all[kHeavyBlock / 64];
-    __shared__ unsigned int next_local;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     HeavyLds& L = lds_all[wv];
     for (int k = tid; k < prnb::kKTab; k += kHeavyBlock) inv_k[k] = (k && k < prnb::kKTab - 1) ? 1.0f / (float)k : 0.0f;
-    if (tid == 0) next_local = 0u;
     __syncthreads();
 
     int hg_top = 0, hp_top = 0;      // wave-uniform
@@ -126,10 +125,9 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
         if (lane < cnt) {
             e = L.hg[hg_top - 1 - lane];
             const prnb::Params P = prnb::make_params(means[(int64_t)e.row * G + e.g], scal[e.n],
-                                                     ga[e.g], gbm1[e.g], 0.0f);
+                                                     ga[e.g], gbm1[e.g]);
             const float r = P.m * P.inv_th;
-            // the flag only says "not the inversion class": m <= 0 or theta <= 0 is a count of 0,
-            // and so is r under 2^-40 (P(X > 0) < 2^-32)
+            // (a flagged sample is valid: m > 0, theta > 0); r under 2^-40 is a count of 0 (P(X > 0) < 2^-32)
             if (P.valid && r >= prnb::kRMin) {
                 const uint64_t cell = cell_id(e.n);
                 const bool boost = r < 1.0f;
@@ -188,64 +186,42 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
         while (hp_top >= 64) poisson_pass();
     };
 
-    // ---- scan the flags in tickets of 512 bytes (one 8-byte load per lane) ----------------------
-    // The number of flagged genes of a cell grows steeply with its library-size factor, so the
-    // work per ticket is very uneven: a static split over waves left the slowest wave at 2x the
-    // mean, and global atomic ticket heads cost more than they saved (~8 grabs/us per address
-    // under 8192 contending waves).  So: blocks get a strided, static share of the tickets
-    // (~1000 each, which averages the unevenness out to a few per cent) and the 16 waves of a
-    // block hand them out among themselves through a counter in LDS.
-    const int32_t bytes_per_cell = tiles_g * 64;          // a multiple of 8
-    const int32_t batches_per_cell = (bytes_per_cell + 511) / 512;
-    const int64_t tickets = N * batches_per_cell;
-    struct Ticket { int64_t n; int32_t byte0, row; unsigned long long bits; };
-    auto fetch = [&](int64_t tk) -> Ticket {
-        Ticket t;
-        t.n = 0; t.byte0 = 0; t.row = 0; t.bits = 0ull;
-        if (tk < tickets) {
-            t.n = tk / batches_per_cell;
-            t.byte0 = (int32_t)(tk - t.n * batches_per_cell) * 512 + lane * 8;   // 8 flag bytes per lane
-            t.row = row_of_cell[t.n];
-            if (t.byte0 < bytes_per_cell)
-                t.bits = *reinterpret_cast<const unsigned long long*>(flags + t.n * bytes_per_cell + t.byte0);
+    // ---- feed the gamma stack: 64 list entries per wave and step ----------------------------------
+    auto feed = [&](bool has, int32_t n, int32_t g) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(has);
+        if (has) {
+            HGEntry e;
+            e.n = n; e.g = g; e.attempt = 0; e.row = row_of_cell[n];
+            L.hg[hg_top + lane_rank(m)] = e;
         }
-        return t;
+        hg_top += __popcll(m);
+        while (hg_top >= 64) gamma_pass();
     };
-    auto expand = [&](const Ticket& t) {
-        unsigned long long bits = t.bits;
-        while (__builtin_amdgcn_ballot_w64(bits != 0ull) != 0ull) {
-            const bool any = bits != 0ull;
-            const int b = any ? __builtin_ctzll(bits) : 0;
-            bits &= bits - 1ull;
-            const int32_t byte = t.byte0 + (b >> 3);       // = tile*64 + lane-in-tile
-            const int32_t gene = byte * 4 + 3 - (b & 7);
-            // (lanes of the last tile beyond G flag whatever NaN or infinite mean they happened to read)
-            const bool has = any && gene < G;
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(has);
-            if (has) {
-                HGEntry e;
-                e.n = (int32_t)t.n; e.g = gene; e.attempt = 0; e.row = t.row;
-                L.hg[hg_top + lane_rank(m)] = e;
+    const int64_t wave0 = ((int64_t)blockIdx.x * (kHeavyBlock / 64) + wv) * 64;
+    const int64_t stride = (int64_t)gridDim.x * kHeavyBlock;
+    if (head[1] == 0u) {
+        const int64_t cnt = head[0] < cap ? head[0] : cap;
+        for (int64_t i0 = wave0; i0 < cnt; i0 += stride) {
+            const bool has = i0 + lane < cnt;
+            HeavyEntry e;
+            e.n = 0; e.g = 0;
+            if (has) e = list[i0 + lane];
+            feed(has, e.n, e.g);
+        }
+    } else {
+        const int64_t total = N * (int64_t)G;
+        for (int64_t i0 = wave0; i0 < total; i0 += stride) {
+            const int64_t i = i0 + lane;
+            bool has = false;
+            int32_t n = 0, g = 0;
+            if (i < total) {
+                n = (int32_t)(i / G);
+                g = (int32_t)(i - (int64_t)n * G);
+                const prnb::Params P = prnb::make_params(means[(int64_t)row_of_cell[n] * G + g], scal[n], ga[g], gbm1[g]);
+                has = P.valid && !P.light;
             }
-            hg_top += __popcll(m);
-            while (hg_top >= 64) gamma_pass();
+            feed(has, n, g);
         }
-    };
-
-    constexpr int kChunk = 4;
-    // tickets of this block: blockIdx.x + gridDim.x * i, i < mine
-    const int64_t mine = (tickets - (int64_t)blockIdx.x + (int64_t)gridDim.x - 1) / (int64_t)gridDim.x;
-    for (;;) {
-        unsigned int got = 0u;
-        if (lane == 0) got = atomicAdd(&next_local, (unsigned int)kChunk);
-        const int64_t i0 = (int64_t)__builtin_amdgcn_readfirstlane(got);
-        if (i0 >= mine) break;
-        Ticket t[kChunk];                           // all loads of the chunk are in flight together
-#pragma unroll
-        for (int c = 0; c < kChunk; ++c)
-            t[c] = fetch(i0 + c < mine ? (int64_t)blockIdx.x + (int64_t)gridDim.x * (i0 + c) : tickets);
-#pragma unroll
-        for (int c = 0; c < kChunk; ++c) expand(t[c]);
     }
     while (hg_top > 0) gamma_pass();
     while (hp_top > 0) poisson_pass();

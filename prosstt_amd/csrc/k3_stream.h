@@ -2,26 +2,28 @@
 // on its own strip of the count matrix, with LDS stacks between the stages so that every
 // stage executes with (nearly) all 64 lanes busy.
 //
-// The scalar algorithm (PRNB-1, prnb_device.h) has very different costs per sample:
-//   ~67 % of the samples of the headline workload are zeros that a 5-instruction bound
-//         settles (exp(-m) <= P(X = 0));
+// The scalar algorithm (PRNB-2, prnb_device.h) has very different costs per sample:
+//   ~65 % of the samples of the headline workload are zeros that a 6-instruction bound
+//         settles (exp(-m * phi_gene) <= P(X = 0), prnb::zero_test_factor);
 //   the rest need P(X = 0) exactly (reciprocal + log1p + exp, ~100 VALU), and
-//   ~30 % then walk the pmf for k >= 1 (data-dependent length, half of them end at k <= 2);
-//   ~1 % need gamma-Poisson.
+//   ~33 % then walk the pmf for k >= 1 (data-dependent length, half of them end at k <= 2);
+//   ~0.1 % need gamma-Poisson.
 // Run lane-per-sample, every wave pays for its slowest lane in every one of these.  Here
 //   stage 1 (uniform)   one count-matrix row segment per wave pass: 16-B mean load, one
-//                       Philox call per lane, bound test and class test as two compare
-//                       masks; survivors are pushed on stack S1 under exec = mask;
-//   stage 2 (64 of S1)  exact P(X = 0), then the terms k = 1, 2; what is still undecided is
-//                       pushed on S2 with the pmf state at k = 3;
+//                       Philox call per lane, the bound test as a compare mask; survivors are
+//                       pushed on stack S1 under exec = mask;
+//   stage 2 (64 of S1)  exact P(X = 0) and the class test, then the terms k = 1, 2; what is
+//                       still undecided is pushed on S2 with the pmf state at k = 3;
 //   stage 3 (lanes pull from S2)  four pmf steps per lane per pass; a lane that finishes
 //                       writes its count into the LDS row ring and pulls the next entry;
 //   output              the last kRing rows of the strip live in LDS, 16 bits per count; a row
 //                       is stored (one coalesced 1 KiB store per wave) kRing cells after stage 1
 //                       started it.  The few counts that arrive later than that are written
 //                       directly (4-B store, after the row's own store);
-//   samples of the gamma-Poisson class are only FLAGGED here (4 bits per lane and pass);
-//   sample_counts_heavy_kernel (k3_heavy.h) draws them afterwards.
+//   samples of the gamma-Poisson class are only LISTED here (a lane of stage 2 that meets one
+//   keeps it in a register; when a lane meets its second, and at the end of the strip, the wave
+//   appends what its lanes hold to a global list); sample_counts_heavy_kernel (k3_heavy.h)
+//   draws them afterwards.
 // Results are pure functions of (sample parameters, seed, global cell id, gene), so the
 // order in which the stacks are drained cannot change them.
 //
@@ -32,10 +34,6 @@
 // save/restore around the pushes.
 #pragma once
 #include "prnb_device.h"
-
-#ifndef K3_ABLATE
-#define K3_ABLATE 0   // timing-only experiments (tools/ablate.sh); 0 in every shipped build
-#endif
 
 namespace k3 {
 
@@ -57,7 +55,7 @@ struct CellInfo { uint64_t row_bytes; float s; uint32_t cell_lo, cell_hi, pos_ba
 static_assert(sizeof(CellInfo) == 32, "one s_load_dwordx8");
 
 struct S1Entry { float m, theta; uint32_t w, pos; };   // theta = a*m + b - 1, not yet clamped
-struct S2Entry { float ps, num, q; uint32_t rem; };   // pmf (x 2^32) and numerator at k = 3
+struct S2Entry { float ps, mp, q; uint32_t rem; };    // pmf (x 2^32) at k = 3; the numerator of step k is mp + k*q
 
 struct WaveLds {
     S1Entry s1[kS1Cap];
@@ -65,6 +63,10 @@ struct WaveLds {
     uint32_t s2pos[kS2Cap];
     uint16_t ring[kRing * 256];    // [row slot][gene-in-tile]: a walk ends below the 1/k table's 1023 entries
 };
+
+// The list of gamma-Poisson samples: head[0] = entries appended (may exceed the capacity),
+// head[1] != 0 once an append did not fit -- K3h then classifies every sample itself.
+struct HeavyEntry { int32_t n, g; };
 
 // rank of this lane among the lanes whose bit is set in `mask`
 __device__ __forceinline__ int lane_rank(unsigned long long mask)
@@ -76,18 +78,21 @@ __device__ __forceinline__ int lane_rank(unsigned long long mask)
 template <bool VEC>
 __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
     const float* __restrict__ means, int32_t G, const CellInfo* __restrict__ cellinfo,
-    const float* __restrict__ ga, const float* __restrict__ gbm1, const float* __restrict__ glim,
+    const float* __restrict__ ga, const float* __restrict__ gbm1, const float* __restrict__ gphi,
     int64_t N, uint32_t k0, uint32_t k1, int32_t* __restrict__ out, int64_t ld, int32_t strips,
-    int32_t strip_cells, uint8_t* __restrict__ heavy_flags, int32_t tiles_g)
+    int32_t strip_cells, uint32_t* __restrict__ heavy_head, HeavyEntry* __restrict__ heavy_list,
+    uint32_t heavy_cap)
 {
-    __shared__ __attribute__((aligned(16))) float inv_k[prnb::kKTab + 8];   // 0 from the sentinel (k = KTAB-1) on
+    // 1/k for k = -4 .. KTAB+7: 0 below k = 1 (an idle stage-3 lane reads there) and from the sentinel (k = KTAB-1) on
+    __shared__ __attribute__((aligned(16))) float inv_k_store[4 + prnb::kKTab + 8];
+    float* const inv_k = inv_k_store + 4;
     __shared__ WaveLds lds_all[kBlock / 64];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     WaveLds& L = lds_all[wv];
 
-    for (int k = tid; k < prnb::kKTab + 8; k += kBlock) inv_k[k] = (k && k < prnb::kKTab - 1) ? 1.0f / (float)k : 0.0f;
+    for (int k = tid - 4; k < prnb::kKTab + 8; k += kBlock) inv_k[k] = (k > 0 && k < prnb::kKTab - 1) ? 1.0f / (float)k : 0.0f;
     __syncthreads();
 
     // block -> (gene tile, group of 4 strips); adjacent blocks share the gene tile (L2 reuse of
@@ -102,21 +107,23 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
     const int cells = (int)((N - n0 < strip_cells) ? (N - n0) : strip_cells);
 
     // lanes beyond G read some valid mean (see load_seg); a = b - 1 = 0 makes theta = 0, which
-    // stage 2 drops, and the huge limit keeps them out of the gamma-Poisson flags
-    float a[4], bm1[4], lim[4];
+    // stage 2 drops before the class test
+    float a[4], bm1[4], phi[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const bool in = g0 + j < G;
         a[j] = in ? ga[g0 + j] : 0.0f;
         bm1[j] = in ? gbm1[g0 + j] : 0.0f;
-        lim[j] = in ? glim[g0 + j] : 3.0e38f;
+        phi[j] = in ? gphi[g0 + j] : 1.0f;
     }
 
     int s1_top = 0, s2_top = 0;                      // wave-uniform
+    constexpr uint32_t kNoHeavy = 0xffffffffu;
+    uint32_t hpend = kNoHeavy;                       // pos of the gamma-Poisson sample this lane holds for the next append
     // stage-3 lane state
-    float ps = 0.0f, num = 0.0f, q = 0.0f;
+    float ps = 0.0f, mp = 0.0f, q = 0.0f, kf = 0.0f;   // kf = (float)k of a busy lane
     uint32_t rem = 0u, pos = 0u;
-    constexpr int kIdle = -1;
+    constexpr int kIdle = -5;        // k + 1 = 0 mod 4 (the aligned read of four reciprocals), k + 3 < 0 (no result)
     int k = kIdle;
     float4 inv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // 1/(k+1) .. 1/(k+4): read one pass ahead
 
@@ -135,7 +142,7 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
         const int32_t v[4] = {(int32_t)(packed.x & 0xffffu), (int32_t)(packed.x >> 16),
                               (int32_t)(packed.y & 0xffffu), (int32_t)(packed.y >> 16)};
         int32_t* dst = row_ptr + lane * 4;
-        if (g0 < G && (K3_ABLATE != 5 || v[0] == 12345)) {
+        if (g0 < G) {
             if (VEC) {
                 *reinterpret_cast<int4*>(dst) = make_int4(v[0], v[1], v[2], v[3]);
             } else {
@@ -147,36 +154,40 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
         flushed_pos = (cl << 8) | 255;
     };
 
-    // a finished count goes into the row ring while its row is still there, else (rare) straight
-    // to memory, after the row's own store
+    // a finished count (> 0) goes into the row ring while its row is still there, else (rare)
+    // straight to memory, after the row's own store: a wave's stores to one address stay in order
     auto deliver = [&](uint32_t p, int32_t res) {
         const bool late = (int32_t)p <= flushed_pos;
-        if ((res != 0) & !late) L.ring[p & (kRing * 256 - 1)] = (uint16_t)res;   // slot = cell % kRing, gene-in-tile
-        if ((res != 0) & late) strip_out[(p >> 8) * ld32 + (p & 255u)] = res;
+        if ((res > 0) & !late) L.ring[p & (kRing * 256 - 1)] = (uint16_t)res;   // slot = cell % kRing, gene-in-tile
+        if ((res > 0) & late) strip_out[(p >> 8) * ld32 + (p & 255u)] = res;
     };
 
     // ---- stage 3: four pmf steps for every busy lane; idle lanes pull from S2 ------------------
-    // A lane is idle iff k == kIdle, and an idle lane keeps ps = 0: its steps end without a hit,
-    // so the arithmetic below never asks which lanes are busy.  The pmf falls once it is under
-    // 2^-32 (it can only get there beyond the mode), so "the first hit, else 0 when the last
-    // of the four terms is 0" is the sequential walk's answer.  A walk enters at k = 3 and
-    // advances by 4: the four reciprocals 1/(k+1)..1/(k+4) are one aligned 16-byte LDS read.
+    // A lane is idle iff k == kIdle, and an idle lane keeps ps = 0: its steps end without a hit
+    // and its "result" k + 3 is negative, so the arithmetic below never asks which lanes are busy.
+    // The pmf falls once it is under 2^-32 (it can only get there beyond the mode), so "the first
+    // hit, else the group's last k when the last of the four terms is 0" is the sequential walk's
+    // answer (prnb::chop_down).  A walk enters at k = 3 and advances by 4: the four reciprocals
+    // 1/(k+1)..1/(k+4) are one aligned 16-byte LDS read.
     auto stage3_pass = [&]() {
         unsigned long long idle_m;
-        asm("v_cmp_eq_u32 %0, -1, %1" : "=s"(idle_m) : "v"(k));
+        asm("v_cmp_eq_u32 %0, -5, %1" : "=s"(idle_m) : "v"(k));
+        static_assert(kIdle == -5, "the inline constant above");
         if (idle_m != 0ull && s2_top > 0) {
             const int rank = lane_rank(idle_m);
             if (k == kIdle && rank < s2_top) {
                 const int idx = s2_top - 1 - rank;
                 const S2Entry e = L.s2[idx];
-                ps = e.ps; num = e.num; q = e.q; rem = e.rem;
+                ps = e.ps; mp = e.mp; q = e.q; rem = e.rem;
                 pos = L.s2pos[idx];
                 k = 3;
+                kf = 3.0f;
                 inv = *reinterpret_cast<const float4*>(&inv_k[4]);
             }
             const int left = s2_top - __popcll(idle_m);
             s2_top = left > 0 ? left : 0;
         }
+        const float num = PRNB_FMA(kf, q, mp);          // the group's first numerator by fma, the others by addition
         const uint32_t pf0 = (uint32_t)ps;
         const bool hit0 = rem < pf0;
         const uint32_t rem1 = rem - pf0;
@@ -196,27 +207,49 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
         const bool hit3 = rem3 < pf3;
         const bool any = hit0 | hit1 | hit2 | hit3;
         const bool done = any | (pf3 == 0u);
-        const int32_t res = any ? k + (hit0 ? 0 : (hit1 ? 1 : (hit2 ? 2 : 3))) : 0;
+        const int32_t res = done ? k + (hit0 ? 0 : (hit1 ? 1 : (hit2 ? 2 : 3))) : 0;
         deliver(pos, res);
         rem = rem3 - pf3;
         ps = done ? 0.0f : (ps3 * num3) * inv.w;
-        num = num3 + q;
+        kf = kf + 4.0f;
         k = done ? kIdle : k + 4;
         inv = *reinterpret_cast<const float4*>(__builtin_assume_aligned(&inv_k[k + 1], 16));   // k + 1 = 0 mod 4
     };
 
-    // ---- stage 2: exact P(X = 0), then the terms k = 1, 2, for up to 64 entries of S1 ----------
+    // ---- stage 2: exact P(X = 0), class test, then the terms k = 1, 2, for up to 64 entries of S1
+    // append the gamma-Poisson samples the lanes hold to the global list: one returning atomic
+    // per wave (about ten entries each time on the headline workload: the first lane to meet its
+    // second sample triggers it)
+    auto flush_heavy = [&]() {
+        const unsigned long long mp = __builtin_amdgcn_ballot_w64(hpend != kNoHeavy);
+        const uint32_t cnt = (uint32_t)__popcll(mp);
+        uint32_t base = 0u;
+        if (lane == 0) base = atomicAdd(heavy_head, cnt);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (hpend != kNoHeavy) {
+            const uint32_t slot = base + (uint32_t)lane_rank(mp);
+            HeavyEntry e;
+            e.n = (int32_t)(n0 + (hpend >> 8));
+            e.g = gbase + (int32_t)(hpend & 255u);
+            if (slot < heavy_cap) heavy_list[slot] = e;
+        }
+        if (lane == 0 && base + cnt > heavy_cap) heavy_head[1] = 1u;
+        hpend = kNoHeavy;
+    };
     auto stage2_pass = [&]() {
         const int cnt = s1_top < 64 ? s1_top : 64;
         const bool mine = lane < cnt;
-        bool push = false;
+        bool push = false, heavy = false;
         int32_t res = 0;
         S2Entry e2;
         uint32_t p2 = 0u;
-        e2.ps = 0.0f; e2.num = 0.0f; e2.q = 0.0f; e2.rem = 0u;
+        e2.ps = 0.0f; e2.mp = 0.0f; e2.q = 0.0f; e2.rem = 0u;
         if (mine) {
             const S1Entry e = L.s1[s1_top - 1 - lane];
-            // (the clamp to kThetaMax of the general path cannot bind: theta <= 16 in this class)
+            p2 = e.pos;
+            // (m <= 0 or theta <= 0: the count is 0 by definition; stage 1 does not test that)
+            const bool valid = (e.m > 0.0f) & (e.theta > 0.0f);
+            // prnb::make_params; the clamp to kThetaMax only matters to the gamma-Poisson class
             const float theta = __builtin_fmaxf(e.theta, prnb::kThetaMin);
             const float u1 = 1.0f + theta;
             const float d = prnb::det_rcp(theta * u1);
@@ -224,12 +257,12 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
             const float qq = theta * inv_u1;
             const float mpp = e.m * inv_u1;
             const float t = e.m * (prnb::det_log1p(theta) * inv_th);
-            const float p0 = __builtin_fminf(prnb::det_exp_small(-t), 0.99999994f);   // t <= 19
+            const bool light = (theta <= prnb::kLightTheta) & (t <= prnb::kLightT);
+            heavy = valid & !light;                      // gamma-Poisson class: listed for K3h (rare)
+            const float p0 = __builtin_fminf(prnb::det_exp_small(-t), 0.99999994f);   // t <= 19 where it is used
             const float ps0 = p0 * 4294967296.0f;       // pmf scaled by 2^32 (exact scaling)
             const uint32_t pf0 = (uint32_t)ps0;
-            // (m <= 0 or theta <= 0: the count is 0 by definition; stage 1 does not test that)
-            if ((e.w >= pf0) & (e.m > 0.0f) & (e.theta > 0.0f)) {   // k >= 1
-                p2 = e.pos;
+            if ((e.w >= pf0) & valid & light) {          // k >= 1
                 const uint32_t rem1 = e.w - pf0;
                 const float ps1 = ps0 * mpp;              // (* 1/1)
                 const float num1 = mpp + qq;
@@ -240,11 +273,12 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
                 const float num2 = num1 + qq;
                 const uint32_t pf2 = (uint32_t)ps2;
                 const bool hit2 = rem2 < pf2;
-                res = hit1 ? 1 : (hit2 ? 2 : 0);
-                push = !(hit1 | hit2) & (pf2 != 0u);
+                // no hit and the pmf gone: the group's last k (prnb::chop_down)
+                res = hit1 ? 1 : ((hit2 | (pf2 == 0u)) ? 2 : 0);
+                push = (res == 0);
                 e2.rem = rem2 - pf2;
                 e2.ps = (ps2 * num2) * 0.33333334f;       // pmf at k = 3 (the 1/k table's 1/3)
-                e2.num = num2 + qq;                       // numerator of the step 3 -> 4
+                e2.mp = mpp;
                 e2.q = qq;
             }
             deliver(p2, res);
@@ -257,6 +291,11 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
             L.s2pos[slot] = p2;
         }
         s2_top += __popcll(m2);
+        const unsigned long long mh = __builtin_amdgcn_ballot_w64(heavy);
+        if (mh != 0ull) {
+            if (__builtin_amdgcn_ballot_w64(heavy & (hpend != kNoHeavy)) != 0ull) flush_heavy();
+            if (heavy) hpend = p2;
+        }
     };
 
     // ---- stage 1 over the strip ----------------------------------------------------------------
@@ -266,8 +305,6 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
     static_assert(kStripCells == 128, "pos keeps the cell in 7 bits above the gene's 8");
     const CellInfo* cinfo = cellinfo + n0;                   // wave-uniform running pointers
     int32_t* flush_ptr = strip_out;                          // row cl - kRing of the strip
-    uint8_t* flag_ptr = heavy_flags + ((n0 * tiles_g + tile_g) << 6);
-    const int64_t flag_step = (int64_t)tiles_g << 6;
     const uint32_t lane4 = (uint32_t)lane * 4u;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const uint32_t s1_lds = (uint32_t)(uintptr_t)&L.s1[0];     // LDS byte address of the stack
@@ -309,61 +346,38 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
         const uint32_t c_lo_next = cinfo[1].cell_lo, c_hi_next = cinfo[1].cell_hi, posbase_next = cinfo[1].pos_base;
         ++cinfo;
         __builtin_amdgcn_sched_barrier(0);
-#if K3_ABLATE == 3     // no Philox: a 2-instruction hash stands in
-        prnb::Words W;
-        W.w[0] = (c_lo * 2654435761u) ^ ((uint32_t)g0 * 40503u); W.w[1] = W.w[0] * 3u + k0;
-        W.w[2] = W.w[1] ^ 0x9E3779B9u; W.w[3] = W.w[2] + W.w[0];
-#else
         const prnb::Words W = prnb::philox4x32_10<2>(c_lo, c_hi, (uint32_t)g0 >> 2, 0u, k0, k1);
-#endif
-        uint32_t hflag = 0u;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float m = M[j] * s;
-            // P(X=0) = exp(-m*log1p(theta)/theta) >= exp(-m) >= 1 - m + m^2/2 - m^3/6 for theta > 0.
-            // The polynomial is evaluated times 2^32 with 1e-5 taken off the constant term: far
-            // more than every rounding of the exact evaluation, so a sample settled here is one
-            // the exact path would also call 0 (and a sample with theta <= 0 is 0 by definition).
-            const float bound32 = PRNB_FMA(PRNB_FMA(PRNB_FMA(-715827882.7f, m, 2147483648.0f), m, -4294967296.0f),
-                                           m, 4294924346.0f);
-            // Compare masks straight into SGPR pairs (every lane is active here, so they are the
-            // ballots), the push as one LDS store under exec = mask: no branch, no exec save.
-            unsigned long long hv_m, nlt_m, carry;
-            asm("v_cmp_nle_f32 %0, %1, %2" : "=s"(hv_m) : "v"(m), "v"(lim[j]));         // not the inversion class (or NaN)
-            asm("v_cmp_nlt_f32 %0, %1, %2" : "=s"(nlt_m) : "v"((float)W.w[j]), "v"(bound32));   // not settled as 0
-            const unsigned long long push_m = nlt_m & ~hv_m;
+            // P(X=0) = exp(-m*log1p(theta)/theta) >= exp(-x) >= 1 - x + x^2/2 - x^3/6, x = m * phi
+            // (prnb::zero_test_factor).  The polynomial is evaluated times 2^32 with 1e-5 taken off
+            // the constant term: far more than every rounding of the exact evaluation, so a sample
+            // settled here is one the exact path would also call 0 (and a sample with theta <= 0 is
+            // 0 by definition); it is negative from x = 1.6 on, which keeps every sample of the
+            // gamma-Poisson class out.
+            const float x = m * phi[j];
+            const float bound32 = PRNB_FMA(PRNB_FMA(PRNB_FMA(-715827882.7f, x, 2147483648.0f), x, -4294967296.0f),
+                                           x, 4294924346.0f);
+            // The compare mask goes straight into an SGPR pair (every lane is active here, so it is
+            // the ballot), the push is one LDS store under exec = mask: no branch, no exec save.
+            // (The stage-1 loop must stay wave-uniform: the asm below ends with exec = -1.)
+            unsigned long long push_m;
+            asm("v_cmp_nlt_f32 %0, %1, %2" : "=s"(push_m) : "v"((float)W.w[j]), "v"(bound32));   // not settled as 0 (or NaN)
             u32x4 e;                                           // S1Entry {m, theta, w, pos}
             e.x = __float_as_uint(m);
             e.y = __float_as_uint(PRNB_FMA(a[j], m, bm1[j]));
             e.z = W.w[j];
             e.w = posbase | (lane4 + j);
             const uint32_t slot = (s1_lds + ((uint32_t)s1_top << 4)) + ((uint32_t)lane_rank(push_m) << 4);
-#if K3_ABLATE != 6
             asm volatile("s_mov_b64 exec, %0\n\tds_write_b128 %1, %2\n\ts_mov_b64 exec, -1"
                          :: "s"(push_m), "v"(slot), "v"(e) : "memory");
-#else
-            asm volatile("" :: "s"(push_m), "v"(slot), "v"(e));
-#endif
             s1_top += __popcll(push_m);
-            // gamma-Poisson samples are only flagged: hflag = 2 * hflag + bit, i.e. gene j -> bit 3 - j
-            asm("v_addc_co_u32 %0, %1, %0, %0, %2" : "+v"(hflag), "=s"(carry) : "s"(hv_m));
         }
-#if K3_ABLATE != 7
-        *(flag_ptr + lane) = (uint8_t)hflag;                   // one byte per (cell, tile, lane)
-#else
-        asm volatile("" :: "v"(hflag));
-#endif
-        flag_ptr += flag_step;
-#if K3_ABLATE == 2 || K3_ABLATE >= 5      // stage 1 only (5: no row store, 6: no S1 push, 7: no flag store)
-        s1_top = 0;
-#elif K3_ABLATE == 1    // no stage 3
-        while (s1_top >= 64) { stage2_pass(); s2_top = 0; }
-#else
         while (s1_top >= 64) {
             stage2_pass();
             while (s2_top >= kS2Run) stage3_pass();
         }
-#endif
         cur = nxt;
         nxt = nn;
         row2 = row3;
@@ -380,6 +394,7 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
     }
     while (s2_top > 0 || __builtin_amdgcn_ballot_w64(k != kIdle) != 0ull) stage3_pass();
     for (int cl = (cells > kRing ? cells - kRing : 0); cl < cells; ++cl) flush_row(cl, strip_out + (int64_t)cl * ld);
+    if (__builtin_amdgcn_ballot_w64(hpend != kNoHeavy) != 0ull) flush_heavy();
 }
 
 }  // namespace k3

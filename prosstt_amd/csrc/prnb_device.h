@@ -1,4 +1,4 @@
-// PRNB-1 count sampler, device side (gfx950).  DESIGN.md section 4 defines it; this is
+// PRNB-2 count sampler, device side (gfx950).  DESIGN.md section 4 defines it; this is
 // the product implementation.  Replaces, per (cell, gene):
 //   count_model.get_pr_umi                 /root/reference/prosstt/count_model.py:131-161
 //   scipy.stats.nbinom(n=r,p=1-p).rvs()    /root/reference/prosstt/simulation.py:647-648
@@ -15,8 +15,8 @@
 
 namespace prnb {
 
-constexpr float kLightM = 19.0f;       // inversion iff m <= min(19, largest m with theta <= 16): P0 >= e^-19 > 2^-28
-constexpr float kLightTheta = 16.0f;
+constexpr float kLightT = 19.0f;       // inversion iff theta <= 16 and t = -log P(X=0) <= 19: P0 * 2^32 >= 24
+constexpr float kLightTheta = 16.0f;   // tail ratio <= 16/17: the walk ends far below the 1/k table's 1023 entries
 constexpr float kThetaMin = 8.6736174e-19f;  // 2^-60
 constexpr float kThetaMax = 1.0e18f;
 constexpr float kRMin = 9.094947e-13f;       // 2^-40
@@ -159,7 +159,9 @@ __device__ __forceinline__ float unif(uint32_t w) { return ((float)w + 0.5f) * 2
 __device__ __forceinline__ float det_sqrt(float x) { return __builtin_sqrtf(x); }  // IEEE (see Makefile)
 
 // Inversion by chop-down in 0.32 fixed point; inv_k = LDS table of 1/k (0 sentinel at the end).
-// P(k+1) = P(k) * num_k / (k+1), num_0 = mp, num_(k+1) = num_k + q; pmf below 2^-32 -> 0.
+// P(k+1) = P(k) * num_k / (k+1), num_k = mp + k*q.  When the pmf falls below
+// 2^-32 before w is used up (mass lost to rounding, < 1e-6) the draw is the last k of the group
+// of terms (k = 0..2, then four at a time: the streaming kernel's passes) in which it vanished.
 __device__ __forceinline__ int32_t chop_down(uint32_t w, float p0, float mp, float q,
                                              const float* inv_k)
 {
@@ -170,11 +172,13 @@ __device__ __forceinline__ int32_t chop_down(uint32_t w, float p0, float mp, flo
     for (;;) {
         const uint32_t pf = (uint32_t)(p * 4294967296.0f);
         if (rem < pf) return k;
-        if (pf == 0u) return 0;
+        if (pf == 0u) return ((k + 1) | 3) - 1;
         rem -= pf;
+        p = (p * num) * inv_k[k + 1];
         ++k;
-        p = (p * num) * inv_k[k];
-        num = num + q;
+        // numerator mp + k*q: one fma where a group of four terms starts (k = 3, 7, ...), by
+        // addition inside a group (the rounding errors of a running sum would pile up over a long walk)
+        num = ((k & 3) == 3) ? PRNB_FMA((float)k, q, mp) : num + q;
     }
 }
 
@@ -281,20 +285,28 @@ __device__ __forceinline__ float gamma_scaled(float r, float theta, uint32_t c0,
 // Per-sample parameters shared by the light and heavy paths.
 struct Params {
     float m, theta, inv_th, inv_u1;
+    float t;      // -log P(X = 0) = m * log1p(theta) / theta
     bool valid;   // m > 0 and theta > 0
-    bool light;
+    bool light;   // inversion class: theta <= 16 and t <= 19
 };
 
-// Largest mean of gene (a, b - 1) that is sampled by inversion: theta = a*m + b - 1 stays <= 16
-// (up to one rounding) for every m in (0, limit].  One IEEE division per gene, done once.
-__device__ __forceinline__ float light_limit(float a, float bm1)
+// Per-gene factor of the streaming kernel's zero test.  With theta = a*m + b - 1 >= b - 1 =: c
+// (a >= 0) and f(theta) = log1p(theta)/theta decreasing, -log P(X = 0) = m*f(theta) <= m*f(c):
+// x = m * phi, phi = f(c), bounds it from above; phi = 1 (f <= 1 for every theta > 0) when that
+// argument does not apply.  A sample of the gamma-Poisson class must never pass the zero test
+// (it draws from other counter domains): t > 19 implies x > 18.9, where the test's cubic is
+// negative; theta > 16 implies the same once the gene's theta stays under 16 for every x <= 1.7 --
+// a gene for which it does not gets a huge phi, so that all of its samples take the exact path.
+__device__ __forceinline__ float zero_test_factor(float a, float bm1)
 {
-    if (!(bm1 <= kLightTheta)) return -__builtin_inff();      // also NaN
-    if (!(a > 0.0f)) return kLightM;
-    return __builtin_fminf(kLightM, (kLightTheta - bm1) / a);
+    float phi = 1.0f;
+    if (a >= 0.0f && bm1 >= 2.44140625e-4f) phi = det_log1p(bm1) * det_rcp(bm1);
+    const float th_edge = PRNB_FMA(a, 1.7f * det_rcp(phi), bm1);      // theta at x = 1.7
+    if (!(__builtin_fmaxf(th_edge, bm1) <= 15.9f)) phi = 3.0e38f;      // also NaN
+    return phi;
 }
 
-__device__ __forceinline__ Params make_params(float M, float s, float a, float bm1, float lim)
+__device__ __forceinline__ Params make_params(float M, float s, float a, float bm1)
 {
     Params P;
     P.m = M * s;
@@ -306,7 +318,8 @@ __device__ __forceinline__ Params make_params(float M, float s, float a, float b
     P.theta = theta;
     P.inv_th = d * u1;
     P.inv_u1 = d * theta;
-    P.light = P.m <= lim;
+    P.t = P.m * (det_log1p(theta) * P.inv_th);
+    P.light = (theta <= kLightTheta) && (P.t <= kLightT);
     return P;
 }
 
@@ -314,8 +327,7 @@ __device__ __forceinline__ Params make_params(float M, float s, float a, float b
 __device__ __forceinline__ int32_t light_draw(const Params& P, uint32_t w, const float* inv_k)
 {
     const float q = P.theta * P.inv_u1;
-    const float t = P.m * (det_log1p(P.theta) * P.inv_th);
-    return chop_down(w, det_exp(-t), P.m * P.inv_u1, q, inv_k);
+    return chop_down(w, det_exp(-P.t), P.m * P.inv_u1, q, inv_k);
 }
 
 // Heavy path: Poisson(theta * Gamma(r)).

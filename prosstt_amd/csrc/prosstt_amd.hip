@@ -118,7 +118,7 @@ __global__ void prep_params_kernel(const double* __restrict__ scaling, int64_t N
                                    const double* __restrict__ alpha,
                                    const double* __restrict__ beta, int32_t G,
                                    float* __restrict__ scal_f, float* __restrict__ a_f,
-                                   float* __restrict__ bm1_f, float* __restrict__ lim_f)
+                                   float* __restrict__ bm1_f, float* __restrict__ phi_f)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < N) scal_f[i] = (float)scaling[i];
@@ -127,7 +127,7 @@ __global__ void prep_params_kernel(const double* __restrict__ scaling, int64_t N
         const float bm1 = (float)(beta[i] - 1.0);   // binary64 subtraction: beta = 1 + 1e-8 must survive
         a_f[i] = a;
         bm1_f[i] = bm1;
-        lim_f[i] = prnb::light_limit(a, bm1);
+        phi_f[i] = prnb::zero_test_factor(a, bm1);
     }
 }
 
@@ -183,13 +183,12 @@ __global__ __launch_bounds__(kBlock) void sample_counts_kernel(
     if (tid == 0) q_count = 0;
     __syncthreads();
 
-    float a[4], bm1[4], lim[4];
+    float a[4], bm1[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const bool in = g0 + j < G;
         a[j] = in ? ga[g0 + j] : 0.0f;
         bm1[j] = in ? gbm1[g0 + j] : 0.0f;
-        lim[j] = prnb::light_limit(a[j], bm1[j]);
     }
 
     bool bad = false;
@@ -215,7 +214,7 @@ __global__ __launch_bounds__(kBlock) void sample_counts_kernel(
         for (int j = 0; j < 4; ++j) {
             int32_t res = 0;
             if (g0 + j < G) {
-                const prnb::Params P = prnb::make_params(M[j], s, a[j], bm1[j], lim[j]);
+                const prnb::Params P = prnb::make_params(M[j], s, a[j], bm1[j]);
                 if (!P.valid) {
                     bad = bad || !(P.m > 0.0f) || (__builtin_fmaf(a[j], P.m, bm1[j]) < 0.0f);
                 } else if (P.light) {
@@ -238,8 +237,7 @@ __global__ __launch_bounds__(kBlock) void sample_counts_kernel(
         const int32_t g = tile_g * kTileG + gl;
         const uint64_t cell = cell_index ? (uint64_t)cell_index[n] : cell_offset + (uint64_t)n;
         const prnb::Params P =
-            prnb::make_params(means[(int64_t)row_of_cell[n] * G + g], scal[n], ga[g], gbm1[g],
-                          prnb::light_limit(ga[g], gbm1[g]));
+            prnb::make_params(means[(int64_t)row_of_cell[n] * G + g], scal[n], ga[g], gbm1[g]);
         tile[cl][gl] = prnb::heavy_draw(P, (uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)g, k0,
                                         k1, inv_k);
     }
@@ -274,8 +272,7 @@ __global__ void nb_params_kernel(const float* __restrict__ means, int32_t G,
     const int64_t n = i / G;
     const int32_t g = (int32_t)(i - n * G);
     const prnb::Params P =
-        prnb::make_params(means[(int64_t)row_of_cell[n] * G + g], scal[n], ga[g], gbm1[g],
-                          prnb::light_limit(ga[g], gbm1[g]));
+        prnb::make_params(means[(int64_t)row_of_cell[n] * G + g], scal[n], ga[g], gbm1[g]);
     if (mu) mu[i] = P.m;
     if (p) p[i] = P.valid ? P.theta * P.inv_u1 : 0.0f;
     if (r) r[i] = P.valid ? P.m * P.inv_th : 0.0f;
@@ -561,7 +558,7 @@ PA_EXPORT int prosstt_amd_last_kernel_ms(prosstt_amd_ctx* c, float* ms)
 // converts the binary64 per-cell / per-gene parameters into the workspace.
 struct SamplerArgs {
     const float* means; const int32_t* row_of_cell;
-    float *scal, *ga, *gbm1, *glim;
+    float *scal, *ga, *gbm1, *gphi;
     void* extra;     // `extra_bytes` of workspace behind the parameter vectors (256-B aligned)
 };
 
@@ -605,11 +602,11 @@ static int sampler_setup(prosstt_amd_ctx* c, Staging& st, const float* means, in
     A->scal = (float*)c->ws;
     A->ga = A->scal + n_pad;
     A->gbm1 = A->ga + G;
-    A->glim = A->gbm1 + G;
+    A->gphi = A->gbm1 + G;
     A->extra = (char*)c->ws + vec_bytes;
     const int64_t span = N > G ? N : G;
     prep_params_kernel<<<dim3((unsigned)((span + 255) / 256)), dim3(256), 0, c->stream>>>(
-        scaling, N, alpha, beta, G, A->scal, A->ga, A->gbm1, A->glim);
+        scaling, N, alpha, beta, G, A->scal, A->ga, A->gbm1, A->gphi);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -622,20 +619,24 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
 {
     Staging st;
     SamplerArgs A{};
-    // one flag byte per (cell, 256-gene tile, lane) for the gamma-Poisson samples, then one byte
-    // per row of the mean tensor for the domain check
-    const size_t flag_bytes = (flags & PROSSTT_AMD_KERNEL_TILED) ? 0
-        : (size_t)(N > 0 ? N : 0) * (size_t)(((int64_t)(G > 0 ? G : 0) + kTileG - 1) / kTileG) * 64;
+    // room for the list of gamma-Poisson samples (one in 64 may be one before K3h has to classify
+    // the matrix itself), then one byte per row of the mean tensor for the domain check
+    const bool tiled = (flags & PROSSTT_AMD_KERNEL_TILED) != 0;
+    const uint64_t samples = (uint64_t)(N > 0 ? N : 0) * (uint64_t)(G > 0 ? G : 0);
+    const uint64_t cap64 = samples / 64 + 4096;
+    const uint32_t heavy_cap = tiled ? 0u : (uint32_t)(cap64 < 0x7fffffffull ? cap64 : 0x7fffffffull);
+    const size_t list_bytes = (((size_t)heavy_cap * sizeof(k3::HeavyEntry)) + 255) & ~(size_t)255;
     const size_t rows_bytes = (((size_t)(rows > 0 ? rows : 0)) + 255) & ~(size_t)255;
-    const size_t info_bytes = (flags & PROSSTT_AMD_KERNEL_TILED) ? 0 : ((size_t)(N > 0 ? N : 0) + 4) * sizeof(k3::CellInfo);
-    const size_t word_bytes = ((flag_bytes + 255) & ~(size_t)255) + rows_bytes + info_bytes + 256;
+    const size_t info_bytes = tiled ? 0 : ((size_t)(N > 0 ? N : 0) + 4) * sizeof(k3::CellInfo);
+    const size_t word_bytes = list_bytes + rows_bytes + info_bytes + 256;
     int rc = sampler_setup(c, st, means, rows, G, row_of_cell, scaling, alpha, beta, N, flags, &A, word_bytes);
     if (rc) return rc;
     if (N == 0 || G == 0) return 0;
     if (!out) return fail(PROSSTT_AMD_EINVAL, "out is NULL");
-    uint8_t* heavy_flags = (uint8_t*)A.extra;
-    uint8_t* rows_used = heavy_flags + ((flag_bytes + 255) & ~(size_t)255);
+    k3::HeavyEntry* heavy_list = (k3::HeavyEntry*)A.extra;
+    uint8_t* rows_used = (uint8_t*)A.extra + list_bytes;
     k3::CellInfo* cellinfo = (k3::CellInfo*)(rows_used + rows_bytes);
+    uint32_t* heavy_head = (uint32_t*)(c->scratch + 3);     // {appended, overflowed}: zeroed with the flags below
     if (ld_out < G) return fail(PROSSTT_AMD_EINVAL, "ld_out %lld < G %d", (long long)ld_out, G);
 
     if (cell_index && (flags & PROSSTT_AMD_HOST_INPUTS)) {
@@ -649,7 +650,7 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
         if ((rc = st.alloc(&p, (size_t)N * ld_out * 4))) return rc;
         d_out = (int32_t*)p;
     }
-    HIP_TRY(hipMemsetAsync(c->scratch, 0, 32, c->stream));   // [0] domain flag, [2] full-test request
+    HIP_TRY(hipMemsetAsync(c->scratch, 0, 32, c->stream));   // [0] domain flag, [2] full-test request, [3] list head
 
     const int64_t tiles_g = ((int64_t)G + kTileG - 1) / kTileG;
     const bool vec = (G % 4 == 0) && (ld_out % 4 == 0) && (((uintptr_t)A.means & 15) == 0) &&
@@ -690,24 +691,18 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
         if (ev_start) HIP_TRY(hipEventRecord(ev_start, c->stream));    // the dominant kernel is timed alone
         if (vec)
             k3::sample_counts_stream_kernel<true><<<grid, block, 0, c->stream>>>(
-                A.means, G, cellinfo, A.ga, A.gbm1, A.glim, N, k0, k1, d_out, ld_out, (int32_t)strips,
-                (int32_t)strip_cells, heavy_flags, (int32_t)tiles_g);
+                A.means, G, cellinfo, A.ga, A.gbm1, A.gphi, N, k0, k1, d_out, ld_out, (int32_t)strips,
+                (int32_t)strip_cells, heavy_head, heavy_list, heavy_cap);
         else
             k3::sample_counts_stream_kernel<false><<<grid, block, 0, c->stream>>>(
-                A.means, G, cellinfo, A.ga, A.gbm1, A.glim, N, k0, k1, d_out, ld_out, (int32_t)strips,
-                (int32_t)strip_cells, heavy_flags, (int32_t)tiles_g);
+                A.means, G, cellinfo, A.ga, A.gbm1, A.gphi, N, k0, k1, d_out, ld_out, (int32_t)strips,
+                (int32_t)strip_cells, heavy_head, heavy_list, heavy_cap);
         HIP_TRY(hipGetLastError());
         if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, c->stream));   // the dominant kernel is timed alone
-        // 16-wave blocks, two per CU; each gets a strided share of the flag tickets
-        const int64_t tickets = N * ((tiles_g * 64 + 511) / 512);
-        int64_t hblocks = (tickets + 255) / 256;
-        if (hblocks > 256 * 2) hblocks = 256 * 2;
-        if (hblocks < 1) hblocks = 1;
-#if K3_ABLATE != 4
-        k3::sample_counts_heavy_kernel<<<dim3((unsigned)hblocks), dim3(k3::kHeavyBlock), 0, c->stream>>>(
-            heavy_flags, (int32_t)tiles_g, A.means, G, A.row_of_cell, A.scal, A.ga, A.gbm1, N, k0, k1, cell_offset,
-            cell_index, d_out, ld_out);
-#endif
+        // every wave takes 64 list entries per step; waves beyond the list's end leave at once
+        k3::sample_counts_heavy_kernel<<<dim3(2048), dim3(k3::kHeavyBlock), 0, c->stream>>>(
+            heavy_head, heavy_list, heavy_cap, A.means, G, A.row_of_cell, A.scal, A.ga, A.gbm1, N, k0, k1,
+            cell_offset, cell_index, d_out, ld_out);
         ev_stop = nullptr;
         if (flags & PROSSTT_AMD_CHECK_DOMAIN) {
             HIP_TRY(hipMemsetAsync(rows_used, 0, (size_t)rows, c->stream));

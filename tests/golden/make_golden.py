@@ -229,7 +229,10 @@ def g7_nb_tables():
             (19.1, 0.2, 2.0), (15.0, 0.9, 2.4), (15.0, 1.1, 2.4), (30.0, 0.2, 2.0), (30.0, 2.0, 2.0),
             (100.0, 0.05, 1.5), (100.0, 1.2, 4.0), (400.0, 0.2, 2.0), (3000.0, 0.25, 2.0),
             (3.0, 5.0, 2.0), (20.0, 0.0, 1.0 + 1e-8), (0.7, 0.0, 1.0 + 1e-8), (2.0, 0.0, 7.0),
-            (8.0, 3.0, 1.0), (50.0, 1e-4, 1.2)]
+            (8.0, 3.0, 1.0), (50.0, 1e-4, 1.2),
+            # the inversion class reaches beyond m = 19 where the NB is overdispersed (-log P0 <= 19, theta <= 16)
+            (60.0, 0.2, 2.0), (75.0, 0.1, 3.0), (80.0, 0.1, 3.0), (106.0, 0.0, 17.0), (40.0, 0.37, 2.0),
+            (44.0, 0.37, 2.0), (25.0, 0.02, 1.3)]
     kmax = 4096
     k = np.arange(kmax)
     pmf = np.zeros((len(grid), kmax))

@@ -1,7 +1,7 @@
 """
 -m gpu: the HIP count sampler (K3) against the oracle, through the C ABI.
 
- * counts: BIT-EXACT against oracle/nb_model.c (the scalar C model of PRNB-1) on the
+ * counts: BIT-EXACT against oracle/nb_model.c (the scalar C model of PRNB-2) on the
    same seeded inputs -- integer work, no tolerance;
  * (mu, p, r): bit-exact against the model AND within rtol 1e-6 of the reference's
    float64 get_pr_umi (count_model.py:156-158) -- the stated fp32 tolerance;
@@ -91,9 +91,10 @@ def test_edge_parameters_bit_exact(ctx):
 
 
 def test_inversion_class_limit_and_invalid_inputs_bit_exact(ctx, monkeypatch):
-    """The inversion class is `m <= light_limit(gene)`; everything else -- including
+    """The inversion class is `theta <= 16 and -log P0 <= 19`; everything else -- including
     non-positive, infinite and NaN means, alpha < 0, beta < 1, beta - 1 > 16 -- takes the
-    gamma-Poisson kernel or is a 0 by definition.  Unchecked mode, both kernels, bit-exact
+    gamma-Poisson kernel or is a 0 by definition (genes whose theta can pass 16 at small means
+    skip the zero test: prnb::zero_test_factor).  Unchecked mode, both kernels, bit-exact
     against the model; the path codes of nb_params agree with the model's too."""
     from oracle import nb_model
     rng = np.random.default_rng(77)
@@ -126,6 +127,39 @@ def test_inversion_class_limit_and_invalid_inputs_bit_exact(ctx, monkeypatch):
     mpath = nb_model.nb_params(means, roc, sc, al, be)[3]
     np.testing.assert_array_equal(path, mpath)
     assert set(np.unique(path)) == {0, 1, 2}
+
+
+def test_many_gamma_poisson_samples_overflow_the_list(ctx):
+    """More gamma-Poisson samples than the streaming kernel's list holds (1/64 of the matrix):
+    K3h then classifies every sample itself; a list that just fits takes the normal way.  Both
+    bit-exact against the model."""
+    from oracle import nb_model
+    for frac, seed in ((0.6, 31), (0.012, 32)):
+        means, roc, sc, al, be = synthetic(seed, 50, 1024, 900, heavy_frac=frac)
+        path = nb_model.nb_params(means, roc, sc, al, be)[3]
+        share = (path == 2).mean()
+        assert (share > 0.3) if frac > 0.5 else (0.002 < share < 1 / 64)
+        got = ctx.sample_counts(means, roc, sc, al, be, seed=seed).cpu().numpy()
+        np.testing.assert_array_equal(got, nb_model.sample_counts(means, roc, sc, al, be, seed))
+
+
+def test_long_inversion_walks_bit_exact(ctx):
+    """Means of 20-100 with theta <= 16 are drawn by inversion (walks of a hundred terms and more,
+    results far later than their row's store): bit-exact, and the class is the model's."""
+    from oracle import nb_model
+    rng = np.random.default_rng(8)
+    G, rows, N = 512, 16, 700
+    means = np.exp(rng.uniform(np.log(15), np.log(110), (rows, G))).astype(np.float32)
+    roc = rng.integers(0, rows, N).astype(np.int32)
+    sc = np.exp(rng.normal(0, 0.3, N))
+    al = rng.uniform(0.0, 0.15, G)
+    be = rng.uniform(1.5, 6.0, G)
+    want = nb_model.sample_counts(means, roc, sc, al, be, 5)
+    path = nb_model.nb_params(means, roc, sc, al, be)[3]
+    assert 0.3 < (path == 1).mean() < 0.95 and (path == 2).any()
+    got = ctx.sample_counts(means, roc, sc, al, be, seed=5).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    assert want[path == 1].max() > 150
 
 
 def test_domain_errors_like_scipy(ctx):

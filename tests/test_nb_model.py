@@ -1,5 +1,5 @@
 """
-CPU tests of oracle/nb_model.c, the scalar C model of the device count sampler (PRNB-1):
+CPU tests of oracle/nb_model.c, the scalar C model of the device count sampler (PRNB-2):
 known-answer vectors of Philox4x32-10, accuracy of the deterministic binary32 math, and the
 LAW of the sampler against the reference's distribution (scipy.stats.nbinom tables of fixture
 g7 and the oracle's numpy path).  The HIP kernel is then held bit-exact to this model (-m gpu).
@@ -133,21 +133,31 @@ def test_degenerate_parameters():
     assert abs(big.mean() / 3.0e5 - 1) < 0.05 and big.min() >= 0
 
 
-def test_inversion_class_is_a_per_gene_mean_limit():
-    """PRNB-1: inversion iff m <= min(19, (16 - (b-1))/a) (a > 0), 19 (a <= 0), never when
-    b - 1 > 16; m <= 0 or theta <= 0 is the degenerate path.  Both classes follow the same
-    law, so the split must not show in the moments."""
-    means = np.array([[0.5, 18.9, 19.0, 19.1, 6.0, 8.0, 3.0, 3.0, 25.0, 2.0, 2.0, 0.0]], np.float32)
-    alpha = np.array([0.2, 0.2, 0.2, 0.2, 2.0, 2.0, 0.0, 0.0, -0.5, 0.3, np.nan, 0.2])
-    beta = np.array([2.0, 2.0, 2.0, 2.0, 2.0, 2.0, 17.0, 17.5, 30.0, 1.0, 2.0, 2.0])
+def test_inversion_class_rule():
+    """PRNB-2: inversion iff theta = a*m + b - 1 <= 16 and t = -log P(X=0) = m*log1p(theta)/theta <= 19
+    (P0 * 2^32 >= 24, tail ratio <= 16/17); m <= 0 or theta <= 0 is the degenerate path.  Both classes
+    follow the same law, so the split must not show in the moments."""
+    means = np.array([[0.5, 18.9, 30.0, 60.0, 6.0, 8.0, 3.0, 3.0, 25.0, 2.0, 2.0, 0.0, 75.0, 80.0, 25.0, 19.5]], np.float32)
+    alpha = np.array([0.2, 0.2, 0.2, 0.2, 2.0, 2.0, 0.0, 0.0, -0.5, 0.3, np.nan, 0.2, 0.1, 0.1, 0.0, 0.0])
+    beta = np.array([2.0, 2.0, 2.0, 2.0, 2.0, 2.0, 17.0, 17.5, 30.0, 1.0, 2.0, 2.0, 3.0, 3.0, 1.0 + 1e-8, 1.0 + 1e-8])
     path = nm.nb_params(means, np.zeros(1, np.int32), np.ones(1), alpha, beta)[3][0]
-    #                 m=.5 18.9 19 19.1 | a=2: limit (16-1)/2 = 7.5 | b-1 = 16, 16.5 | a<0: theta = 29-12.5 | b=1 | NaN | m=0
-    assert path.tolist() == [1, 1, 1, 2, 1, 2, 1, 2, 2, 1, 0, 0]
-    for m, a, b in ((7.4, 2.0, 2.0), (7.6, 2.0, 2.0), (18.9, 0.3, 3.0), (19.1, 0.3, 3.0)):
+    #         m=.5 18.9 30 60 (t=.4, 8.9, 8.9, 12.2) | a=2: theta=13, 17 | b-1 = 16, 16.5 | a<0: theta=16.5 | b=1: theta=.6
+    #         | NaN | m=0 | t=18.6, 19.2 | Poisson limit: t = m = 25 / 19.5
+    assert path.tolist() == [1, 1, 1, 1, 1, 2, 1, 2, 2, 1, 0, 0, 1, 2, 2, 2]
+    for m, a, b in ((7.4, 2.0, 2.0), (7.6, 2.0, 2.0), (75.0, 0.1, 3.0), (80.0, 0.1, 3.0), (60.0, 0.2, 2.0)):
         x = nm.sample_iid(m, a, b, 400000, seed=5)
         var = a * m * m + b * m
         assert abs(x.mean() - m) < 5 * np.sqrt(var / x.size)
         assert abs(x.var() / var - 1) < 0.03
+
+
+def test_lost_mass_goes_to_the_tail():
+    """A walk that runs out of representable pmf before the uniform is used up ends at the tail value
+    where it stopped, never at 0: no zero may appear among samples whose P(X=0) is below 1e-7."""
+    x = nm.sample_iid(75.0, 0.1, 3.0, 2_000_000, seed=9)        # P0 = e^-18.6
+    assert x.min() > 0
+    x = nm.sample_iid(25.0, 0.02, 1.3, 2_000_000, seed=9)       # P0 = e^-18.4, near-Poisson
+    assert x.min() > 0
 
 
 def test_device_mode_walk_law():
