@@ -38,11 +38,11 @@
 
 /* ---- sampler constants (part of the PRNB-1 definition) ------------------ */
 #define PRNB_LIGHT_T      19.0f        /* inversion iff theta <= 16 and t = -log P(X=0) <= 19: P0 * 2^32 >= 24 */
-#define PRNB_LIGHT_THETA  16.0f        /* tail ratio theta/(1+theta) <= 16/17: the walk ends far below the 1/k table's 1023 entries */
+#define PRNB_LIGHT_THETA  16.0f        /* tail ratio theta/(1+theta) <= 16/17: the walk ends far below the 1/k table's 511 entries */
 #define PRNB_THETA_MIN    8.6736174e-19f /* 2^-60: below this NB == Poisson in binary32 */
 #define PRNB_THETA_MAX    1.0e18f
 #define PRNB_R_MIN        9.094947e-13f  /* 2^-40: P(X>0) < 2^-32, return 0 */
-#define PRNB_KTAB         1024         /* 1/k table size, last entry = 0 sentinel */
+#define PRNB_KTAB         512          /* 1/k table size, last entry = 0 sentinel: with theta <= 16 and -log P0 <= 19 (mean <= 107) P(X >= 511) < 1e-10 */
 #define PRNB_POIS_INV     10.0f        /* Poisson: inversion below, PTRS above */
 #define PRNB_LAM_BIG      4194304.0f   /* 2^22: rounded normal above */
 #define PRNB_MAX_TRIES    64

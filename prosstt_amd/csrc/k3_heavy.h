@@ -1,6 +1,8 @@
-// K3h: the gamma-Poisson path of PRNB-2 (prnb_device.h) for the samples the streaming
-// kernel (k3_stream.h) listed -- theta above 16 or -log P(X = 0) above 19, about one in a
-// thousand of a typical workload.  Both halves are rejection samplers; run lane-per-sample
+// K3h: the samples the streaming kernel (k3_stream.h) listed instead of drawing them: the
+// gamma-Poisson class of PRNB-2 (prnb_device.h; theta above 16 or -log P(X = 0) above 19, about
+// one in a thousand of a typical workload) and the few inversion walks whose hardware-math
+// evaluation came too close to a threshold (drawn here with the exact arithmetic).
+// Both halves of the gamma-Poisson path are rejection samplers; run lane-per-sample
 // they would make every wave repeat each half until its unluckiest lane is accepted.  Here
 // every ATTEMPT is a stack entry: a gamma pass runs one Marsaglia-Tsang attempt for 64
 // entries of HG (accepted -> the Poisson stack HP, rejected -> back on HG with the next
@@ -19,16 +21,19 @@ constexpr int kHCap = 128;     // < 64 left over + 64 pushed (new entries, or re
 struct HGEntry { int32_t n, g, attempt, row; };   // row = row_of_cell[n], looked up once per ticket
 struct HPEntry { int32_t n, g; float lam; int32_t attempt; };
 
+struct HLEntry { int32_t n, g, row; };             // an inversion walk to redo
+
 struct HeavyLds {
     HGEntry hg[kHCap];
     HPEntry hp[kHCap];
+    HLEntry hl[kHCap];
 };
 
-// head/list: what the streaming kernel appended (k3::HeavyEntry).  If an append did not fit
-// (head[1] != 0; more than `cap` such samples), the list is ignored and every sample of the
-// matrix is classified here instead: slow, but any parameter set stays correct.
+// heavy: what the streaming kernel's waves listed (k3::HeavyList; `regions` of them, laid out by
+// its block -> (gene tile, strip group) map).  If a region was too small, the list is ignored
+// and every sample of the matrix is redone here instead: slow, but any parameter set stays correct.
 __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
-    const uint32_t* __restrict__ head, const HeavyEntry* __restrict__ list, uint32_t cap,
+    HeavyList heavy, uint32_t regions, int32_t strips, int32_t strip_cells,
     const float* __restrict__ means,
     int32_t G, const int32_t* __restrict__ row_of_cell, const float* __restrict__ scal,
     const float* __restrict__ ga, const float* __restrict__ gbm1, int64_t N, uint32_t k0, uint32_t k1,
@@ -41,7 +46,7 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
     for (int k = tid; k < prnb::kKTab; k += kHeavyBlock) inv_k[k] = (k && k < prnb::kKTab - 1) ? 1.0f / (float)k : 0.0f;
     __syncthreads();
 
-    int hg_top = 0, hp_top = 0;      // wave-uniform
+    int hg_top = 0, hp_top = 0, hl_top = 0;      // wave-uniform
 
     auto cell_id = [&](int32_t n) -> uint64_t {
         return cell_index ? (uint64_t)cell_index[n] : cell_offset + (uint64_t)n;
@@ -186,43 +191,74 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
         while (hp_top >= 64) poisson_pass();
     };
 
-    // ---- feed the gamma stack: 64 list entries per wave and step ----------------------------------
+    // ---- inversion walks the streaming kernel's approximate arithmetic gave up on: PRNB-2's exact
+    // arithmetic, 64 at a time, each lane walking its own pmf
+    auto light_pass = [&]() {
+        const int cnt = hl_top < 64 ? hl_top : 64;
+        if (lane < cnt) {
+            const HLEntry e = L.hl[hl_top - 1 - lane];
+            const prnb::Params P = prnb::make_params(means[(int64_t)e.row * G + e.g], scal[e.n], ga[e.g], gbm1[e.g]);
+            const uint64_t cell = cell_id(e.n);
+            const prnb::Words w = prnb::philox4x32_10((uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)e.g >> 2, 0u, k0, k1);
+            const int32_t x = prnb::light_draw(P, w.w[e.g & 3], inv_k);
+            if (x != 0) out[(int64_t)e.n * ld + e.g] = x;
+        }
+        hl_top -= cnt;
+    };
+
+    // ---- 64 list entries per wave and step, sorted onto the gamma stack and the redo stack ---------
     auto feed = [&](bool has, int32_t n, int32_t g) {
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(has);
+        bool heavy = false, light = false;
+        int32_t row = 0;
         if (has) {
+            row = row_of_cell[n];
+            const prnb::Params P = prnb::make_params(means[(int64_t)row * G + g], scal[n], ga[g], gbm1[g]);
+            light = P.valid && P.light;
+            heavy = P.valid && !P.light;
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(heavy);
+        if (heavy) {
             HGEntry e;
-            e.n = n; e.g = g; e.attempt = 0; e.row = row_of_cell[n];
+            e.n = n; e.g = g; e.attempt = 0; e.row = row;
             L.hg[hg_top + lane_rank(m)] = e;
         }
         hg_top += __popcll(m);
+        const unsigned long long ml = __builtin_amdgcn_ballot_w64(light);
+        if (light) {
+            HLEntry e;
+            e.n = n; e.g = g; e.row = row;
+            L.hl[hl_top + lane_rank(ml)] = e;
+        }
+        hl_top += __popcll(ml);
         while (hg_top >= 64) gamma_pass();
+        while (hl_top >= 64) light_pass();
     };
-    const int64_t wave0 = ((int64_t)blockIdx.x * (kHeavyBlock / 64) + wv) * 64;
-    const int64_t stride = (int64_t)gridDim.x * kHeavyBlock;
-    if (head[1] == 0u) {
-        const int64_t cnt = head[0] < cap ? head[0] : cap;
-        for (int64_t i0 = wave0; i0 < cnt; i0 += stride) {
-            const bool has = i0 + lane < cnt;
-            HeavyEntry e;
-            e.n = 0; e.g = 0;
-            if (has) e = list[i0 + lane];
-            feed(has, e.n, e.g);
+    const int64_t wave_id = (int64_t)blockIdx.x * (kHeavyBlock / 64) + wv;
+    const int64_t waves = (int64_t)gridDim.x * (kHeavyBlock / 64);
+    const int64_t wave0 = wave_id * 64, stride = waves * 64;
+    if (heavy.overflow[0] == 0u) {
+        const int32_t groups = (strips + 3) / 4;
+        for (int64_t r = wave_id; r < (int64_t)regions; r += waves) {
+            const uint32_t cnt = heavy.count[r];
+            const int32_t blk = (int32_t)(r >> 2);
+            const int32_t tile_g = blk / groups;
+            const int64_t n0 = (int64_t)((blk - tile_g * groups) * 4 + (int32_t)(r & 3)) * strip_cells;
+            for (uint32_t i0 = 0u; i0 < cnt; i0 += 64u) {
+                const bool has = i0 + (uint32_t)lane < cnt;
+                const uint32_t p = has ? heavy.list[(uint64_t)r * heavy.cap + i0 + (uint32_t)lane] : 0u;
+                feed(has, (int32_t)(n0 + (p >> 8)), tile_g * kTileG + (int32_t)(p & 255u));
+            }
         }
     } else {
+        // the list overflowed: every sample of the matrix is redone here
         const int64_t total = N * (int64_t)G;
         for (int64_t i0 = wave0; i0 < total; i0 += stride) {
             const int64_t i = i0 + lane;
-            bool has = false;
-            int32_t n = 0, g = 0;
-            if (i < total) {
-                n = (int32_t)(i / G);
-                g = (int32_t)(i - (int64_t)n * G);
-                const prnb::Params P = prnb::make_params(means[(int64_t)row_of_cell[n] * G + g], scal[n], ga[g], gbm1[g]);
-                has = P.valid && !P.light;
-            }
-            feed(has, n, g);
+            const int32_t n = i < total ? (int32_t)(i / G) : 0;
+            feed(i < total, n, (int32_t)(i - (int64_t)n * G));
         }
     }
+    while (hl_top > 0) light_pass();
     while (hg_top > 0) gamma_pass();
     while (hp_top > 0) poisson_pass();
 }

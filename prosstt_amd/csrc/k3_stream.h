@@ -12,18 +12,31 @@
 //   stage 1 (uniform)   one count-matrix row segment per wave pass: 16-B mean load, one
 //                       Philox call per lane, the bound test as a compare mask; survivors are
 //                       pushed on stack S1 under exec = mask;
-//   stage 2 (64 of S1)  exact P(X = 0) and the class test, then the terms k = 1, 2; what is
-//                       still undecided is pushed on S2 with the pmf state at k = 3;
+//   stage 2 (64 of S1)  P(X = 0) and the class test, then the terms k = 1, 2; what is still
+//                       undecided is pushed on S2 with the pmf state at k = 3;
 //   stage 3 (lanes pull from S2)  four pmf steps per lane per pass; a lane that finishes
 //                       writes its count into the LDS row ring and pulls the next entry;
 //   output              the last kRing rows of the strip live in LDS, 16 bits per count; a row
 //                       is stored (one coalesced 1 KiB store per wave) kRing cells after stage 1
-//                       started it.  The few counts that arrive later than that are written
-//                       directly (4-B store, after the row's own store);
-//   samples of the gamma-Poisson class are only LISTED here (a lane of stage 2 that meets one
-//   keeps it in a register; when a lane meets its second, and at the end of the strip, the wave
-//   appends what its lanes hold to a global list); sample_counts_heavy_kernel (k3_heavy.h)
-//   draws them afterwards.
+//                       started it.  The few counts that arrive later than that (long walks)
+//                       are collected in LDS and written in bursts of 4-B stores -- a store per
+//                       late count would sit in front of every wait for the next mean load
+//                       (loads and stores retire in order on one counter);
+//   samples of the gamma-Poisson class are only LISTED here (a lane that meets one keeps it in
+//   a register; when a lane meets its second, and at the end of the strip, the wave writes what
+//   its lanes hold to its own region of a global list -- no atomics: one counter for all waves
+//   serialises them); sample_counts_heavy_kernel (k3_heavy.h) draws them afterwards.
+//
+// Stages 2 and 3 evaluate P(X = 0) with the hardware's v_rcp/v_log/v_exp (each within 1.2e-7 of
+// the true value on gfx950, tools/hwmath_probe.hip) instead of PRNB-2's deterministic binary32
+// arithmetic -- a third of the instructions.  The result must still be the model's, bit for bit:
+// a walk's answer is the first k with w < C_k (the running sum of the scaled pmf), so it can
+// only differ from the exact evaluation's when w lies within the two evaluations' distance of
+// some C_k.  Every lane therefore tracks how close w came to a threshold and, when that is
+// within a margin of about three times the worst-case distance (2^-20 + t*2^-19 + k*2^-22 of 2^32,
+// t = -log2 P0), gives the sample up: it goes on the same list, and K3h redoes it with the
+// exact arithmetic (about 1 in 10^4 of the walks).  So does a sample whose class the
+// approximate t cannot decide.
 // Results are pure functions of (sample parameters, seed, global cell id, gene), so the
 // order in which the stacks are drained cannot change them.
 //
@@ -45,6 +58,17 @@ constexpr int kS2Cap = 96;         // < 32 left over + 64 pushed by one stage-2 
 constexpr int kS2Run = 32;         // stage 3 runs while S2 holds at least this many entries (8, 16: 3-5 % slower)
 static_assert(kS2Cap >= kS2Run - 1 + 64 && kS1Cap >= 63 + 256, "a stack must take one more pass of pushes");
 constexpr int kRing = 4;           // rows of the strip kept in LDS (16 bits per count) before they are stored; a power of 2
+// Threshold margins of the hardware-math evaluation, in units of 2^-32 (see the header): about
+// three times the worst-case distance between the two evaluations of a running pmf sum C_k --
+//   P0:  |t_exact - t_hw| <= (6.1e-7 + 3.5e-7) * t  (det_log1p 2.5e-7, det_rcp 1.2e-7, four roundings |
+//        log2(u1)*rcp(u1-1) 2.9e-7 measured over (0, 16], one rounding), exp 2.0e-7 + 0.9e-7;
+//   numerators: none (mp and q are formed by PRNB-2's own arithmetic here), so a term adds only
+//        the two paths' rounding differences, 2 * 2^-24 each at most.
+constexpr float kMargin0 = 4096.0f;          // 2^-20        (worst case 2.9e-7 = 1245 units)
+constexpr float kMarginPerT2 = 8192.0f;      // 2^-19 per unit of t2 = t / ln 2   (worst case 9.6e-7 * ln 2 = 2858 units)
+constexpr uint32_t kMarginPerTerm = 1024u;   // 2^-22 per term                   (worst case 1.2e-7 = 515 units)
+constexpr float kT2Sure = 27.41120f * (1.0f - 1.53e-5f);   // 19 / ln 2, less 2^-16: surely t <= 19
+constexpr int kLateCap = 128;      // results that missed their row wait here for one burst of stores (< 64 left + 64)
 
 // What stage 1 needs to know about a cell, packed by cellinfo_kernel so that one scalar load
 // fetches it: byte offset of the cell's row in the mean tensor, library-size factor, global id.
@@ -60,13 +84,17 @@ struct S2Entry { float ps, mp, q; uint32_t rem; };    // pmf (x 2^32) at k = 3; 
 struct WaveLds {
     S1Entry s1[kS1Cap];
     S2Entry s2[kS2Cap];
-    uint32_t s2pos[kS2Cap];
-    uint16_t ring[kRing * 256];    // [row slot][gene-in-tile]: a walk ends below the 1/k table's 1023 entries
+    uint32_t s2pos[kS2Cap];        // pos | (threshold margin at k = 3) >> 8 << 16
+    uint16_t ring[kRing * 256];    // [row slot][gene-in-tile]: a walk ends below the 1/k table's 511 entries
+    uint32_t late[kLateCap];       // (pos << 16) | count of results whose row has left the ring already
 };
 
-// The list of gamma-Poisson samples: head[0] = entries appended (may exceed the capacity),
-// head[1] != 0 once an append did not fit -- K3h then classifies every sample itself.
-struct HeavyEntry { int32_t n, g; };
+// The list of samples left to K3h: wave w of block b owns region r = 4*b + w, entries
+// list[r * cap .. + count[r]) = pos (cell-in-strip << 8 | gene-in-tile); overflow[0] != 0 once a
+// region was too small (more than one sample in 16 listed) -- K3h then redoes every sample itself.
+struct HeavyList { uint32_t* count; uint32_t* list; uint32_t* overflow; uint32_t cap; };
+
+__device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
 // rank of this lane among the lanes whose bit is set in `mask`
 __device__ __forceinline__ int lane_rank(unsigned long long mask)
@@ -80,8 +108,7 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
     const float* __restrict__ means, int32_t G, const CellInfo* __restrict__ cellinfo,
     const float* __restrict__ ga, const float* __restrict__ gbm1, const float* __restrict__ gphi,
     int64_t N, uint32_t k0, uint32_t k1, int32_t* __restrict__ out, int64_t ld, int32_t strips,
-    int32_t strip_cells, uint32_t* __restrict__ heavy_head, HeavyEntry* __restrict__ heavy_list,
-    uint32_t heavy_cap)
+    int32_t strip_cells, HeavyList heavy)
 {
     // 1/k for k = -4 .. KTAB+7: 0 below k = 1 (an idle stage-3 lane reads there) and from the sentinel (k = KTAB-1) on
     __shared__ __attribute__((aligned(16))) float inv_k_store[4 + prnb::kKTab + 8];
@@ -103,7 +130,11 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
     const int32_t gbase = tile_g * kTileG;
     const int32_t g0 = gbase + lane * 4;
     const int64_t n0 = (int64_t)strip * strip_cells;
-    if (strip >= strips || n0 >= N) return;          // whole wave leaves together (no barrier below)
+    const uint32_t region = blockIdx.x * 4u + (uint32_t)wv;
+    if (strip >= strips || n0 >= N) {                // whole wave leaves together (no barrier below)
+        if (lane == 0) heavy.count[region] = 0u;
+        return;
+    }
     const int cells = (int)((N - n0 < strip_cells) ? (N - n0) : strip_cells);
 
     // lanes beyond G read some valid mean (see load_seg); a = b - 1 = 0 makes theta = 0, which
@@ -119,10 +150,10 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
 
     int s1_top = 0, s2_top = 0;                      // wave-uniform
     constexpr uint32_t kNoHeavy = 0xffffffffu;
-    uint32_t hpend = kNoHeavy;                       // pos of the gamma-Poisson sample this lane holds for the next append
+    uint32_t hpend = kNoHeavy;                       // pos of the sample this lane holds for the next append to K3h's list
     // stage-3 lane state
     float ps = 0.0f, mp = 0.0f, q = 0.0f, kf = 0.0f;   // kf = (float)k of a busy lane
-    uint32_t rem = 0u, pos = 0u;
+    uint32_t rem = 0u, pos = 0u, dl = 0u;            // dl: this lane's threshold margin (grows with k)
     constexpr int kIdle = -5;        // k + 1 = 0 mod 4 (the aligned read of four reciprocals), k + 3 < 0 (no result)
     int k = kIdle;
     float4 inv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // 1/(k+1) .. 1/(k+4): read one pass ahead
@@ -154,14 +185,51 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
         flushed_pos = (cl << 8) | 255;
     };
 
-    // a finished count (> 0) goes into the row ring while its row is still there, else (rare)
-    // straight to memory, after the row's own store: a wave's stores to one address stay in order
+    // a finished count (> 0) goes into the row ring while its row is still there, else (rare) on
+    // the late list; a burst of 4-B stores empties the list when it is full and when the strip ends,
+    // always after the rows' own stores (a wave's stores to one address stay in order).  Every lane
+    // of the wave calls this (res = 0: nothing to deliver).
+    int late_top = 0;                                // wave-uniform
+    auto flush_late = [&]() {
+        for (int i = lane; i < late_top; i += 64) {
+            const uint32_t e = L.late[i];
+            const uint32_t p = e >> 16;
+            strip_out[(p >> 8) * ld32 + (p & 255u)] = (int32_t)(e & 0xffffu);
+        }
+        late_top = 0;
+    };
     auto deliver = [&](uint32_t p, int32_t res) {
         const bool late = (int32_t)p <= flushed_pos;
         if ((res > 0) & !late) L.ring[p & (kRing * 256 - 1)] = (uint16_t)res;   // slot = cell % kRing, gene-in-tile
-        if ((res > 0) & late) strip_out[(p >> 8) * ld32 + (p & 255u)] = res;
+        const unsigned long long ml = __builtin_amdgcn_ballot_w64((res > 0) & late);
+        if (ml != 0ull) {
+            const int cnt = __popcll(ml);
+            if (late_top + cnt > kLateCap) flush_late();
+            if ((res > 0) & late) L.late[late_top + lane_rank(ml)] = (p << 16) | (uint32_t)res;
+            late_top += cnt;
+        }
     };
 
+    // write the samples the lanes hold for K3h to this wave's region of the list (about ten entries
+    // each time on the headline workload: the first lane to meet its second sample triggers it)
+    uint32_t* const my_list = heavy.list + (uint64_t)region * heavy.cap;
+    uint32_t h_cnt = 0u;                              // wave-uniform
+    auto flush_heavy = [&]() {
+        const unsigned long long mp_ = __builtin_amdgcn_ballot_w64(hpend != kNoHeavy);
+        if (hpend != kNoHeavy) {
+            const uint32_t slot = h_cnt + (uint32_t)lane_rank(mp_);
+            if (slot < heavy.cap) my_list[slot] = hpend;
+        }
+        h_cnt += (uint32_t)__popcll(mp_);
+        hpend = kNoHeavy;
+    };
+    // every lane of the wave calls this; `mine` lanes leave sample `p` to K3h
+    auto list_sample = [&](bool mine_, uint32_t p) {
+        if (__builtin_amdgcn_ballot_w64(mine_) != 0ull) {
+            if (__builtin_amdgcn_ballot_w64(mine_ & (hpend != kNoHeavy)) != 0ull) flush_heavy();
+            if (mine_) hpend = p;
+        }
+    };
     // ---- stage 3: four pmf steps for every busy lane; idle lanes pull from S2 ------------------
     // A lane is idle iff k == kIdle, and an idle lane keeps ps = 0: its steps end without a hit
     // and its "result" k + 3 is negative, so the arithmetic below never asks which lanes are busy.
@@ -169,6 +237,8 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
     // hit, else the group's last k when the last of the four terms is 0" is the sequential walk's
     // answer (prnb::chop_down).  A walk enters at k = 3 and advances by 4: the four reciprocals
     // 1/(k+1)..1/(k+4) are one aligned 16-byte LDS read.
+    // Margin (see the header): rem_j + dl < 2*dl (unsigned) iff w is within dl of the threshold C_j,
+    // on either side; a lane that comes that close stops and leaves its sample to K3h.
     auto stage3_pass = [&]() {
         unsigned long long idle_m;
         asm("v_cmp_eq_u32 %0, -5, %1" : "=s"(idle_m) : "v"(k));
@@ -179,7 +249,9 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
                 const int idx = s2_top - 1 - rank;
                 const S2Entry e = L.s2[idx];
                 ps = e.ps; mp = e.mp; q = e.q; rem = e.rem;
-                pos = L.s2pos[idx];
+                const uint32_t pd = L.s2pos[idx];
+                pos = pd & 0xffffu;
+                dl = (pd >> 16) << 8;
                 k = 3;
                 kf = 3.0f;
                 inv = *reinterpret_cast<const float4*>(&inv_k[4]);
@@ -205,97 +277,91 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
         const float num3 = num2 + q;
         const uint32_t pf3 = (uint32_t)ps3;
         const bool hit3 = rem3 < pf3;
+        const uint32_t rem4 = rem3 - pf3;
+        const uint32_t near = umin(umin(rem1 + dl, rem2 + dl), umin(rem3 + dl, rem4 + dl));
+        const bool close = near < 2u * dl;               // never for an idle lane: its dl is 0
         const bool any = hit0 | hit1 | hit2 | hit3;
-        const bool done = any | (pf3 == 0u);
-        const int32_t res = done ? k + (hit0 ? 0 : (hit1 ? 1 : (hit2 ? 2 : 3))) : 0;
+        const bool done = any | (pf3 == 0u) | close;
+        const int32_t res = (done & !close) ? k + (hit0 ? 0 : (hit1 ? 1 : (hit2 ? 2 : 3))) : 0;
         deliver(pos, res);
-        rem = rem3 - pf3;
+        list_sample(close, pos);
+        rem = rem4;
         ps = done ? 0.0f : (ps3 * num3) * inv.w;
+        dl = done ? 0u : dl + 4u * kMarginPerTerm;
         kf = kf + 4.0f;
         k = done ? kIdle : k + 4;
         inv = *reinterpret_cast<const float4*>(__builtin_assume_aligned(&inv_k[k + 1], 16));   // k + 1 = 0 mod 4
     };
 
-    // ---- stage 2: exact P(X = 0), class test, then the terms k = 1, 2, for up to 64 entries of S1
-    // append the gamma-Poisson samples the lanes hold to the global list: one returning atomic
-    // per wave (about ten entries each time on the headline workload: the first lane to meet its
-    // second sample triggers it)
-    auto flush_heavy = [&]() {
-        const unsigned long long mp = __builtin_amdgcn_ballot_w64(hpend != kNoHeavy);
-        const uint32_t cnt = (uint32_t)__popcll(mp);
-        uint32_t base = 0u;
-        if (lane == 0) base = atomicAdd(heavy_head, cnt);
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        if (hpend != kNoHeavy) {
-            const uint32_t slot = base + (uint32_t)lane_rank(mp);
-            HeavyEntry e;
-            e.n = (int32_t)(n0 + (hpend >> 8));
-            e.g = gbase + (int32_t)(hpend & 255u);
-            if (slot < heavy_cap) heavy_list[slot] = e;
-        }
-        if (lane == 0 && base + cnt > heavy_cap) heavy_head[1] = 1u;
-        hpend = kNoHeavy;
-    };
+    // ---- stage 2: P(X = 0), class test, then the terms k = 1, 2, for up to 64 entries of S1 -------
+    // prnb::make_params with the hardware's log2, reciprocal and exp2 for P(X = 0):
+    // log1p(theta)/theta = log(u1)/(u1 - 1) (u1 = fl(1 + theta): the rounding of the sum cancels),
+    // P0 = 2^-t2; mp and q by PRNB-2's own arithmetic (they multiply into every term of a walk).  What the approximation cannot decide -- the class of a sample with t within
+    // 2^-16 of 19, a threshold within the margin -- goes to K3h's list.
     auto stage2_pass = [&]() {
         const int cnt = s1_top < 64 ? s1_top : 64;
         const bool mine = lane < cnt;
-        bool push = false, heavy = false;
+        bool push = false, give_up = false;
         int32_t res = 0;
         S2Entry e2;
-        uint32_t p2 = 0u;
+        uint32_t p2 = 0u, pd2 = 0u;
         e2.ps = 0.0f; e2.mp = 0.0f; e2.q = 0.0f; e2.rem = 0u;
         if (mine) {
             const S1Entry e = L.s1[s1_top - 1 - lane];
             p2 = e.pos;
             // (m <= 0 or theta <= 0: the count is 0 by definition; stage 1 does not test that)
             const bool valid = (e.m > 0.0f) & (e.theta > 0.0f);
-            // prnb::make_params; the clamp to kThetaMax only matters to the gamma-Poisson class
             const float theta = __builtin_fmaxf(e.theta, prnb::kThetaMin);
             const float u1 = 1.0f + theta;
-            const float d = prnb::det_rcp(theta * u1);
-            const float inv_th = d * u1, inv_u1 = d * theta;
+            const float dm1 = u1 - 1.0f;
+            const float inv_u1 = prnb::det_rcp(theta * u1) * theta;
             const float qq = theta * inv_u1;
             const float mpp = e.m * inv_u1;
-            const float t = e.m * (prnb::det_log1p(theta) * inv_th);
-            const bool light = (theta <= prnb::kLightTheta) & (t <= prnb::kLightT);
-            heavy = valid & !light;                      // gamma-Poisson class: listed for K3h (rare)
-            const float p0 = __builtin_fminf(prnb::det_exp_small(-t), 0.99999994f);   // t <= 19 where it is used
+            // t2 = -log2 P(X = 0) = m * log2(1+theta)/theta; theta below 2^-24: the Poisson limit m * log2(e)
+            const float f2 = dm1 > 0.0f ? __builtin_amdgcn_logf(u1) * __builtin_amdgcn_rcpf(dm1) : 1.44269504f;
+            const float t2 = e.m * f2;
+            // inversion class for sure: theta <= 16 and t = t2 * ln 2 below 19 by more than the two
+            // evaluations can differ (NaN: not); every other valid sample is K3h's
+            const bool light = (theta <= prnb::kLightTheta) & (t2 < kT2Sure);
+            const float p0 = __builtin_fminf(__builtin_amdgcn_exp2f(-t2), 0.99999994f);
             const float ps0 = p0 * 4294967296.0f;       // pmf scaled by 2^32 (exact scaling)
             const uint32_t pf0 = (uint32_t)ps0;
-            if ((e.w >= pf0) & valid & light) {          // k >= 1
-                const uint32_t rem1 = e.w - pf0;
-                const float ps1 = ps0 * mpp;              // (* 1/1)
-                const float num1 = mpp + qq;
-                const uint32_t pf1 = (uint32_t)ps1;
+            // threshold margin of this sample at k = 2 (in units of 2^-32), a multiple of 256
+            const uint32_t d2 = ((uint32_t)PRNB_FMA(t2, kMarginPerT2, kMargin0 + 2.0f * kMarginPerTerm + 255.0f)) & ~255u;
+            const uint32_t rem1 = e.w - pf0;
+            const float ps1 = ps0 * mpp;                  // (* 1/1)
+            const float num1 = mpp + qq;
+            const uint32_t pf1 = (uint32_t)ps1;
+            const uint32_t rem2 = rem1 - pf1;
+            const float ps2 = (ps1 * num1) * 0.5f;
+            const float num2 = num1 + qq;
+            const uint32_t pf2 = (uint32_t)ps2;
+            const uint32_t rem3 = rem2 - pf2;
+            const bool close = umin(umin(rem1 + d2, rem2 + d2), rem3 + d2) < 2u * d2;
+            give_up = valid & (!light | close);
+            if (valid & light & !close & (e.w >= pf0)) {  // k >= 1
                 const bool hit1 = rem1 < pf1;
-                const uint32_t rem2 = rem1 - pf1;
-                const float ps2 = (ps1 * num1) * 0.5f;
-                const float num2 = num1 + qq;
-                const uint32_t pf2 = (uint32_t)ps2;
                 const bool hit2 = rem2 < pf2;
                 // no hit and the pmf gone: the group's last k (prnb::chop_down)
                 res = hit1 ? 1 : ((hit2 | (pf2 == 0u)) ? 2 : 0);
                 push = (res == 0);
-                e2.rem = rem2 - pf2;
+                e2.rem = rem3;
                 e2.ps = (ps2 * num2) * 0.33333334f;       // pmf at k = 3 (the 1/k table's 1/3)
                 e2.mp = mpp;
                 e2.q = qq;
+                pd2 = p2 | (((d2 + 4u * kMarginPerTerm) >> 8) << 16);   // margin of the terms k = 3..6
             }
-            deliver(p2, res);
         }
+        deliver(p2, res);
+        list_sample(give_up, p2);
         s1_top -= cnt;
         const unsigned long long m2 = __builtin_amdgcn_ballot_w64(push);
         if (push) {
             const int slot = s2_top + lane_rank(m2);
             L.s2[slot] = e2;
-            L.s2pos[slot] = p2;
+            L.s2pos[slot] = pd2;
         }
         s2_top += __popcll(m2);
-        const unsigned long long mh = __builtin_amdgcn_ballot_w64(heavy);
-        if (mh != 0ull) {
-            if (__builtin_amdgcn_ballot_w64(heavy & (hpend != kNoHeavy)) != 0ull) flush_heavy();
-            if (heavy) hpend = p2;
-        }
     };
 
     // ---- stage 1 over the strip ----------------------------------------------------------------
@@ -394,7 +460,12 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
     }
     while (s2_top > 0 || __builtin_amdgcn_ballot_w64(k != kIdle) != 0ull) stage3_pass();
     for (int cl = (cells > kRing ? cells - kRing : 0); cl < cells; ++cl) flush_row(cl, strip_out + (int64_t)cl * ld);
+    flush_late();
     if (__builtin_amdgcn_ballot_w64(hpend != kNoHeavy) != 0ull) flush_heavy();
+    if (lane == 0) {
+        heavy.count[region] = h_cnt < heavy.cap ? h_cnt : heavy.cap;
+        if (h_cnt > heavy.cap) heavy.overflow[0] = 1u;
+    }
 }
 
 }  // namespace k3

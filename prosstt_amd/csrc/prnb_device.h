@@ -16,11 +16,11 @@
 namespace prnb {
 
 constexpr float kLightT = 19.0f;       // inversion iff theta <= 16 and t = -log P(X=0) <= 19: P0 * 2^32 >= 24
-constexpr float kLightTheta = 16.0f;   // tail ratio <= 16/17: the walk ends far below the 1/k table's 1023 entries
+constexpr float kLightTheta = 16.0f;   // tail ratio <= 16/17: the walk ends far below the 1/k table's 511 entries
 constexpr float kThetaMin = 8.6736174e-19f;  // 2^-60
 constexpr float kThetaMax = 1.0e18f;
 constexpr float kRMin = 9.094947e-13f;       // 2^-40
-constexpr int kKTab = 1024;                  // entries of the 1/k table; the last one is a 0 sentinel
+constexpr int kKTab = 512;                   // entries of the 1/k table; the last one is a 0 sentinel (P(X >= 511) < 1e-10 in the inversion class)
 constexpr float kPoisInv = 10.0f;
 constexpr float kLamBig = 4194304.0f;        // 2^22
 constexpr int kMaxTries = 64;

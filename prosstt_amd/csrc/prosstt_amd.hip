@@ -619,24 +619,34 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
 {
     Staging st;
     SamplerArgs A{};
-    // room for the list of gamma-Poisson samples (one in 64 may be one before K3h has to classify
-    // the matrix itself), then one byte per row of the mean tensor for the domain check
+    // geometry of the streaming kernel: strips of 64 cells per wave (the kernel takes up to 128);
+    // shorter ones when the problem is too small to give every SIMD of the chip a few waves
     const bool tiled = (flags & PROSSTT_AMD_KERNEL_TILED) != 0;
-    const uint64_t samples = (uint64_t)(N > 0 ? N : 0) * (uint64_t)(G > 0 ? G : 0);
-    const uint64_t cap64 = samples / 64 + 4096;
-    const uint32_t heavy_cap = tiled ? 0u : (uint32_t)(cap64 < 0x7fffffffull ? cap64 : 0x7fffffffull);
-    const size_t list_bytes = (((size_t)heavy_cap * sizeof(k3::HeavyEntry)) + 255) & ~(size_t)255;
+    const int64_t tiles_g = ((int64_t)(G > 0 ? G : 0) + kTileG - 1) / kTileG;
+    int64_t strip_cells = k3::kStripCells / 2;    // 64: measured best on C3 (128: +1.7 %, 32: +2.7 %)
+    while (strip_cells > 8 && (((N > 0 ? N : 0) + strip_cells - 1) / strip_cells) * tiles_g < 4 * 5 * 1024) strip_cells /= 2;
+    const int64_t strips = ((N > 0 ? N : 0) + strip_cells - 1) / strip_cells;
+    const int64_t groups = (strips + 3) / 4;
+    // the list of samples left to K3h: every wave of the streaming kernel owns a region of it, with
+    // room for one in 16 of its samples (beyond that K3h redoes the matrix itself) and a count
+    const uint64_t regions = tiled ? 0 : (uint64_t)(groups * tiles_g) * 4u;
+    const uint32_t region_cap = (uint32_t)strip_cells * (kTileG / 16);
+    const size_t list_bytes = ((regions * (size_t)region_cap * 4u) + 255) & ~(size_t)255;
+    const size_t count_bytes = ((regions * 4u) + 255) & ~(size_t)255;
     const size_t rows_bytes = (((size_t)(rows > 0 ? rows : 0)) + 255) & ~(size_t)255;
     const size_t info_bytes = tiled ? 0 : ((size_t)(N > 0 ? N : 0) + 4) * sizeof(k3::CellInfo);
-    const size_t word_bytes = list_bytes + rows_bytes + info_bytes + 256;
+    const size_t word_bytes = list_bytes + count_bytes + rows_bytes + info_bytes + 256;
     int rc = sampler_setup(c, st, means, rows, G, row_of_cell, scaling, alpha, beta, N, flags, &A, word_bytes);
     if (rc) return rc;
     if (N == 0 || G == 0) return 0;
     if (!out) return fail(PROSSTT_AMD_EINVAL, "out is NULL");
-    k3::HeavyEntry* heavy_list = (k3::HeavyEntry*)A.extra;
-    uint8_t* rows_used = (uint8_t*)A.extra + list_bytes;
+    k3::HeavyList heavy;
+    heavy.list = (uint32_t*)A.extra;
+    heavy.count = (uint32_t*)((char*)A.extra + list_bytes);
+    heavy.overflow = (uint32_t*)(c->scratch + 3);           // zeroed with the flags below
+    heavy.cap = region_cap;
+    uint8_t* rows_used = (uint8_t*)A.extra + list_bytes + count_bytes;
     k3::CellInfo* cellinfo = (k3::CellInfo*)(rows_used + rows_bytes);
-    uint32_t* heavy_head = (uint32_t*)(c->scratch + 3);     // {appended, overflowed}: zeroed with the flags below
     if (ld_out < G) return fail(PROSSTT_AMD_EINVAL, "ld_out %lld < G %d", (long long)ld_out, G);
 
     if (cell_index && (flags & PROSSTT_AMD_HOST_INPUTS)) {
@@ -650,9 +660,8 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
         if ((rc = st.alloc(&p, (size_t)N * ld_out * 4))) return rc;
         d_out = (int32_t*)p;
     }
-    HIP_TRY(hipMemsetAsync(c->scratch, 0, 32, c->stream));   // [0] domain flag, [2] full-test request, [3] list head
+    HIP_TRY(hipMemsetAsync(c->scratch, 0, 32, c->stream));   // [0] domain flag, [2] full-test request, [3] list overflow
 
-    const int64_t tiles_g = ((int64_t)G + kTileG - 1) / kTileG;
     const bool vec = (G % 4 == 0) && (ld_out % 4 == 0) && (((uintptr_t)A.means & 15) == 0) &&
                      (((uintptr_t)d_out & 15) == 0);
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
@@ -676,13 +685,7 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
     } else {
         if (ld_out * k3::kStripCells >= ((int64_t)1 << 32))
             return fail(PROSSTT_AMD_EINVAL, "ld_out too large for 32-bit strip offsets");
-        // strips of 64 cells per wave (the kernel takes up to 128); shorter ones when the problem is too small to give
-        // every SIMD of the chip a few waves
-        int64_t strip_cells = k3::kStripCells / 2;    // 64: measured best on C3 (128: +1.7 %, 32: +2.7 %)
-        while (strip_cells > 8 && ((N + strip_cells - 1) / strip_cells) * tiles_g < 4 * 5 * 1024) strip_cells /= 2;
-        const int64_t strips = (N + strip_cells - 1) / strip_cells;
-        const int64_t groups = (strips + 3) / 4;
-        if (groups * tiles_g > 0x7fffffffll || N > 0x7fffffffll)
+        if (groups * tiles_g > 0x1fffffffll || N > 0x7fffffffll)
             return fail(PROSSTT_AMD_EINVAL, "too many tiles; chunk the cells");
         if ((uint64_t)rows * (uint64_t)G >= ((uint64_t)1 << 61)) return fail(PROSSTT_AMD_EINVAL, "mean tensor too large");
         cellinfo_kernel<<<dim3((unsigned)((N + 4 + 255) / 256)), dim3(256), 0, c->stream>>>(
@@ -692,17 +695,17 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
         if (vec)
             k3::sample_counts_stream_kernel<true><<<grid, block, 0, c->stream>>>(
                 A.means, G, cellinfo, A.ga, A.gbm1, A.gphi, N, k0, k1, d_out, ld_out, (int32_t)strips,
-                (int32_t)strip_cells, heavy_head, heavy_list, heavy_cap);
+                (int32_t)strip_cells, heavy);
         else
             k3::sample_counts_stream_kernel<false><<<grid, block, 0, c->stream>>>(
                 A.means, G, cellinfo, A.ga, A.gbm1, A.gphi, N, k0, k1, d_out, ld_out, (int32_t)strips,
-                (int32_t)strip_cells, heavy_head, heavy_list, heavy_cap);
+                (int32_t)strip_cells, heavy);
         HIP_TRY(hipGetLastError());
         if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, c->stream));   // the dominant kernel is timed alone
-        // every wave takes 64 list entries per step; waves beyond the list's end leave at once
+        // every wave takes whole regions of the list
         k3::sample_counts_heavy_kernel<<<dim3(2048), dim3(k3::kHeavyBlock), 0, c->stream>>>(
-            heavy_head, heavy_list, heavy_cap, A.means, G, A.row_of_cell, A.scal, A.ga, A.gbm1, N, k0, k1,
-            cell_offset, cell_index, d_out, ld_out);
+            heavy, (uint32_t)regions, (int32_t)strips, (int32_t)strip_cells, A.means, G, A.row_of_cell, A.scal, A.ga,
+            A.gbm1, N, k0, k1, cell_offset, cell_index, d_out, ld_out);
         ev_stop = nullptr;
         if (flags & PROSSTT_AMD_CHECK_DOMAIN) {
             HIP_TRY(hipMemsetAsync(rows_used, 0, (size_t)rows, c->stream));

@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""
+Timing-only variants of the K3 streaming kernel, built from a patched COPY of prosstt_amd/csrc
+(the shipped sources carry no experiment switches).  Each variant is a list of (old, new) text
+substitutions; outputs of these builds are wrong by construction, only their kernel time is read:
+
+    python tools/ablate.py [names...]          # builds build/ab/libprosstt_amd_<name>.so
+    PROSSTT_AMD_LIB=build/ab/libprosstt_amd_s1.so python tools/kbench.py C3
+
+Keeping the cut stages' inputs alive (asm volatile sinks) stops the compiler from deleting the
+work that feeds them.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "prosstt_amd", "csrc")
+OUT = os.path.join(ROOT, "build", "ab")
+
+RUN_23 = """        while (s1_top >= 64) {
+            stage2_pass();
+            while (s2_top >= kS2Run) stage3_pass();
+        }
+        cur = nxt;"""
+
+VARIANTS = {
+    "base": [],
+    # stage 1 only: survivors are pushed, then dropped
+    "s1": [(RUN_23, "        s1_top = 0;\n        cur = nxt;")],
+    # stages 1 + 2: what stage 2 pushes on S2 is dropped
+    "s12": [(RUN_23, "        while (s1_top >= 64) { stage2_pass(); s2_top = 0; }\n        cur = nxt;")],
+    # no late results (they are dropped instead of listed)
+    "nolate": [("        const unsigned long long ml = __builtin_amdgcn_ballot_w64((res > 0) & late);",
+                "        const unsigned long long ml = 0ull; asm volatile(\"\" :: \"v\"(late));")],
+    # stage 1 without the Philox call (a 2-instruction hash stands in)
+    "s1_nophilox": [(RUN_23, "        s1_top = 0;\n        cur = nxt;"),
+                    ("        const prnb::Words W = prnb::philox4x32_10<2>(c_lo, c_hi, (uint32_t)g0 >> 2, 0u, k0, k1);",
+                     "        prnb::Words W; W.w[0] = (c_lo * 2654435761u) ^ ((uint32_t)g0 * 40503u); W.w[1] = W.w[0] * 3u + k0;\n"
+                     "        W.w[2] = W.w[1] ^ 0x9E3779B9u; W.w[3] = W.w[2] + W.w[0];")],
+    # stage 1 without the S1 push
+    "s1_nopush": [(RUN_23, "        s1_top = 0;\n        cur = nxt;"),
+                  ('            asm volatile("s_mov_b64 exec, %0\\n\\tds_write_b128 %1, %2\\n\\ts_mov_b64 exec, -1"\n'
+                   '                         :: "s"(push_m), "v"(slot), "v"(e) : "memory");',
+                   '            asm volatile("" :: "s"(push_m), "v"(slot), "v"(e));')],
+    # stages 1 + 2 without the listing of given-up samples
+    "s12_nolist": [(RUN_23, "        while (s1_top >= 64) { stage2_pass(); s2_top = 0; }\n        cur = nxt;"),
+                   ("        list_sample(give_up, p2);", "        asm volatile(\"\" :: \"v\"((int)give_up));")],
+    # stages 1 + 2 with plain multiplies standing in for v_rcp / v_log / v_exp
+    "s12_nohw": [(RUN_23, "        while (s1_top >= 64) { stage2_pass(); s2_top = 0; }\n        cur = nxt;"),
+                 ("__builtin_amdgcn_rcpf(u1)", "(u1 * 0.3f)"), ("__builtin_amdgcn_rcpf(dm1)", "(dm1 * 0.7f)"),
+                 ("__builtin_amdgcn_logf(u1)", "(u1 * 0.9f)"), ("__builtin_amdgcn_exp2f(-t2)", "(t2 * 0.01f)")],
+    # stages 1 + 2 without deliver
+    "s12_nodeliver": [(RUN_23, "        while (s1_top >= 64) { stage2_pass(); s2_top = 0; }\n        cur = nxt;"),
+                      ("        deliver(p2, res);\n        list_sample(give_up, p2);", "        asm volatile(\"\" :: \"v\"(res), \"v\"(p2));\n        list_sample(give_up, p2);")],
+    # stage 1 without the push and with a small S1: 6 waves per SIMD instead of 4 (is stage 1 latency-bound?)
+    "s1_nopush_occ6": [(RUN_23, "        s1_top = 0;\n        cur = nxt;"),
+                       ('            asm volatile("s_mov_b64 exec, %0\\n\\tds_write_b128 %1, %2\\n\\ts_mov_b64 exec, -1"\n'
+                        '                         :: "s"(push_m), "v"(slot), "v"(e) : "memory");',
+                        '            asm volatile("" :: "s"(push_m), "v"(slot), "v"(e));'),
+                       ("constexpr int kS1Cap = 320;", "constexpr int kS1Cap = 16;"),
+                       ('static_assert(kS2Cap >= kS2Run - 1 + 64 && kS1Cap >= 63 + 256, "a stack must take one more pass of pushes");', "")],
+}
+
+
+def build(name):
+    work = os.path.join(OUT, "src_" + name)
+    shutil.rmtree(work, ignore_errors=True)
+    shutil.copytree(SRC, os.path.join(work, "prosstt_amd", "csrc"))
+    shutil.copytree(os.path.join(ROOT, "include"), os.path.join(work, "include"))
+    for fn in ("k3_stream.h",):
+        path = os.path.join(work, "prosstt_amd", "csrc", fn)
+        text = open(path).read()
+        for old, new in VARIANTS[name]:
+            if old not in text:
+                raise SystemExit("variant %s: anchor not found:\n%s" % (name, old))
+            text = text.replace(old, new)
+        open(path, "w").write(text)
+    lib = os.path.join(OUT, "libprosstt_amd_%s.so" % name)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                           "-fPIC", "-shared", "-fvisibility=hidden", "-o", lib,
+                           os.path.join(work, "prosstt_amd", "csrc", "prosstt_amd.hip")])
+    shutil.rmtree(work, ignore_errors=True)
+    return lib
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    for n in (sys.argv[1:] or list(VARIANTS)):
+        print("built", build(n))
