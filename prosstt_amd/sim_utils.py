@@ -113,21 +113,24 @@ def diverging_parallel(branches, programs, genes, tol=0.5):
 
 
 def commited_branches(tree, branches, rel_means):
-    """Blend two sibling branches over their first common timezone (sim_utils.py:255-271)."""
-    b1, b2 = branches
-    timezones = tree.populate_timezone()
-    assignments = assign_branches(tree.branch_times(), timezones)
-    matches = np.min(np.where([a == branches for a in assignments.values()]))
-    offsets = np.array([tree.branch_times()[b][0] for b in branches])
-    mix = np.array(timezones[matches]) - offsets
-    mix_range = np.arange(mix[0], mix[1] + 1)
-    other = np.arange(0, 0.5, 1 / (2 * len(mix_range)))[::-1]
-    own = 1 - other
-    first = ((own * rel_means[b1][mix_range].transpose()) +
-             (other * rel_means[b2][mix_range].transpose())).transpose()
-    rel_means[b1] = first
-    rel_means[b2] = ((own * rel_means[b2][mix_range].transpose()) +
-                     (other * rel_means[b1][mix_range].transpose())).transpose()
+    """Blend two sibling branches into each other over the first timezone they share
+    (sim_utils.py:255-271).  The weight of the sibling falls linearly from just under 1/2 at the
+    start of the zone to 0 at its end.  As in the reference, both branches are cut down to the
+    zone's steps, the zone is located with the first branch's start on its left edge and the
+    second branch's start on its right edge, and the second branch is blended with the ALREADY
+    blended first one."""
+    first, second = branches
+    zones = tree.populate_timezone()
+    owners = assign_branches(tree.branch_times(), zones)
+    shared = min(i for i, who in enumerate(owners.values()) if who == branches)
+    starts = tree.branch_times()
+    lo = zones[shared][0] - starts[first][0]
+    hi = zones[shared][1] - starts[second][0]
+    steps = np.arange(lo, hi + 1)
+    w_sibling = np.arange(0, 0.5, 1 / (2 * len(steps)))[::-1][:, None]
+    w_own = 1 - w_sibling
+    rel_means[first] = w_own * rel_means[first][steps] + w_sibling * rel_means[second][steps]
+    rel_means[second] = w_own * rel_means[second][steps] + w_sibling * rel_means[first][steps]
     return rel_means
 
 
@@ -247,20 +250,21 @@ def calc_scalings(cells, scale=True, scale_mean=0, scale_v=0.7):
 
 
 def process_timeseries_input(series_points, cells, point_std):
-    """Broadcast the arguments of sample_pseudotime_series (sim_utils.py:501-542); a scalar
-    ``point_std`` is divided by the number of sample points, as in the reference (:536-537)."""
-    no_samples = len(series_points)
-    if isinstance(cells, collections.abc.Iterable):
-        cells = np.array(cells, dtype=int)
-    elif isinstance(cells, numbers.Number):
-        cells = np.array([cells / no_samples] * no_samples, dtype=int)
-    if isinstance(point_std, collections.abc.Iterable):
-        point_std = np.array(point_std, dtype=float)
-    elif isinstance(point_std, numbers.Number):
-        point_std = np.array([point_std / no_samples] * no_samples, dtype=float)
+    """Arguments of sample_pseudotime_series as three arrays of one length (sim_utils.py:501-542).
+    A total cell count is split evenly over the sample points (truncating); a scalar ``point_std``
+    is DIVIDED by the number of sample points, as in the reference (:536-537)."""
+    n_points = len(series_points)
+
+    def per_point(value, dtype):
+        if isinstance(value, collections.abc.Iterable):
+            return np.array(value, dtype=dtype)
+        if isinstance(value, numbers.Number):
+            return np.full(n_points, value / n_points).astype(dtype)
+        return value
+
     if not isinstance(series_points, np.ndarray):
         series_points = np.array(series_points, dtype=int)
-    return series_points, cells, point_std
+    return series_points, per_point(cells, int), per_point(point_std, float)
 
 
 def breadth_first_branches(tree):
@@ -314,16 +318,19 @@ def find_parallel(tree, programs, branch):
 
 
 def learn_data_summary(cell_stats, gene_stats, relative_means):
-    """Hyper-parameters from summaries of a real dataset (sim_utils.py:670-719)."""
-    real_scalings = np.log(cell_stats.loc["total"] / np.mean(cell_stats.loc["total"]))
-    scale_mean = np.mean(real_scalings)
-    scale_var = np.sqrt(np.var(real_scalings))
-    nonzero = (gene_stats.loc['var'] > 0) & (gene_stats.loc['means'] > 0)
-    fit = np.polyfit(x=gene_stats.loc['means'][nonzero], y=gene_stats.loc['var'][nonzero], deg=2,
-                     w=1 / gene_stats.loc['var'][nonzero])
-    rel_expr = np.array([relative_means[b] for b in relative_means.index])
-    avg_relative_expr = np.mean(np.mean(np.exp(rel_expr), axis=1), axis=0)
-    proposed_means = gene_stats.loc['means'][nonzero]
-    avg_relative_expr[avg_relative_expr < np.min(proposed_means)] = np.min(proposed_means)
-    proposed_means = proposed_means / avg_relative_expr
-    return [scale_mean, scale_var], np.log(fit[0]), np.log(fit[1] - 1), np.array(proposed_means)
+    """Hyper-parameters that make a simulation resemble a real dataset's summaries
+    (sim_utils.py:670-719): library-size distribution [mean, sd] of log(total / mean total);
+    log alpha and log(beta - 1) from the weighted quadratic fit var ~ alpha*mean^2 + beta*mean + c
+    over the genes with positive mean and variance; base expression = observed mean / average
+    relative expression along the tree (floored at the smallest observed mean)."""
+    totals = np.asarray(cell_stats.loc["total"], dtype=float)
+    log_size = np.log(totals / totals.mean())
+    observed_mean, observed_var = gene_stats.loc["means"], gene_stats.loc["var"]
+    informative = (observed_var > 0) & (observed_mean > 0)
+    quad, lin, _ = np.polyfit(observed_mean[informative], observed_var[informative], 2,
+                              w=1 / observed_var[informative])
+    along_tree = np.exp(np.array([relative_means[b] for b in relative_means.index]))   # (branches, T, G)
+    avg_relative = along_tree.mean(axis=1).mean(axis=0)
+    base = observed_mean[informative]
+    avg_relative[avg_relative < base.min()] = base.min()
+    return [log_size.mean(), log_size.std()], np.log(quad), np.log(lin - 1), np.array(base / avg_relative)

@@ -234,10 +234,11 @@ def _plain_label(tree, label):
 def sample_whole_tree_restricted(tree, alpha=0.2, beta=3, **device_opts):
     """Default one-shot simulation (simulation.py:289-316); returns 4 values like the
     reference does (its docstring lists 3)."""
-    sample_time = np.arange(0, tree.get_max_time())
+    # one cell per pseudotime step; the stream order is: lineage, base expression, alpha/beta, branches, scalings
     tree.default_gene_expression()
-    alphas, betas = cm.generate_negbin_params(tree, mean_alpha=alpha, mean_beta=beta)
-    return _sample_data_at_times(tree, sample_time, alpha=alphas, beta=betas, **device_opts)
+    per_gene = cm.generate_negbin_params(tree, mean_alpha=alpha, mean_beta=beta)
+    return _sample_data_at_times(tree, np.arange(tree.get_max_time()), alpha=per_gene[0], beta=per_gene[1],
+                                 **device_opts)
 
 
 def sample_pseudotime_series(tree, cells, series_points, point_std, alpha=0.3, beta=2, scale=True,
@@ -303,16 +304,13 @@ def cover_whole_tree(tree):
 def _sample_data_at_times(tree, sample_pt, branches=None, alpha=0.3, beta=2, scale=True,
                           scale_mean=0., scale_v=0.7, **device_opts):
     """Counts for cells at given pseudotimes (simulation.py:551-599)."""
-    no_cells = len(sample_pt)
-    if np.shape(alpha) == ():
-        alpha = [alpha] * tree.G
-    if np.shape(beta) == ():
-        beta = [beta] * tree.G
+    # scalar hyper-parameters apply to every gene; branches are drawn before the scalings (stream order)
+    alpha, beta = (np.full(tree.G, v) if np.ndim(v) == 0 else v for v in (alpha, beta))
     if branches is None:
         branches = sut.pick_branches(tree, sample_pt)
-    scalings = sut.calc_scalings(no_cells, scale, scale_mean, scale_v)
-    expr_matrix = draw_counts(tree, sample_pt, branches, scalings, alpha, beta, **device_opts)
-    return expr_matrix, sample_pt, branches, scalings
+    scalings = sut.calc_scalings(len(sample_pt), scale, scale_mean, scale_v)
+    counts = draw_counts(tree, sample_pt, branches, scalings, alpha, beta, **device_opts)
+    return counts, sample_pt, branches, scalings
 
 
 def cell_rows(tree, pseudotime, branches):

@@ -268,6 +268,37 @@ def g8_end_to_end():
          H=H.astype(np.float64), rel_E=rel["E"], total=int(X.sum()))
 
 
+# --------------------------------------------------------------------- G9
+def g9_helpers():
+    """commited_branches, process_timeseries_input, learn_data_summary (sim_utils.py:255-271, 501-542,
+    670-719) on small inputs."""
+    import pandas as pd
+    out = {}
+    rng = np.random.default_rng(9)
+    # commited_branches: the two children of a bifurcation, blended over their common timezone
+    spec = TREES["bifurcation"]
+    t = build_tree(spec, 6, 4)
+    rel = pd.Series({b: rng.normal(size=(spec["time"][b], 6)) for b in "ABC"})
+    out.update({"cb_in_%s" % b: rel[b].copy() for b in "ABC"})
+    res = rsut.commited_branches(t, ["B", "C"], rel.copy())
+    out.update({"cb_out_%s" % b: np.asarray(res[b]) for b in "ABC"})
+    # process_timeseries_input: scalar and list forms
+    cases = [([5, 30, 60], 100, 6.0), ([10, 20], [30, 50], [2.0, 3.5]), (np.array([7, 8, 9, 10]), 33, [1.0, 2.0, 3.0, 4.0])]
+    for i, (pts, cells, std) in enumerate(cases):
+        a, b, c = rsut.process_timeseries_input(pts, cells, std)
+        out.update({"ts%d_points" % i: a, "ts%d_cells" % i: b, "ts%d_std" % i: c})
+    # learn_data_summary: summaries of a small synthetic count matrix
+    G, N = 12, 40
+    X = rng.negative_binomial(3, 0.3, size=(N, G)).astype(float)
+    cell_stats = pd.DataFrame({"total": X.sum(axis=1), "zeros": (X == 0).sum(axis=1)}).T
+    gene_stats = pd.DataFrame({"means": X.mean(axis=0), "var": X.var(axis=0), "zeros": (X == 0).sum(axis=0)}).T
+    relm = pd.Series({b: rng.normal(scale=0.3, size=(15, G)) for b in "ABC"})
+    scale, la, lb, prop = rsut.learn_data_summary(cell_stats, gene_stats, relm)
+    out.update(ld_X=X, ld_scale=np.array(scale), ld_alpha=np.array(la), ld_beta=np.array(lb), ld_means=prop)
+    out.update({"ld_rel_%s" % b: relm[b] for b in "ABC"})
+    save("g9_helpers", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:                      # regenerate selected fixtures only, e.g. `make_golden.py g7_nb_tables`
         for name in sys.argv[1:]:
@@ -280,4 +311,5 @@ if __name__ == "__main__":
     g5_topology()
     g6_sampling()
     g7_nb_tables()
+    g9_helpers()
     g8_end_to_end()

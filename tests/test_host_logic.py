@@ -273,3 +273,34 @@ def test_from_newick():
     assert [str(b) for b in sut.breadth_first_branches(t)] == ["A", "B", "E", "C", "D"]
     with pytest.raises(ValueError):
         ptree.Tree.from_newick("((C,D)B,E;")
+
+
+def test_helpers_against_reference_fixtures():
+    """commited_branches, process_timeseries_input, learn_data_summary against outputs of the
+    reference (fixture g9, tests/golden/make_golden.py)."""
+    import pandas as pd
+    from prosstt_amd import sim_utils as sut
+    from prosstt_amd.tree import Tree
+    g = load_golden("g9_helpers")
+    t = Tree(topology=[["A", "B"], ["A", "C"]], time={"A": 40, "B": 40, "C": 40}, num_branches=3,
+             branch_points=1, modules=4, G=6)
+    rel = pd.Series({b: g["cb_in_%s" % b].copy() for b in "ABC"})
+    out = sut.commited_branches(t, ["B", "C"], rel)
+    for b in "ABC":
+        np.testing.assert_array_equal(np.asarray(out[b]), g["cb_out_%s" % b])
+    cases = [([5, 30, 60], 100, 6.0), ([10, 20], [30, 50], [2.0, 3.5]), (np.array([7, 8, 9, 10]), 33, [1.0, 2.0, 3.0, 4.0])]
+    for i, (pts, cells, std) in enumerate(cases):
+        a, b, c = sut.process_timeseries_input(pts, cells, std)
+        for got, key in ((a, "points"), (b, "cells"), (c, "std")):
+            want = g["ts%d_%s" % (i, key)]
+            assert got.dtype == want.dtype
+            np.testing.assert_array_equal(got, want)
+    X = g["ld_X"]
+    cell_stats = pd.DataFrame({"total": X.sum(axis=1), "zeros": (X == 0).sum(axis=1)}).T
+    gene_stats = pd.DataFrame({"means": X.mean(axis=0), "var": X.var(axis=0), "zeros": (X == 0).sum(axis=0)}).T
+    relm = pd.Series({b: g["ld_rel_%s" % b] for b in "ABC"})
+    scale, la, lb, prop = sut.learn_data_summary(cell_stats, gene_stats, relm)
+    np.testing.assert_allclose(scale, g["ld_scale"], rtol=1e-12)
+    np.testing.assert_allclose(la, g["ld_alpha"], rtol=1e-10)
+    np.testing.assert_allclose(lb, g["ld_beta"], rtol=1e-10)
+    np.testing.assert_allclose(prop, g["ld_means"], rtol=1e-12)

@@ -54,6 +54,28 @@ VARIANTS = {
     # stages 1 + 2 without deliver
     "s12_nodeliver": [(RUN_23, "        while (s1_top >= 64) { stage2_pass(); s2_top = 0; }\n        cur = nxt;"),
                       ("        deliver(p2, res);\n        list_sample(give_up, p2);", "        asm volatile(\"\" :: \"v\"(res), \"v\"(p2));\n        list_sample(give_up, p2);")],
+    # stage 1 only, rows not stored (pure issue time of stage 1)
+    "s1_nostore": [(RUN_23, "        s1_top = 0;\n        cur = nxt;"),
+                   ("        if (g0 < G) {\n            if (VEC) {", "        if (g0 < G && v[0] == 12345) {\n            if (VEC) {")],
+    "s1_nostore_nophilox": [(RUN_23, "        s1_top = 0;\n        cur = nxt;"),
+                   ("        if (g0 < G) {\n            if (VEC) {", "        if (g0 < G && v[0] == 12345) {\n            if (VEC) {"),
+                   ("        const prnb::Words W = prnb::philox4x32_10<2>(c_lo, c_hi, (uint32_t)g0 >> 2, 0u, k0, k1);",
+                    "        prnb::Words W; W.w[0] = (c_lo * 2654435761u) ^ ((uint32_t)g0 * 40503u); W.w[1] = W.w[0] * 3u + k0;\n"
+                    "        W.w[2] = W.w[1] ^ 0x9E3779B9u; W.w[3] = W.w[2] + W.w[0];")],
+    # everything, rows not stored
+    "nostore": [("        if (g0 < G) {\n            if (VEC) {", "        if (g0 < G && v[0] == 12345) {\n            if (VEC) {")],
+    # K3h without the redo walks / without the gamma-Poisson samples
+    "k3h_noredo": [("            light = P.valid && P.light;\n", "            light = false;\n")],
+    "k3h_noheavy": [("            heavy = P.valid && !P.light;\n", "            heavy = false;\n")],
+    "k3h_none": [("            light = P.valid && P.light;\n", "            light = false;\n"), ("            heavy = P.valid && !P.light;\n", "            heavy = false;\n")],
+    "k3h_grid256": [("k3::sample_counts_heavy_kernel<<<dim3(2048),", "k3::sample_counts_heavy_kernel<<<dim3(256),")],
+    "k3h_grid512": [("k3::sample_counts_heavy_kernel<<<dim3(2048),", "k3::sample_counts_heavy_kernel<<<dim3(512),")],
+    "k3h_grid1024": [("k3::sample_counts_heavy_kernel<<<dim3(2048),", "k3::sample_counts_heavy_kernel<<<dim3(1024),")],
+    # real variants (correct results): tuning constants
+    "run16": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 16;")],
+    "run48": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 48;"), ("constexpr int kS2Cap = 96;", "constexpr int kS2Cap = 112;")],
+    "strip128": [("int64_t strip_cells = k3::kStripCells / 2;", "int64_t strip_cells = k3::kStripCells;")],
+    "strip32": [("int64_t strip_cells = k3::kStripCells / 2;", "int64_t strip_cells = k3::kStripCells / 4;")],
     # stage 1 without the push and with a small S1: 6 waves per SIMD instead of 4 (is stage 1 latency-bound?)
     "s1_nopush_occ6": [(RUN_23, "        s1_top = 0;\n        cur = nxt;"),
                        ('            asm volatile("s_mov_b64 exec, %0\\n\\tds_write_b128 %1, %2\\n\\ts_mov_b64 exec, -1"\n'
@@ -69,14 +91,16 @@ def build(name):
     shutil.rmtree(work, ignore_errors=True)
     shutil.copytree(SRC, os.path.join(work, "prosstt_amd", "csrc"))
     shutil.copytree(os.path.join(ROOT, "include"), os.path.join(work, "include"))
-    for fn in ("k3_stream.h",):
-        path = os.path.join(work, "prosstt_amd", "csrc", fn)
-        text = open(path).read()
-        for old, new in VARIANTS[name]:
-            if old not in text:
-                raise SystemExit("variant %s: anchor not found:\n%s" % (name, old))
-            text = text.replace(old, new)
-        open(path, "w").write(text)
+    files = {fn: open(os.path.join(work, "prosstt_amd", "csrc", fn)).read()
+             for fn in ("k3_stream.h", "k3_heavy.h", "prnb_device.h", "prosstt_amd.hip")}
+    for old, new in VARIANTS[name]:
+        hits = [fn for fn, text in files.items() if old in text]
+        if not hits:
+            raise SystemExit("variant %s: anchor not found:\n%s" % (name, old))
+        for fn in hits:
+            files[fn] = files[fn].replace(old, new)
+    for fn, text in files.items():
+        open(os.path.join(work, "prosstt_amd", "csrc", fn), "w").write(text)
     lib = os.path.join(OUT, "libprosstt_amd_%s.so" % name)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                            "-fPIC", "-shared", "-fvisibility=hidden", "-o", lib,
