@@ -114,6 +114,19 @@ int prosstt_amd_lineage_attempt(prosstt_amd_ctx* ctx, const double* programs, in
                                 double* out_max, int64_t* out_anticorr);
 
 /*
+ * B attempts of the same branch in one launch (the loop of simulation.py:264-282 evaluated a
+ * batch at a time: the host draws the B candidate programs in the reference's stream order,
+ * takes the first accepted one and rewinds its generator to just behind it).
+ *   programs      HOST [B][T][K]
+ *   out_max       HOST [B];   out_anticorr  HOST [B][n_sib]
+ * Everything else as prosstt_amd_lineage_attempt.
+ */
+int prosstt_amd_lineage_attempt_batch(prosstt_amd_ctx* ctx, const double* programs, int32_t B, int32_t T,
+                                      int32_t K, const double* H, int64_t G, int32_t n_sib,
+                                      const double* const* sib_programs, const int32_t* sib_T,
+                                      double* out_max, int64_t* out_anticorr);
+
+/*
  * Device-mode expression programs (K1): the K random walks of one branch attempt,
  * simulation.sim_expr_branch / diffusion (simulation.py:21-124), drawn on the device from
  * Philox streams instead of numpy's global stream (walk definition PRLW-1).

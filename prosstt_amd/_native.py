@@ -20,7 +20,8 @@ SYMBOLS = [
     "prosstt_amd_version", "prosstt_amd_last_error", "prosstt_amd_device_count",
     "prosstt_amd_ctx_create", "prosstt_amd_ctx_destroy", "prosstt_amd_ctx_synchronize",
     "prosstt_amd_last_kernel_ms", "prosstt_amd_sample_counts", "prosstt_amd_nb_params",
-    "prosstt_amd_lineage_attempt", "prosstt_amd_lineage_walk", "prosstt_amd_lineage_commit",
+    "prosstt_amd_lineage_attempt", "prosstt_amd_lineage_attempt_batch", "prosstt_amd_lineage_walk",
+    "prosstt_amd_lineage_commit",
     "prosstt_amd_gene_max",
     "prosstt_amd_means_from_rel",
 ]
@@ -66,6 +67,7 @@ def load():
                                                 vp, vp, i64, u32]
         L.prosstt_amd_nb_params.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp, u32]
         L.prosstt_amd_lineage_attempt.argtypes = [vp, vp, i32, i32, vp, i64, i32, vp, vp, vp, vp]
+        L.prosstt_amd_lineage_attempt_batch.argtypes = [vp, vp, i32, i32, i32, vp, i64, i32, vp, vp, vp, vp]
         L.prosstt_amd_lineage_walk.argtypes = [vp, u64, u64, i32, i32, vp]
         L.prosstt_amd_lineage_commit.argtypes = [vp, vp, i32, i32, vp, i64, vp, vp]
         L.prosstt_amd_gene_max.argtypes = [vp, vp, i64, i64, vp]

@@ -305,9 +305,13 @@ template <bool HREG>
 __global__ __launch_bounds__(256) void lineage_attempt_kernel(
     const double* __restrict__ progs, const int32_t* __restrict__ meta, int32_t T, int32_t K,
     const double* __restrict__ H, int64_t G, unsigned long long* __restrict__ max_bits,
-    unsigned long long* __restrict__ anticorr)
+    unsigned long long* __restrict__ anticorr, int64_t attempt_stride, int32_t result_stride)
 {
     __shared__ double part[kLinChunks][64][3];
+    // attempt blockIdx.y of a batch: its own block of programs and its own result words
+    progs += (int64_t)blockIdx.y * attempt_stride;
+    max_bits += (int64_t)blockIdx.y * result_stride;
+    anticorr += (int64_t)blockIdx.y * result_stride;
     const int gl = threadIdx.x & 63, c = threadIdx.x >> 6;
     const int64_t g = (int64_t)blockIdx.x * 64 + gl;
     const bool live = g < G;
@@ -773,50 +777,79 @@ static void centred(const double* src, int steps, int K, double* dst)
     }
 }
 
+// One launch for B attempts of a branch.  Device layout per attempt (stride = `per` doubles):
+// raw programs [T][K], then per sibling the centred current and sibling series (see the kernel);
+// results: per attempt (1 + n_sib) words {max bits, anticorrelated-gene counts}.
+PA_EXPORT int prosstt_amd_lineage_attempt_batch(prosstt_amd_ctx* c, const double* programs, int32_t B, int32_t T,
+                                                int32_t K, const double* H, int64_t G, int32_t n_sib,
+                                                const double* const* sib_programs, const int32_t* sib_T,
+                                                double* out_max, int64_t* out_anticorr)
+{
+    if (!c || !programs || !H || !out_max) return fail(PROSSTT_AMD_EINVAL, "NULL argument");
+    if (B <= 0 || T <= 0 || K <= 0 || G <= 0 || n_sib < 0) return fail(PROSSTT_AMD_EINVAL, "bad size");
+    if (B > 65535) return fail(PROSSTT_AMD_EINVAL, "more than 65535 attempts in a batch");
+    if (n_sib > 64) return fail(PROSSTT_AMD_EINVAL, "more than 64 siblings");
+    if (n_sib && (!sib_programs || !sib_T || !out_anticorr)) return fail(PROSSTT_AMD_EINVAL, "NULL sibling argument");
+    HIP_TRY(hipSetDevice(c->device));
+
+    std::vector<int32_t> meta(1 + n_sib);
+    meta[0] = n_sib;
+    size_t per = (size_t)T * K;
+    for (int j = 0; j < n_sib; ++j) {
+        if (sib_T[j] <= 0 || !sib_programs[j]) return fail(PROSSTT_AMD_EINVAL, "bad sibling %d", j);
+        meta[1 + j] = T < sib_T[j] ? T : sib_T[j];
+        per += 2 * (size_t)meta[1 + j] * K;
+    }
+    std::vector<double> host(per * (size_t)B);
+    for (int b = 0; b < B; ++b) {
+        const double* cur = programs + (size_t)b * T * K;
+        double* base = host.data() + per * (size_t)b;
+        memcpy(base, cur, sizeof(double) * T * K);
+        size_t at = (size_t)T * K;                                   // offset inside an attempt's block
+        for (int j = 0; j < n_sib; ++j) {
+            const size_t len = (size_t)meta[1 + j] * K;
+            centred(cur, meta[1 + j], K, base + at);
+            if (b == 0) centred(sib_programs[j], meta[1 + j], K, base + at + len);
+            else memcpy(base + at + len, host.data() + at + len, sizeof(double) * len);   // the same for every attempt
+            at += 2 * len;
+        }
+    }
+    const int32_t words = 1 + n_sib;
+    const size_t prog_bytes = host.size() * 8, meta_bytes = (meta.size() * 4 + 7) & ~(size_t)7;
+    const size_t res_bytes = (size_t)B * words * 8;
+    int rc = ws_reserve(c, prog_bytes + meta_bytes + res_bytes);
+    if (rc) return rc;
+    double* d_prog = (double*)c->ws;
+    int32_t* d_meta = (int32_t*)((char*)c->ws + prog_bytes);
+    unsigned long long* d_res = (unsigned long long*)((char*)c->ws + prog_bytes + meta_bytes);
+    HIP_TRY(hipMemcpyAsync(d_prog, host.data(), prog_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_meta, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(d_res, 0, res_bytes, c->stream));   // ordered_bits(x) > 0 for every x
+    const dim3 grid((unsigned)((G + 63) / 64), (unsigned)B);
+    if (K <= 32)
+        lineage_attempt_kernel<true><<<grid, dim3(256), 0, c->stream>>>(d_prog, d_meta, T, K, H, G, d_res, d_res + 1,
+                                                                       (int64_t)per, words);
+    else
+        lineage_attempt_kernel<false><<<grid, dim3(256), 0, c->stream>>>(d_prog, d_meta, T, K, H, G, d_res, d_res + 1,
+                                                                        (int64_t)per, words);
+    HIP_TRY(hipGetLastError());
+    std::vector<unsigned long long> res((size_t)B * words);
+    HIP_TRY(hipMemcpyAsync(res.data(), d_res, res_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));   // also keeps `host` alive until the H2D copies are done
+    for (int b = 0; b < B; ++b) {
+        out_max[b] = from_ordered_bits(res[(size_t)b * words]);
+        for (int j = 0; j < n_sib; ++j) out_anticorr[(size_t)b * n_sib + j] = (int64_t)res[(size_t)b * words + 1 + j];
+    }
+    return 0;
+}
+
 PA_EXPORT int prosstt_amd_lineage_attempt(prosstt_amd_ctx* c, const double* programs, int32_t T, int32_t K,
                                           const double* H, int64_t G, int32_t n_sib,
                                           const double* const* sib_programs, const int32_t* sib_T,
                                           double* out_max, int64_t* out_anticorr)
 {
-    if (!c || !programs || !H || !out_max) return fail(PROSSTT_AMD_EINVAL, "NULL argument");
-    if (T <= 0 || K <= 0 || G <= 0 || n_sib < 0) return fail(PROSSTT_AMD_EINVAL, "bad size");
-    if (n_sib > 64) return fail(PROSSTT_AMD_EINVAL, "more than 64 siblings");
-    if (n_sib && (!sib_programs || !sib_T || !out_anticorr)) return fail(PROSSTT_AMD_EINVAL, "NULL sibling argument");
-    HIP_TRY(hipSetDevice(c->device));
-
-    std::vector<double> host((size_t)T * K);
-    std::vector<int32_t> meta(1 + n_sib);
-    memcpy(host.data(), programs, sizeof(double) * T * K);
-    meta[0] = n_sib;
-    for (int j = 0; j < n_sib; ++j) {
-        if (sib_T[j] <= 0 || !sib_programs[j]) return fail(PROSSTT_AMD_EINVAL, "bad sibling %d", j);
-        const int common = T < sib_T[j] ? T : sib_T[j];
-        meta[1 + j] = common;
-        const size_t at = host.size();
-        host.resize(at + 2 * (size_t)common * K);
-        centred(programs, common, K, host.data() + at);
-        centred(sib_programs[j], common, K, host.data() + at + (size_t)common * K);
-    }
-    const size_t prog_bytes = host.size() * 8, meta_bytes = (meta.size() * 4 + 7) & ~(size_t)7;
-    int rc = ws_reserve(c, prog_bytes + meta_bytes);
-    if (rc) return rc;
-    double* d_prog = (double*)c->ws;
-    int32_t* d_meta = (int32_t*)((char*)c->ws + prog_bytes);
-    HIP_TRY(hipMemcpyAsync(d_prog, host.data(), prog_bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(d_meta, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemsetAsync(c->scratch, 0, 128 * 8, c->stream));   // ordered_bits(x) > 0 for every x
-    if (K <= 32)
-        lineage_attempt_kernel<true><<<dim3((unsigned)((G + 63) / 64)), dim3(256), 0, c->stream>>>(
-            d_prog, d_meta, T, K, H, G, (unsigned long long*)c->scratch + 1, (unsigned long long*)c->scratch + 2);
-    else
-        lineage_attempt_kernel<false><<<dim3((unsigned)((G + 63) / 64)), dim3(256), 0, c->stream>>>(
-            d_prog, d_meta, T, K, H, G, (unsigned long long*)c->scratch + 1, (unsigned long long*)c->scratch + 2);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(c->h_scratch, c->scratch, (2 + n_sib) * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));   // also keeps `host` alive until the H2D copies are done
-    *out_max = from_ordered_bits((unsigned long long)c->h_scratch[1]);
-    for (int j = 0; j < n_sib; ++j) out_anticorr[j] = c->h_scratch[2 + j];
-    return 0;
+    return prosstt_amd_lineage_attempt_batch(c, programs, 1, T, K, H, G, n_sib, sib_programs, sib_T, out_max,
+                                             out_anticorr);
 }
 
 PA_EXPORT int prosstt_amd_lineage_walk(prosstt_amd_ctx* c, uint64_t seed, uint64_t stream_id, int32_t T,

@@ -125,24 +125,31 @@ class Context:
         return mu, p, r, path
 
     # ---- K2: lineage ---------------------------------------------------------
-    def lineage_attempt(self, programs, H, sib_programs=()):
-        """(max(programs@H), [#genes with r<0 per sibling]) -- simulation.py:269-272."""
+    def lineage_attempt_batch(self, programs, H, sib_programs=()):
+        """B attempts of one branch in one launch: ``programs`` is (B, T, K); returns
+        (max(programs[b]@H) as (B,) float64, #genes with r<0 per sibling as (B, n_sib) int64)
+        -- simulation.py:269-272 per attempt."""
         programs = np.ascontiguousarray(programs, np.float64)
-        T, K = programs.shape
+        B, T, K = programs.shape
         sibs = [np.ascontiguousarray(s, np.float64) for s in sib_programs]
         n = len(sibs)
-        ptrs = (ctypes.c_void_p * max(n, 1))(*[s.ctypes.data for s in sibs])
-        lens = (ctypes.c_int32 * max(n, 1))(*[s.shape[0] for s in sibs])
         for s in sibs:
             if s.shape[1] != K:
                 raise ValueError("sibling programs must have %d columns" % K)
-        mx = ctypes.c_double(0)
-        counts = (ctypes.c_int64 * max(n, 1))()
-        _native.check(self._lib.prosstt_amd_lineage_attempt(
-            self._h, programs.ctypes.data_as(ctypes.c_void_p), T, K, _ptr(H), H.shape[1], n,
+        ptrs = (ctypes.c_void_p * max(n, 1))(*[s.ctypes.data for s in sibs])
+        lens = (ctypes.c_int32 * max(n, 1))(*[s.shape[0] for s in sibs])
+        top = np.empty(B, np.float64)
+        counts = np.zeros((B, max(n, 1)), np.int64)
+        _native.check(self._lib.prosstt_amd_lineage_attempt_batch(
+            self._h, programs.ctypes.data_as(ctypes.c_void_p), B, T, K, _ptr(H), H.shape[1], n,
             ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(lens, ctypes.c_void_p),
-            ctypes.cast(ctypes.byref(mx), ctypes.c_void_p), ctypes.cast(counts, ctypes.c_void_p)))
-        return mx.value, [int(counts[j]) for j in range(n)]
+            top.ctypes.data_as(ctypes.c_void_p), counts.ctypes.data_as(ctypes.c_void_p)))
+        return top, counts[:, :n]
+
+    def lineage_attempt(self, programs, H, sib_programs=()):
+        """(max(programs@H), [#genes with r<0 per sibling]) -- simulation.py:269-272."""
+        top, counts = self.lineage_attempt_batch(np.asarray(programs, np.float64)[None], H, sib_programs)
+        return float(top[0]), [int(c) for c in counts[0]]
 
     def lineage_walk(self, seed, stream_id, T, K):
         """(T, K) float64 expression programs drawn on the device (K1, PRLW-1)."""

@@ -149,18 +149,20 @@ def _device_gene_max(tree, relative_means):
 
 
 def simulate_lineage(tree, rel_exp_cutoff=8, intra_branch_tol=0.5, inter_branch_tol=0,
-                     *, max_attempts=None, stats=None, rng="numpy", seed=None, **kwargs):
+                     *, max_attempts=None, stats=None, rng="numpy", seed=None, batch=16, **kwargs):
     """Relative mean expression of every gene at every point of the tree
     (simulation.py:215-286).
 
     Returns ``(pd.Series rel_means, pd.Series programs, coefficients)`` like the
     reference.  Per branch, in breadth-first order, programs are redrawn until
     ``max(programs @ H) <= rel_exp_cutoff`` and more than ``inter_branch_tol`` of
-    the genes are anticorrelated with every already-simulated sibling.  Each
-    attempt costs one ``lineage_attempt`` kernel (no (T, G) matrix is formed) and
-    two scalars back; the accepted branch is materialised once by ``lineage_commit``.
+    the genes are anticorrelated with every already-simulated sibling.  ``batch``
+    attempts are evaluated by one ``lineage_attempt`` launch (no (T, G) matrix is formed,
+    a few scalars come back per attempt); the first acceptable one is taken and numpy's
+    stream is rewound to just behind its draws, so results and stream position equal the
+    one-at-a-time loop's.  The accepted branch is materialised once by ``lineage_commit``.
 
-    New keyword-only options: ``max_attempts`` bounds the redraws per branch
+    New keyword-only options: ``batch`` (attempts per launch); ``max_attempts`` bounds the redraws per branch
     (default unlimited, like the reference); ``stats`` (a list) receives one
     ``(branch, max, [anticorrelated counts])`` record per attempt; ``rng="device"``
     draws the random walks on the device (``lineage_walk`` kernel, one lane per program,
@@ -184,29 +186,47 @@ def simulate_lineage(tree, rel_exp_cutoff=8, intra_branch_tol=0.5, inter_branch_
         seed = int(lo) | (int(hi) << 32)
     programs = {}
     for ordinal, branch in enumerate(sut.breadth_first_branches(tree)):
-        tries = 0
-        while True:
-            tries += 1
-            if rng == "device":
-                if tree.modules < 2:
-                    raise ValueError("at least 2 expression programs are needed")
-                programs[branch] = ctx.lineage_walk(seed, (ordinal << 32) | (tries - 1),
-                                                    int(tree.time[branch]), int(tree.modules))
-            else:
-                programs[branch] = sim_expr_branch(tree.time[branch], tree.modules, cutoff=intra_branch_tol)
-            programs[branch] = sut.adjust_to_parent(programs, branch, topology)
-            siblings = [b for b in sut.find_parallel(tree, programs, branch)
-                        if b is not None and b != branch]
-            top, counts = ctx.lineage_attempt(programs[branch], H, [programs[s] for s in siblings])
-            if stats is not None:
-                stats.append((branch, top, counts))
-            diverges = all(c / (tree.G * 1.0) > inter_branch_tol for c in counts)
-            if not (top > rel_exp_cutoff) and diverges:
-                break
-            if max_attempts is not None and tries >= max_attempts:
+        steps, tries, accepted = int(tree.time[branch]), 0, None
+        siblings = None
+        while accepted is None:
+            # Candidate programs for the next `width` attempts, drawn in the reference's stream order
+            # (one sim_expr_branch per attempt); all of them go through ONE lineage_attempt launch.  The
+            # first acceptable one is taken and numpy's generator is put back to where the sequential
+            # loop would have left it, just behind that attempt's draws -- same numbers, same stream
+            # position, one device round trip per batch instead of per attempt.
+            width = min(batch, 4 if tries == 0 else batch)           # most branches are accepted early
+            if max_attempts is not None:
+                width = min(width, max_attempts - tries)
+            candidates, states = [], []
+            for i in range(width):
+                if rng == "device":
+                    if tree.modules < 2:
+                        raise ValueError("at least 2 expression programs are needed")
+                    programs[branch] = ctx.lineage_walk(seed, (ordinal << 32) | (tries + i), steps, int(tree.modules))
+                else:
+                    programs[branch] = sim_expr_branch(steps, tree.modules, cutoff=intra_branch_tol)
+                    states.append(random.get_state())
+                candidates.append(sut.adjust_to_parent(programs, branch, topology))
+            if siblings is None:
+                siblings = [b for b in sut.find_parallel(tree, programs, branch)
+                            if b is not None and b != branch]
+            tops, counts = ctx.lineage_attempt_batch(np.stack(candidates), H, [programs[s] for s in siblings])
+            for i in range(width):
+                tries += 1
+                if stats is not None:
+                    stats.append((branch, float(tops[i]), [int(c) for c in counts[i]]))
+                diverges = all(c / (tree.G * 1.0) > inter_branch_tol for c in counts[i])
+                if not (tops[i] > rel_exp_cutoff) and diverges:
+                    accepted = candidates[i]
+                    if states:
+                        random.set_state(states[i])
+                    break
+            if accepted is None and max_attempts is not None and tries >= max_attempts:
+                del programs[branch]
                 raise RuntimeError("branch %r: no acceptable expression programs after %d attempts "
                                    "(rel_exp_cutoff=%r, inter_branch_tol=%r)"
                                    % (branch, tries, rel_exp_cutoff, inter_branch_tol))
+        programs[branch] = accepted
         key = _plain_label(tree, branch)
         at = offsets[key]
         ctx.lineage_commit(programs[branch], H, rel[at:at + int(tree.time[key])], gene_max)
