@@ -2,22 +2,33 @@
 """
 bench.py -- simulated cells x genes / second of the PROSSTT sampling hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3] [--scaling weak|strong]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (BASELINE.json metric): config C3 -- 8-branch tree (T = 50 per branch, K = 25
 programs), 20 000 genes, 50 000 cells PER GPU; the tree goes through the product's own
 lineage stage on the device (timed separately, not part of the metric), the cells are drawn
 from the tree's density.  A *step* = one pass of the fused count sampler
-(prosstt_amd_sample_counts: parameter prep kernel + K3) over the rank's cells, all inputs
-resident in HBM, output left in HBM.  With N GPUs the plan has 50 000 x N cells sharded by
-branch (prosstt_amd.parallel), no collective on the data path: weak scaling.
+(prosstt_amd_sample_counts: parameter prep + cell records + K3 stream kernel + K3h) over the
+rank's cells, all inputs resident in HBM, output left in HBM.  With N GPUs the plan is sharded by
+branch (prosstt_amd.parallel), no collective on the data path: 50 000 x N cells under
+``--scaling weak`` (default), the configuration's own cell count under ``--scaling strong``
+(e.g. ``--config C4 --scaling strong``: 200 000 cells over the N GPUs).
 
-One JSON line on rank 0.  `roofline` is for the dominant kernel (sample_counts_kernel):
-algorithmic bytes per launch / its mean duration from HIP events on the
-launch stream.  `cpu_baseline` (N = 1 only) times the oracle's numpy restatement of the
-reference's draw_counts (1 core, as the reference is single-threaded) on a bounded sample
-of the same workload.
+One JSON line on rank 0.
+ * ``ms_per_step`` / ``value``: the sampler as bench.py calls it (no domain check);
+   ``ms_per_step_strict``: the product API's default (``strict=True``: the domain check of the
+   reference's scipy call -- three more kernels, a copy back and a sync).
+ * ``roofline``: the dominant kernel (k3::sample_counts_stream_kernel): algorithmic bytes per
+   launch (DESIGN.md section 6) / its mean duration from HIP events on the launch stream;
+   ``frac_whole_step`` prices the same bytes against ms_per_step (K3h, prep kernels, launch gaps
+   included).  ``traffic`` comes from the committed rocprofv3 PMC passes and is reported only
+   while the kernel sources are the ones that were profiled.
+ * ``cpu_baseline`` (N = 1 only): the oracle's restatement of the reference's draw_counts WITH the
+   reference's loop structure (oracle/ref_numpy.draw_counts_as_reference; within 1 % of the imported
+   reference's time, tools/cpu_port_vs_reference.py) on a bounded sample of the same workload,
+   1 core, as the reference is single-threaded; ``cpu_baseline_all_cores``: the same on one process
+   per physical core over disjoint cell ranges.
 """
 import argparse
 import json
@@ -39,48 +50,86 @@ def algorithmic_bytes(n_cells, G, rows):
     return 4 * n_cells * G + 4 * rows * G + 8 * G + 8 * n_cells
 
 
+def kernel_source_sha():
+    """Fingerprint of the kernel sources (what a profile is a profile OF)."""
+    import hashlib
+    h = hashlib.sha256()
+    for fn in ("k3_stream.h", "k3_heavy.h", "prnb_device.h", "prosstt_amd.hip"):
+        h.update(open(os.path.join(ROOT, "prosstt_amd", "csrc", fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def profiled_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS
     command (profiles/rNN_summary.txt, written by tools/profile_bench.sh: separate --pmc runs for
     FETCH_SIZE and WRITE_SIZE).  Units and corrections as MI355X_MICROARCH.md prescribes: both
     counters are KiB; WRITE_SIZE is exact for 16-B/lane stores, FETCH_SIZE reads half of a wide
     coalesced stream on gfx950 and is doubled.  bench.py cannot run the profiler on itself, so
-    this is the last profiled value, not a live one; None when no profile is committed."""
+    this is the last profiled value, not a live one: (None, why) when no profile is committed or
+    the committed one was taken on other kernel sources."""
     import glob
     import re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.txt")))
     if not files:
-        return None, None
+        return None, "no profile committed"
     text = open(files[-1]).read()
+    name = os.path.relpath(files[-1], ROOT)
+    m = re.search(r"kernel_source_sha:\s*([0-9a-f]+)", text)
+    if not m or m.group(1) != kernel_source_sha():
+        return None, "%s was taken on other kernel sources" % name
     vals = {}
-    for name in ("FETCH_SIZE", "WRITE_SIZE"):
-        m = re.search(r"sample_counts_stream_kernel<true>\s+%s\s+([0-9.e+]+)" % name, text)
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        m = re.search(r"sample_counts_stream_kernel<true>\s+%s\s+([0-9.e+]+)" % counter, text)
         if not m:
-            return None, None
-        vals[name] = float(m.group(1)) * 1024.0
-    return vals["WRITE_SIZE"] + 2.0 * vals["FETCH_SIZE"], os.path.relpath(files[-1], ROOT)
+            return None, "%s lacks %s" % (name, counter)
+        vals[counter] = float(m.group(1)) * 1024.0
+    return vals["WRITE_SIZE"] + 2.0 * vals["FETCH_SIZE"], name
 
 
-def cpu_baseline(work, pt, br, sc, cells):
-    """Reference-equivalent CPU path: oracle/ref_numpy.draw_counts (bit-identical to the real
-    reference at equal seed, tests/test_oracle_golden.py) on the first `cells` cells, 1 core."""
+def physical_cores():
+    """Physical cores of the host (distinct (package, core) pairs of /proc/cpuinfo); half the
+    logical CPUs when that cannot be read."""
+    try:
+        pairs, pkg = set(), None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                pkg = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                pairs.add((pkg, line.split(":")[1].strip()))
+        if pairs:
+            return len(pairs)
+    except OSError:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+def _ref_tree(tree):
     from oracle import ref_numpy
-    tree = work.tree
     ref = ref_numpy.RefTree(tree.topology, {b: int(tree.time[b]) for b in tree.branches},
                             modules=tree.modules, G=tree.G)
     ref.means = tree.means                      # host float64 view of the device tensor
+    return ref
+
+
+def cpu_baseline(work, pt, br, sc, cells):
+    """Reference-equivalent CPU path: oracle/ref_numpy.draw_counts_as_reference -- the reference's
+    simulation.draw_counts with its own loop structure and library calls (bit-identical output
+    at equal seed and within 1 % of the imported reference's wall time in the build container:
+    tools/cpu_port_vs_reference.py) -- on the first `cells` cells, 1 core."""
+    from oracle import ref_numpy
+    ref = _ref_tree(work.tree)
     np.random.seed(12345)
     # chunks of 500 cells keep the reference's ~77 B per cell x gene of temporaries bounded
     done, t0 = 0, time.perf_counter()
     for lo in range(0, cells, 500):
         hi = min(lo + 500, cells)
-        x = ref_numpy.draw_counts(ref, pt[lo:hi], list(br[lo:hi]), sc[lo:hi], work.alpha, work.beta)
+        x = ref_numpy.draw_counts_as_reference(ref, pt[lo:hi], list(br[lo:hi]), sc[lo:hi], work.alpha, work.beta)
         done += x.size
     dt = time.perf_counter() - t0
     return dict(value=done / dt, unit="cells*genes/s", cores=1, kind="port",
-                sample="oracle/ref_numpy.draw_counts (numpy restatement of simulation.py:602-651, "
-                       "RandomState.negative_binomial) on the first %d cells x %d genes of the same plan, "
-                       "%.1f s" % (cells, tree.G, dt),
+                sample="oracle/ref_numpy.draw_counts_as_reference (simulation.py:602-651 with the reference's "
+                       "per-cell branch_times()/get_pr_umi loops and scipy.stats.nbinom(...).rvs()) on the first "
+                       "%d cells x %d genes of the same plan, %.1f s" % (cells, work.tree.G, dt),
                 host_cpus=os.cpu_count())
 
 
@@ -97,7 +146,7 @@ ref.means = {b: d["means_" + b] for b in branches}
 np.random.seed(1000 + lo)
 for a in range(lo, hi, 250):
     b = min(a + 250, hi)
-    ref_numpy.draw_counts(ref, d["pt"][a:b], list(d["br"][a:b]), d["sc"][a:b], d["alpha"], d["beta"])
+    ref_numpy.draw_counts_as_reference(ref, d["pt"][a:b], list(d["br"][a:b]), d["sc"][a:b], d["alpha"], d["beta"])
 """
 
 
@@ -115,16 +164,18 @@ def cpu_baseline_all_cores(work, pt, br, sc, cells, procs):
                  pt=pt[:cells], br=np.array([str(b) for b in br[:cells]]), sc=sc[:cells], alpha=work.alpha,
                  beta=work.beta, **{"means_" + str(b): means[b] for b in tree.branches})
         edges = np.linspace(0, cells, procs + 1).astype(int)
+        env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
         t0 = time.perf_counter()
-        kids = [subprocess.Popen([sys.executable, "-c", _WORKER, ROOT, path, str(lo), str(hi)])
+        kids = [subprocess.Popen([sys.executable, "-c", _WORKER, ROOT, path, str(lo), str(hi)], env=env)
                 for lo, hi in zip(edges[:-1], edges[1:]) if hi > lo]
         rcs = [k.wait() for k in kids]
         dt = time.perf_counter() - t0
     if any(rcs):
         raise RuntimeError("a CPU baseline worker failed: %r" % (rcs,))
     return dict(value=cells * tree.G / dt, unit="cells*genes/s", cores=len(kids), kind="port",
-                sample="oracle/ref_numpy.draw_counts on %d processes, %d cells x %d genes in all, %.1f s wall "
-                       "(process start-up and plan loading included)" % (len(kids), cells, tree.G, dt),
+                sample="oracle/ref_numpy.draw_counts_as_reference on %d processes (one per physical core), %d cells x "
+                       "%d genes in all, %.1f s wall (process start-up and plan loading included)"
+                       % (len(kids), cells, tree.G, dt),
                 host_cpus=os.cpu_count())
 
 
@@ -134,10 +185,14 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4", "C5"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --cells-per-gpu (default: the config's cell count) on every GPU; "
+                         "strong: the config's cell count in all, split over the GPUs")
     ap.add_argument("--cells-per-gpu", type=int, default=None)
     ap.add_argument("--cpu-cells", type=int, default=10000, help="cells timed by the CPU baseline (0 = skip)")
-    ap.add_argument("--cpu-procs", type=int, default=0,
-                    help="also time the CPU port on this many host processes (adds cpu_baseline_all_cores)")
+    ap.add_argument("--cpu-procs", type=int, default=-1,
+                    help="host processes of the all-cores CPU baseline (-1: one per physical core, 0: skip)")
+    ap.add_argument("--strict-steps", type=int, default=5, help="steps timed with the domain check on (0 = skip)")
     ap.add_argument("--gather", action="store_true", help="also time the optional row gather to rank 0")
     args = ap.parse_args()
 
@@ -170,8 +225,12 @@ def main():
     work = workloads.build(args.config)
     tree, G = work.tree, work.tree.G
     rows_total = work.info["rows"]
-    per_gpu = args.cells_per_gpu or work.cfg["N"]
-    n_total = per_gpu * world
+    if args.scaling == "strong":
+        n_total = args.cells_per_gpu * world if args.cells_per_gpu else work.cfg["N"]
+        per_gpu = n_total // world
+    else:
+        per_gpu = args.cells_per_gpu or work.cfg["N"]
+        n_total = per_gpu * world
     pt, br, sc, rows = work.plan(n_total)
     mine, owner = parallel.shard_cells(br, rank, world)
 
@@ -183,9 +242,9 @@ def main():
     d_idx = ctx.tensor(mine, torch.int64)
     out = torch.empty((len(mine), G), dtype=torch.int32, device=ctx.torch_device)
 
-    def step(seed, timed=False):
+    def step(seed, timed=False, strict=False):
         ctx.sample_counts(means, d_rows, d_sc, d_al, d_be, seed=seed, out=out, cell_index=d_idx,
-                          check_domain=False, time_kernel=timed)
+                          check_domain=strict, time_kernel=timed)
 
     def fence():
         if use_dist:
@@ -211,6 +270,20 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = n_total * G / (elapsed / args.steps)
 
+    # the product API's default: with the domain check of the reference's scipy call
+    ms_strict = None
+    if args.strict_steps > 0:
+        step(99, strict=True)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.strict_steps):
+            step(i, strict=True)
+        fence()
+        t_s = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
+        if use_dist:
+            dist.all_reduce(t_s, op=dist.ReduceOp.MAX)
+        ms_strict = float(t_s.item()) / args.strict_steps * 1e3
+
     gather_ms = None
     if args.gather:
         fence()
@@ -229,32 +302,39 @@ def main():
         kms = float(np.mean(kernel_ms))
         abytes = algorithmic_bytes(len(mine), G, rows_total)
         achieved = abytes / (kms * 1e-3)
-        traffic, traffic_src = profiled_traffic() if (args.config == "C3" and args.cells_per_gpu is None) else (None, None)
+        default_shape = args.config == "C3" and args.cells_per_gpu is None and args.scaling == "weak"
+        traffic, traffic_src = profiled_traffic() if default_shape else (None, "profiles are of the default C3 run")
         line = {
             "metric": "simulated cells*genes per second (count sampling: sample_density -> draw_counts)",
             "value": value, "unit": "cells*genes/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "ms_per_step_strict": ms_strict,
+            "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %d-branch tree (T=50, K=25), %d genes, %d cells per GPU "
                                    "(%d total), density sampling; lineage via the product pipeline"
                                    % (args.config, work.info["branches"], G, per_gpu, n_total),
+                       "cells_on_rank_0": int(len(mine)),
                        "parallelism": "cells sharded by branch, %d rank(s), no data-path collective" % world,
                        "lineage_attempts": work.info["attempts"], "lineage_s": round(work.info["lineage_s"], 3),
                        "sum_counts_over_sum_means": round(ratio, 5)},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k3::sample_counts_stream_kernel<true>", "kernel_ms": kms,
-                         "algorithmic_bytes_per_launch": abytes,
-                         "note": "VALU-bound exact sampler: see DESIGN.md section 6 and profiles/"},
+                         "frac_whole_step": abytes / (ms_per_step * 1e-3) / HBM_PEAK,
+                         "algorithmic_bytes_per_launch": abytes, "kernel_source_sha": kernel_source_sha(),
+                         "note": "frac = algorithmic bytes / the dominant kernel's mean duration (HIP events); "
+                                 "frac_whole_step prices them against ms_per_step (K3h, prep kernels, gaps). "
+                                 "VALU-issue-bound sampler: DESIGN.md section 6 and profiles/"},
         }
         if gather_ms is not None:
             line["gather_ms"] = gather_ms
         if world == 1 and args.cpu_cells > 0:
             line["cpu_baseline"] = cpu_baseline(work, pt, br, sc, min(args.cpu_cells, n_total))
             line["speedup_vs_cpu_1core"] = value / line["cpu_baseline"]["value"]
-        if world == 1 and args.cpu_procs > 1:
+        procs = physical_cores() if args.cpu_procs < 0 else args.cpu_procs
+        if world == 1 and args.cpu_cells > 0 and procs > 1:
             line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(
-                work, pt, br, sc, min(max(args.cpu_cells, 250 * args.cpu_procs), n_total), args.cpu_procs)
+                work, pt, br, sc, min(max(args.cpu_cells, 250 * procs), n_total), procs)
         print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()

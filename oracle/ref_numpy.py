@@ -408,6 +408,47 @@ def draw_counts(tree, pseudotime, branches, scalings, alpha, beta):
     return x.astype(np.int64).reshape((len(branches), tree.G))
 
 
+def draw_counts_as_reference(tree, pseudotime, branches, scalings, alpha, beta):
+    """simulation.py:602-651 with the reference's own loop structure and library calls -- the CPU
+    baseline of bench.py.  ``draw_counts`` above returns the same matrix faster (it looks the branch
+    offsets up once); this one pays what the reference pays: ``tree.branch_times()`` rebuilt for
+    every cell from a pandas Series of branch lengths (:634, tree.py:376-399), one row product per
+    cell (:638-639), one ``get_pr_umi`` per cell on float64 rows written into the flat p/r vectors
+    (:641-644), and ``scipy.stats.nbinom(n, p).rvs()`` on N*G elements (:647-648).
+    tools/cpu_port_vs_reference.py times it against the imported reference."""
+    import collections
+    import pandas as pd
+    import scipy.stats
+    lengths = pd.Series({b: tree.time[b] for b in tree.branches})
+
+    def branch_times():
+        spans = collections.defaultdict(list)
+        spans[tree.root] = [0, lengths[tree.root] - 1]
+        for parent, child in tree.topology:
+            end = spans[parent][1]
+            spans[child] = [end + 1, end + lengths[child]]
+        return spans
+
+    n_cells, G = len(branches), tree.G
+    mu = np.zeros((n_cells, G))
+    starts = [branch_times()[b][0] for b in branches]
+    steps = pseudotime - starts
+    p_flat = np.zeros(n_cells * G)
+    r_flat = np.zeros(n_cells * G)
+    for n, t, b in zip(np.arange(n_cells), steps, branches):
+        mu[n] = tree.means[b][t] * scalings[n]
+    for n in range(n_cells):
+        a, bb, m = alpha, beta, mu[n]
+        s2 = (a * m ** 2 + bb * m)
+        p = (s2 - m) / s2
+        r = (m ** 2) / (s2 - m)
+        p[s2 <= 0] = 0
+        r[s2 <= 0] = 0
+        p_flat[n * G:(n + 1) * G] = p
+        r_flat[n * G:(n + 1) * G] = r
+    return scipy.stats.nbinom(n=r_flat, p=(1 - p_flat)).rvs().reshape((n_cells, G))
+
+
 def sample_data_at_times(tree, sample_pt, branches=None, alpha=0.3, beta=2,
                          scale=True, scale_mean=0., scale_v=0.7):
     """simulation.py:551-599."""

@@ -440,11 +440,13 @@ __global__ __launch_bounds__(256) void means_from_rel_kernel(const double* __res
 // gene has a < 0 or b < 1 is the full N x G test needed.
 __global__ void domain_rows_kernel(const int32_t* __restrict__ row_of_cell, const float* __restrict__ scal,
                                    int64_t N, const float* __restrict__ ga, const float* __restrict__ gbm1,
-                                   int32_t G, uint8_t* __restrict__ rows_used, int64_t* __restrict__ flagp)
+                                   int32_t G, int64_t rows, uint8_t* __restrict__ rows_used,
+                                   int64_t* __restrict__ flagp)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < N) {
-        rows_used[row_of_cell[i]] = 1;
+        const int64_t r = row_of_cell[i];
+        if (r >= 0 && r < rows) rows_used[r] = 1;      // (an index outside the tensor is the caller's bug; never write there)
         if (!(scal[i] > 0.0f)) flagp[0] = 1;
     }
     if (i < G && (!(ga[i] >= 0.0f) || !(gbm1[i] >= 0.0f))) flagp[2] = 1;     // needs the full test
@@ -715,7 +717,7 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
             HIP_TRY(hipMemsetAsync(rows_used, 0, (size_t)rows, c->stream));
             const int64_t span = N > G ? N : G;
             domain_rows_kernel<<<dim3((unsigned)((span + 255) / 256)), dim3(256), 0, c->stream>>>(
-                A.row_of_cell, A.scal, N, A.ga, A.gbm1, G, rows_used, c->scratch);
+                A.row_of_cell, A.scal, N, A.ga, A.gbm1, G, rows, rows_used, c->scratch);
             domain_means_kernel<<<dim3(2048), dim3(256), 0, c->stream>>>(A.means, rows, G, rows_used, c->scratch);
             domain_full_kernel<<<dim3(8192), dim3(256), 0, c->stream>>>(A.means, G, A.row_of_cell, A.scal, A.ga,
                                                                       A.gbm1, N, c->scratch);

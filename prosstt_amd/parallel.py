@@ -14,8 +14,9 @@ are independent.  Every rank
      the cells on them, keyed by their position in the GLOBAL plan (``cell_index``), so the
      count of cell n is the same whether 1, 2, 4 or 8 GPUs ran, and
   4. keeps its shard on its own device.  There is no collective on the data path; the one
-     optional exchange is ``gather_rows``: count rows to rank 0 by point-to-point send/recv
-     (shards are unequal, so not ncclGather), each sender driving one xGMI link.
+     optional exchange is ``gather_rows``: count rows to rank 0 by point-to-point transfers
+     (shards are unequal, so not ncclGather), all senders at once -- each drives its own xGMI
+     link into the root -- in chunks, the scatter of one chunk under the transfer of the next.
 """
 import numpy as np
 
@@ -70,6 +71,32 @@ def broadcast_plan(plan, group=None, src=0):
     return box[0]
 
 
+def _digest(*arrays):
+    """Order-sensitive 64-bit digest of host arrays (what the ranks must agree on)."""
+    import hashlib
+    h = hashlib.blake2b(digest_size=8)
+    for a in arrays:
+        a = np.ascontiguousarray(a)
+        h.update(str(a.dtype).encode() + str(a.shape).encode())
+        h.update(a.tobytes())
+    return h.hexdigest()
+
+
+def assert_replicas_agree(tree, alpha, beta, group=None):
+    """Every rank must hold the same tree and per-gene parameters (the lineage is replicated, not
+    exchanged): compare a digest of (row sums of the device mean tensor, alpha, beta) across ranks."""
+    rank, size = world(group)
+    if size == 1:
+        return
+    row_sums = tree.device_means().double().sum(dim=1).cpu().numpy()
+    mine = _digest(row_sums, np.asarray(alpha, np.float64), np.asarray(beta, np.float64))
+    seen = [None] * size
+    _dist().all_gather_object(seen, mine, group=group)
+    if len(set(seen)) != 1:
+        raise RuntimeError("ranks hold different trees or (alpha, beta): digests %r -- seed numpy identically "
+                           "on every rank before building the tree" % (seen,))
+
+
 def sample_density_sharded(tree, no_cells, alpha=0.3, beta=2, scale=True, scale_v=0.7, scale_mean=0.,
                            *, seed=None, group=None, strict=True):
     """``simulation.sample_density`` (simulation.py:416-471) across the ranks of ``group``.
@@ -77,60 +104,85 @@ def sample_density_sharded(tree, no_cells, alpha=0.3, beta=2, scale=True, scale_
     Returns ``(counts, cell_index, sample_pt, branches, scalings)``: ``counts`` is this rank's
     int32 device tensor (len(cell_index), G); the last three are the GLOBAL plan, identical on
     every rank.  ``counts[i]`` equals row ``cell_index[i]`` of the single-GPU result for the
-    same seed."""
+    same seed.
+
+    EVERY rank draws the plan, the scalings and the default seed from its own numpy stream (the
+    draws of the single-process call), then rank 0's values are broadcast: ranks that were seeded
+    alike stay in lock-step for whatever they draw next, and ranks that were not still sample one
+    plan.  With ``strict`` the ranks also compare a digest of their mean tensor, alpha and beta."""
     rank, size = world(group)
-    if rank == 0:
-        pt, br = sim._density_plan(tree, no_cells)
-        sc = sut.calc_scalings(no_cells, scale, scale_mean, scale_v)
-        if seed is None:
-            lo, hi = np.random.randint(0, 2 ** 32, size=2, dtype=np.uint64)
-            seed = int(lo) | (int(hi) << 32)
-        plan = (pt, br, sc, seed)
-    else:
-        plan = None
-    pt, br, sc, seed = broadcast_plan(plan, group)
+    pt, br = sim._density_plan(tree, no_cells)
+    sc = sut.calc_scalings(no_cells, scale, scale_mean, scale_v)
+    if seed is None:
+        lo, hi = np.random.randint(0, 2 ** 32, size=2, dtype=np.uint64)
+        seed = int(lo) | (int(hi) << 32)
+    pt, br, sc, seed = broadcast_plan((pt, br, sc, seed), group)
     mine, _ = shard_cells(br, rank, size)
-    if np.shape(alpha) == ():
-        alpha = [alpha] * tree.G
-    if np.shape(beta) == ():
-        beta = [beta] * tree.G
+    alpha = np.full(tree.G, alpha, np.float64) if np.ndim(alpha) == 0 else np.asarray(alpha, np.float64)
+    beta = np.full(tree.G, beta, np.float64) if np.ndim(beta) == 0 else np.asarray(beta, np.float64)
+    if strict:
+        assert_replicas_agree(tree, alpha, beta, group)
     ctx = _device.get_context()
     rows = sim.cell_rows(tree, pt[mine], br[mine])
-    counts = ctx.sample_counts(tree.device_means(), rows, sc[mine], np.asarray(alpha, dtype=np.float64),
-                               np.asarray(beta, dtype=np.float64), seed=seed, cell_index=mine,
+    counts = ctx.sample_counts(tree.device_means(), rows, sc[mine], alpha, beta, seed=seed, cell_index=mine,
                                check_domain=strict)
     return counts, mine, pt, br, sc
 
 
-def gather_rows(local_rows, cell_index, total_rows, group=None, dst=0):
+def gather_rows(local_rows, cell_index, total_rows, group=None, dst=0, chunk_rows=8192):
     """Collect row shards on rank ``dst`` into a (total_rows, G) tensor in global order.
 
     ``local_rows`` (n_local, G) and ``cell_index`` (n_local,) of every rank; returns the full
-    tensor on ``dst`` and None elsewhere.  Point-to-point: every sender streams its shard over
-    its own link, the root receives into staging and scatters rows with ``index_copy_``."""
+    tensor on ``dst`` and None elsewhere.  Point-to-point (shards are unequal, so not a gather
+    collective), in rounds of ``chunk_rows`` rows per sender: the root posts the receives of a
+    round from ALL senders at once (``batch_isend_irecv``: every xGMI link of the root carries
+    data at the same time) and scatters round r with ``index_copy_`` while round r + 1 is in
+    flight.  A rank may own no rows."""
     import torch
     dist = _dist()
     rank, size = world(group)
     index = torch.as_tensor(np.asarray(cell_index), dtype=torch.int64, device=local_rows.device)
+    G = local_rows.shape[1]
     if size == 1:
-        out = torch.empty((total_rows, local_rows.shape[1]), dtype=local_rows.dtype, device=local_rows.device)
+        out = torch.empty((total_rows, G), dtype=local_rows.dtype, device=local_rows.device)
         out.index_copy_(0, index, local_rows)
         return out
     sizes = [None] * size
     dist.all_gather_object(sizes, int(local_rows.shape[0]), group=group)
-    if rank == dst:
-        out = torch.empty((total_rows, local_rows.shape[1]), dtype=local_rows.dtype, device=local_rows.device)
-        out.index_copy_(0, index, local_rows)
+    rounds = max((n + chunk_rows - 1) // chunk_rows for n in sizes) if max(sizes) else 0
+    if rank != dst:
+        rows = local_rows.contiguous()
+        for r in range(rounds):
+            lo, hi = r * chunk_rows, min((r + 1) * chunk_rows, sizes[rank])
+            if lo >= hi:
+                break
+            ops = [dist.P2POp(dist.isend, index[lo:hi].contiguous(), dst, group),
+                   dist.P2POp(dist.isend, rows[lo:hi], dst, group)]
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return None
+    out = torch.empty((total_rows, G), dtype=local_rows.dtype, device=local_rows.device)
+    out.index_copy_(0, index, local_rows)
+
+    def post(r):
+        """Receives of round r from every sender that still has rows: [(idx, buf)], requests."""
+        bufs, ops = [], []
         for src in range(size):
-            if src == dst or sizes[src] == 0:
+            n = min((r + 1) * chunk_rows, sizes[src]) - r * chunk_rows
+            if src == dst or n <= 0:
                 continue
-            idx = torch.empty(sizes[src], dtype=torch.int64, device=local_rows.device)
-            buf = torch.empty((sizes[src], local_rows.shape[1]), dtype=local_rows.dtype, device=local_rows.device)
-            dist.recv(idx, src=src, group=group)
-            dist.recv(buf, src=src, group=group)
+            idx = torch.empty(n, dtype=torch.int64, device=local_rows.device)
+            buf = torch.empty((n, G), dtype=local_rows.dtype, device=local_rows.device)
+            bufs.append((idx, buf))
+            ops += [dist.P2POp(dist.irecv, idx, src, group), dist.P2POp(dist.irecv, buf, src, group)]
+        return bufs, (dist.batch_isend_irecv(ops) if ops else [])
+
+    pending = post(0) if rounds else ([], [])
+    for r in range(rounds):
+        bufs, reqs = pending
+        for req in reqs:
+            req.wait()
+        pending = post(r + 1) if r + 1 < rounds else ([], [])
+        for idx, buf in bufs:
             out.index_copy_(0, idx, buf)
-        return out
-    if local_rows.shape[0]:
-        dist.send(index, dst=dst, group=group)
-        dist.send(local_rows.contiguous(), dst=dst, group=group)
-    return None
+    return out

@@ -231,6 +231,10 @@ def simulate_lineage(tree, rel_exp_cutoff=8, intra_branch_tol=0.5, inter_branch_
         at = offsets[key]
         ctx.lineage_commit(programs[branch], H, rel[at:at + int(tree.time[key])], gene_max)
     host = rel.cpu().numpy()
+    # the device keeps `rel` for simulate_base_gene_exp / add_genes, which recognise these arrays by
+    # identity: read-only, so that an in-place edit raises instead of being silently ignored (pass
+    # modified COPIES to those functions: they are uploaded afresh)
+    host.flags.writeable = False
     rel_means = {b: host[offsets[b]:offsets[b] + int(tree.time[b])] for b in tree.branches}
     tree._lineage = dict(rel=rel, gene_max=gene_max, host=rel_means, H=H)
     ordered = {}

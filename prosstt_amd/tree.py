@@ -144,9 +144,13 @@ class Tree(object):
     @property
     def means(self):
         """dict branch -> (T_b, G) float64 (tree.py:64, 213).  Materialised from the
-        device tensor on first access when the means were computed there."""
+        device tensor on first access when the means were computed there (the values are the
+        binary32 ones the sampler uses).  These arrays are READ-ONLY views of that tensor's copy:
+        the sampler reads the device tensor, so an in-place edit would silently not take effect --
+        assign a new dict to ``tree.means`` (or call ``add_genes``) to change the means."""
         if self._host_means is None and self._dev_means is not None:
             host = self._dev_means.cpu().numpy().astype(np.float64)
+            host.flags.writeable = False
             offsets, _ = self.row_offsets()
             self._host_means = {b: host[offsets[b]:offsets[b] + int(self.time[b])] for b in self.branches}
         return self._host_means
@@ -169,6 +173,9 @@ class Tree(object):
             tiny = np.float32(1.17549435e-38)      # positive means stay positive in binary32 (see means_from_rel)
             as32[(stacked > 0) & (as32 < tiny)] = tiny
             self._dev_means = ctx.tensor(as32, torch.float32)
+            for b in self.branches:                  # the upload is now what the sampler reads: freeze the source
+                if isinstance(self._host_means[b], np.ndarray):
+                    self._host_means[b].flags.writeable = False
         return self._dev_means
 
     def add_genes(self, *args):

@@ -89,3 +89,88 @@ def test_greedy_balance_and_single_rank():
     mine, owner = parallel.shard_cells(labels, 0, 2)
     assert owner["A"] == 0 and sorted(owner.values()) == [0, 1, 1]
     np.testing.assert_array_equal(mine, [0, 2, 4])
+
+
+class _FakeContext:
+    """Stand-in for device.Context on a box without a GPU: CPU tensors, and a 'sampler' that writes
+    f(global cell id, gene, seed) -- the one property of the real kernel the sharding relies on."""
+    def __init__(self):
+        import torch
+        self.torch_device = torch.device("cpu")
+        self.calls = []
+
+    def tensor(self, host, dtype):
+        import torch
+        return torch.as_tensor(np.ascontiguousarray(host)).to(dtype)
+
+    def sample_counts(self, means, rows, sc, alpha, beta, seed=0, cell_index=None, check_domain=True, **kw):
+        import torch
+        assert len(rows) == len(sc) == len(cell_index) and means.shape[1] == len(alpha) == len(beta)
+        self.calls.append(len(rows))
+        idx = torch.as_tensor(np.asarray(cell_index), dtype=torch.int64)
+        return (idx[:, None] * 1000 + torch.arange(means.shape[1])[None, :] + seed % 7).to(torch.int32)
+
+
+def _worker_sharded(rank, world_size, port, tmpdir, same_seed):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    from prosstt_amd import device, parallel
+    from prosstt_amd.tree import Tree
+    fake = _FakeContext()
+    device.get_context = lambda *a, **k: fake
+    try:
+        G, N = 5, 211
+        t = Tree(topology=[["A", "B"]], time={"A": 30, "B": 20}, num_branches=2, branch_points=0, modules=3, G=G)
+        rng = np.random.default_rng(5 if same_seed else 5 + rank)
+        t.means = {b: np.exp(rng.normal(size=(t.time[b], G))) for b in "AB"}
+        np.random.seed(77 if same_seed else 77 + rank)
+        if not same_seed:
+            # different trees on the ranks: strict mode must notice
+            try:
+                parallel.sample_density_sharded(t, N, seed=3)
+                raise AssertionError("replicas disagree and nobody noticed")
+            except RuntimeError as e:
+                assert "different trees" in str(e)
+            dist.barrier()
+            open(os.path.join(tmpdir, "ok%d" % rank), "w").write("ok")
+            return
+        counts, mine, pt, br, sc = parallel.sample_density_sharded(t, N, seed=3)
+        # two branches, three ranks: somebody owns nothing, and the pieces add up to the plan
+        sizes = [None] * world_size
+        dist.all_gather_object(sizes, len(mine))
+        assert sum(sizes) == N and 0 in sizes and len(set(sizes)) == 3
+        assert tuple(counts.shape) == (len(mine), G)
+        # lock-step: every rank consumed the same draws, so the next variate is the same everywhere
+        nxt = [None] * world_size
+        dist.all_gather_object(nxt, float(np.random.random()))
+        assert len(set(nxt)) == 1
+        plans = [None] * world_size
+        dist.all_gather_object(plans, parallel._digest(pt, np.array([str(b) for b in br]), sc))
+        assert len(set(plans)) == 1
+        # the gather: chunks smaller than every shard, all senders at once, an empty sender among them
+        full = parallel.gather_rows(counts, mine, N, chunk_rows=16)
+        if rank == 0:
+            want = (torch.arange(N)[:, None] * 1000 + torch.arange(G)[None, :] + 3).to(torch.int32)
+            assert torch.equal(full, want)
+        else:
+            assert full is None
+        other = parallel.gather_rows(counts, mine, N, dst=1, chunk_rows=1000)      # another root, one round
+        assert (other is not None) == (rank == 1)
+        dist.barrier()
+        open(os.path.join(tmpdir, "ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("same_seed", [True, False])
+def test_three_ranks_sharded_sampling_and_gather(tmp_path, same_seed):
+    """sample_density_sharded + gather_rows on 3 gloo ranks with unequal shards and an empty rank;
+    ranks seeded alike stay in lock-step, ranks holding different trees are refused in strict mode."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker_sharded, args=(3, port, str(tmp_path), same_seed), nprocs=3, join=True)
+    assert all(os.path.exists(tmp_path / ("ok%d" % r)) for r in range(3))

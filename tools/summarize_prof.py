@@ -7,6 +7,9 @@ import os
 import sys
 
 root = sys.argv[1]
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench                                   # noqa: E402  (only for the fingerprint of the kernel sources)
+print("kernel_source_sha: %s" % bench.kernel_source_sha())
 for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
     print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
     for row in csv.DictReader(open(f)):
