@@ -237,15 +237,19 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
     const int64_t waves = (int64_t)gridDim.x * (kHeavyBlock / 64);
     const int64_t wave0 = wave_id * 64, stride = waves * 64;
     if (heavy.overflow[0] == 0u) {
+        // four regions per step, 16 lanes each: a region holds ~20 entries on the headline workload, and
+        // every step is a chain of dependent loads (count -> entry -> row -> mean)
         const int32_t groups = (strips + 3) / 4;
-        for (int64_t r = wave_id; r < (int64_t)regions; r += waves) {
-            const uint32_t cnt = heavy.count[r];
+        const int sub = lane >> 4, sl = lane & 15;
+        for (int64_t r0 = wave_id * 4; r0 < (int64_t)regions; r0 += waves * 4) {
+            const int64_t r = r0 + sub;
+            const uint32_t cnt = r < (int64_t)regions ? heavy.count[r] : 0u;
             const int32_t blk = (int32_t)(r >> 2);
             const int32_t tile_g = blk / groups;
             const int64_t n0 = (int64_t)((blk - tile_g * groups) * 4 + (int32_t)(r & 3)) * strip_cells;
-            for (uint32_t i0 = 0u; i0 < cnt; i0 += 64u) {
-                const bool has = i0 + (uint32_t)lane < cnt;
-                const uint32_t p = has ? heavy.list[(uint64_t)r * heavy.cap + i0 + (uint32_t)lane] : 0u;
+            for (uint32_t i0 = 0u; __builtin_amdgcn_ballot_w64(i0 < cnt) != 0ull; i0 += 16u) {
+                const bool has = i0 + (uint32_t)sl < cnt;
+                const uint32_t p = has ? heavy.list[(uint64_t)r * heavy.cap + i0 + (uint32_t)sl] : 0u;
                 feed(has, (int32_t)(n0 + (p >> 8)), tile_g * kTileG + (int32_t)(p & 255u));
             }
         }
