@@ -62,6 +62,29 @@ def save_matrices(job_id, save_dir, X, uMs, H):
         np.savetxt("%s_ums%s.txt" % (stem, branch), uMs[branch])
 
 
+def save_matrices_npz(job_id, save_dir, X, uMs=None, H=None, compressed=False):
+    """Binary alternative to ``save_matrices`` for matrices the text format cannot carry (the 50 000 x
+    20 000 headline matrix is 4 GB as int32 and several times that as text): one
+    ``<save_dir>/<job_id>_simulation.npz`` holding ``X`` as int32 (an int32 device tensor -- what
+    ``draw_counts(..., out="torch")`` returns -- is copied to the host as it is, never widened to
+    int64), ``H`` and ``ums<branch>`` when given.  Row i is cell_i, column j gene_j, as in the text file."""
+    if hasattr(X, "detach"):                         # torch tensor
+        X = X.detach().cpu().numpy()
+    X = np.asarray(X)
+    if X.dtype != np.int32:
+        if X.size and (X.min() < 0 or X.max() > np.iinfo(np.int32).max):
+            raise ValueError("counts do not fit int32")
+        X = X.astype(np.int32)
+    arrays = {"X": X}
+    if H is not None:
+        arrays["H"] = np.asarray(H)
+    for branch in (uMs.keys() if uMs is not None else ()):
+        arrays["ums%s" % branch] = np.asarray(uMs[branch])
+    path = "%s/%s_simulation.npz" % (save_dir, job_id)
+    (np.savez_compressed if compressed else np.savez)(path, **arrays)
+    return path
+
+
 def save_params(job_id, save_dir, lineage_tree, rseed):
     """<save_dir>/<job_id>_params.txt: genes, branch lengths, topology, #programs, seed
     (tree_utils.py:148-173)."""

@@ -299,6 +299,36 @@ def g9_helpers():
     save("g9_helpers", **out)
 
 
+# --------------------------------------------------------------------- G10
+def g10_written_files():
+    """Files written by the reference's tree_utils.save_* (tree_utils.py:59-173) for a small simulation,
+    stored byte for byte together with the inputs that produced them."""
+    import tempfile
+    from prosstt import tree_utils as rtut
+    rng = np.random.default_rng(10)
+    spec = TREES["bifurcation"]
+    t = build_tree(spec, 5, 3)
+    N, G = 7, 5
+    X = rng.integers(0, 40, size=(N, G)).astype(np.int64)
+    labs = rng.integers(0, 80, N)
+    brns = np.array(list("ABCABCA"))
+    scal = np.exp(rng.normal(0, 0.7, N))
+    alpha, beta, scale = np.exp(rng.normal(-1.6, 0.4, G)), np.exp(rng.normal(0, 0.4, G)) + 1, np.exp(rng.normal(0.8, 1, G))
+    H = rng.gamma(0.05, size=(3, G))
+    uMs = {b: rng.normal(size=(4, G)) for b in "ABC"}
+    out = dict(X=X, labs=labs, brns=brns, scalings=scal, alpha=alpha, beta=beta, genescale=scale, H=H,
+               tree=tree_json(spec, 5, 3), rseed=np.array(42))
+    out.update({"uMs_%s" % b: uMs[b] for b in "ABC"})
+    with tempfile.TemporaryDirectory() as d:
+        rtut.save_cell_params("job", d, labs, brns, scal)
+        rtut.save_gene_params("job", d, scale, alpha, beta)
+        rtut.save_matrices("job", d, X, uMs, H)
+        rtut.save_params("job", d, t, 42)
+        for fn in sorted(os.listdir(d)):
+            out["file_" + fn] = np.frombuffer(open(os.path.join(d, fn), "rb").read(), dtype=np.uint8)
+    save("g10_written_files", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:                      # regenerate selected fixtures only, e.g. `make_golden.py g7_nb_tables`
         for name in sys.argv[1:]:
@@ -312,4 +342,5 @@ if __name__ == "__main__":
     g6_sampling()
     g7_nb_tables()
     g9_helpers()
+    g10_written_files()
     g8_end_to_end()

@@ -198,3 +198,47 @@ def test_max_attempts_guard():
     t = ptree.Tree(G=2000, modules=10)
     with pytest.raises(RuntimeError):
         sim.simulate_lineage(t, rel_exp_cutoff=-50, a=0.05, max_attempts=3)
+
+
+def test_secondary_samplers_counts_bit_exact_vs_model():
+    """sample_whole_tree, sample_pseudotime_series, _sample_data_at_times and add_non_diff_genes
+    (simulation.py:474-517, 319-379, 551-599, 654-675) with an explicit sampler seed: every count --
+    the appended non-differential columns included -- equals the C model's for the plan the call
+    returned."""
+    from prosstt_amd import simulation as sim, sim_utils as sut
+    from oracle import nb_model
+    np.random.seed(31)
+    t = make_tree(dict(topology=[["A", "B"], ["A", "C"], ["C", "D"], ["C", "E"]],
+                       time={"A": 30, "B": 45, "C": 25, "D": 20, "E": 33}, branch_points=2, G=300, modules=6,
+                       int_labels=False))
+    rel, _, _ = sim.simulate_lineage(t, a=0.05, intra_branch_tol=0)
+    base = sut.simulate_base_gene_exp(t, rel)
+    t.add_genes(rel, base)
+    G = t.G
+    alpha = np.exp(np.random.normal(np.log(0.2), np.log(1.5), G))
+    beta = np.exp(np.random.normal(0, np.log(1.5), G)) + 1
+    host_means = t.device_means().cpu().numpy()
+
+    def model(pt, br, sc, al, be, seed):
+        rows = sim.cell_rows(t, np.asarray(pt), np.asarray(br))
+        return nb_model.sample_counts(host_means, rows, np.asarray(sc), np.broadcast_to(al, (G,)).astype(float),
+                                      np.broadcast_to(be, (G,)).astype(float), seed)
+
+    X, pt, br, sc = sim.sample_whole_tree(t, 2, alpha=alpha, beta=beta, seed=101)
+    assert X.dtype == np.int64 and X.shape == (len(pt), G)
+    np.testing.assert_array_equal(X, model(pt, br, sc, alpha, beta, 101))
+    X, pt, br, sc = sim.sample_pseudotime_series(t, 60, [5, 40, 70], 5.0, alpha=0.3, beta=2, seed=102)
+    np.testing.assert_array_equal(X, model(pt, br, sc, 0.3, 2.0, 102))
+    X, pt, br, sc = sim._sample_data_at_times(t, np.arange(0, t.get_max_time(), 2), alpha=alpha, beta=beta, seed=103)
+    np.testing.assert_array_equal(X, model(pt, br, sc, alpha, beta, 103))
+    X, pt, br, sc = sim.sample_density(t, 150, alpha=alpha, beta=beta, seed=104)
+    np.testing.assert_array_equal(X, model(pt, br, sc, alpha, beta, 104))
+    # add_non_diff_genes: one constant mean row, the cells' own scalings, its own seed
+    extra = 9
+    gp = dict(alpha=alpha[:extra], beta=beta[:extra], base_expr=base[:extra])
+    wide = sim.add_non_diff_genes(X, extra, gp, sc, seed=105)
+    assert wide.dtype == np.float64 and wide.shape == (150, G + extra)
+    np.testing.assert_array_equal(wide[:, :G], X)
+    want = nb_model.sample_counts(base[:extra].astype(np.float32).reshape(1, extra), np.zeros(150, np.int32),
+                                  sc, alpha[:extra], beta[:extra], 105)
+    np.testing.assert_array_equal(wide[:, G:], want)

@@ -304,3 +304,30 @@ def test_helpers_against_reference_fixtures():
     np.testing.assert_allclose(la, g["ld_alpha"], rtol=1e-10)
     np.testing.assert_allclose(lb, g["ld_beta"], rtol=1e-10)
     np.testing.assert_allclose(prop, g["ld_means"], rtol=1e-12)
+
+
+def test_writers_reproduce_the_reference_files(tmp_path):
+    """tree_utils.save_* write, byte for byte, the files the reference's writers wrote for the same
+    inputs (fixture g10: tree_utils.py:59-173); the binary writer keeps int32 and round-trips."""
+    from prosstt_amd import tree_utils as tut
+    g = load_golden("g10_written_files")
+    spec = tree_spec(g)
+    t = ptree.Tree(topology=spec["topology"], time=spec["time"], num_branches=len(spec["time"]),
+                   branch_points=spec["branch_points"], modules=spec["modules"], G=spec["G"])
+    uMs = {b: g["uMs_%s" % b] for b in "ABC"}
+    d = str(tmp_path)
+    tut.save_cell_params("job", d, g["labs"], g["brns"], g["scalings"])
+    tut.save_gene_params("job", d, g["genescale"], g["alpha"], g["beta"])
+    tut.save_matrices("job", d, g["X"], uMs, g["H"])
+    tut.save_params("job", d, t, int(g["rseed"]))
+    names = sorted(k[5:] for k in g.files if k.startswith("file_"))
+    assert sorted(os.listdir(d)) == names
+    for fn in names:
+        assert open(os.path.join(d, fn), "rb").read() == bytes(g["file_" + fn]), fn
+    path = tut.save_matrices_npz("job", d, g["X"], uMs, g["H"])
+    back = np.load(path)
+    assert back["X"].dtype == np.int32
+    np.testing.assert_array_equal(back["X"], g["X"])
+    np.testing.assert_array_equal(back["umsB"], uMs["B"])
+    with pytest.raises(ValueError):
+        tut.save_matrices_npz("job", d, np.array([[2 ** 40]]))
