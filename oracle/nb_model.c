@@ -3,7 +3,7 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library; prosstt_amd never does.
  *
- * Scalar C model of the *device* count sampler ("PRNB-1"): the
+ * Scalar C model of the *device* count sampler ("PRNB-2"): the
  * fused  gather * scale -> get_pr_umi -> negative-binomial draw  that replaces
  *   simulation.draw_counts           /root/reference/prosstt/simulation.py:602-651
  *   count_model.get_pr_umi           /root/reference/prosstt/count_model.py:131-161
@@ -11,7 +11,7 @@
  *
  * The reference draws from numpy's sequential MT19937 stream, which no
  * parallel device can reproduce (SURVEY.md section 0 "RNG reality check"); the count
- * law, not the stream, is the contract.  PRNB-1 is a counter-based sampler of
+ * law, not the stream, is the contract.  PRNB-2 is a counter-based sampler of
  * the SAME law  NB(n = r, p = 1-p)  with  theta = a*m + b - 1,  r = m/theta,
  * p = theta/(1+theta)  (the algebraic form of get_pr_umi), defined so that
  * every sample is a pure function of (M, s, a, b, seed, cell, gene):
@@ -36,7 +36,7 @@
 #define PRNB_CLONES
 #endif
 
-/* ---- sampler constants (part of the PRNB-1 definition) ------------------ */
+/* ---- sampler constants (part of the PRNB-2 definition) ------------------ */
 #define PRNB_LIGHT_T      19.0f        /* inversion iff theta <= 16 and t = -log P(X=0) <= 19: P0 * 2^32 >= 24 */
 #define PRNB_LIGHT_THETA  16.0f        /* tail ratio theta/(1+theta) <= 16/17: the walk ends far below the 1/k table's 511 entries */
 #define PRNB_THETA_MIN    8.6736174e-19f /* 2^-60: below this NB == Poisson in binary32 */

@@ -71,6 +71,22 @@ VARIANTS = {
     "k3h_grid256": [("k3::sample_counts_heavy_kernel<<<dim3(2048),", "k3::sample_counts_heavy_kernel<<<dim3(256),")],
     "k3h_grid512": [("k3::sample_counts_heavy_kernel<<<dim3(2048),", "k3::sample_counts_heavy_kernel<<<dim3(512),")],
     "k3h_grid1024": [("k3::sample_counts_heavy_kernel<<<dim3(2048),", "k3::sample_counts_heavy_kernel<<<dim3(1024),")],
+    # occupancy experiment: S1 too small for the worst case (fine on C3 in practice): 5 blocks per CU instead of 4
+    "occ5": [("constexpr int kS1Cap = 320;", "constexpr int kS1Cap = 200;"), ("constexpr int kLateCap = 128;", "constexpr int kLateCap = 112;"),
+             ('static_assert(kS2Cap >= kS2Run - 1 + 64 && kS1Cap >= 63 + 256, "a stack must take one more pass of pushes");', ""),
+             # never write beyond the stack (entries are lost instead: wrong counts, valid addresses)
+             ("            const uint32_t slot = (s1_lds + ((uint32_t)s1_top << 4)) + ((uint32_t)lane_rank(push_m) << 4);",
+              "            const uint32_t slot = s1_lds + (umin((uint32_t)s1_top + (uint32_t)lane_rank(push_m), (uint32_t)kS1Cap - 1u) << 4);"),
+             ("            s1_top += __popcll(push_m);", "            s1_top += __popcll(push_m); s1_top = s1_top < kS1Cap ? s1_top : kS1Cap;")],
+    # candidate changes of the sampler's definition, timing only (the model is not changed along)
+    "philox7": [("    for (int round = 0; round < 10; ++round) {\n        // one 32x32->64 product", "    for (int round = 0; round < 7; ++round) {\n        // one 32x32->64 product")],
+    "ratio": [("        const float num = PRNB_FMA(kf, q, mp);          // the group's first numerator by fma, the others by addition\n", "        const float cq = mp - q;\n"),
+              ("        const float ps1 = (ps * num) * inv.x;\n        const float num1 = num + q;\n", "        const float ps1 = ps * PRNB_FMA(cq, inv.x, q);\n"),
+              ("        const float ps2 = (ps1 * num1) * inv.y;\n        const float num2 = num1 + q;\n", "        const float ps2 = ps1 * PRNB_FMA(cq, inv.y, q);\n"),
+              ("        const float ps3 = (ps2 * num2) * inv.z;\n        const float num3 = num2 + q;\n", "        const float ps3 = ps2 * PRNB_FMA(cq, inv.z, q);\n"),
+              ("        ps = done ? 0.0f : (ps3 * num3) * inv.w;\n", "        ps = done ? 0.0f : ps3 * PRNB_FMA(cq, inv.w, q);\n"),
+              ("        kf = kf + 4.0f;\n", "")],
+    "rcpu1": [("            const float inv_u1 = prnb::det_rcp(theta * u1) * theta;", "            const float inv_u1 = prnb::det_rcp(u1);")],
     # real variants (correct results): tuning constants
     "run16": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 16;")],
     "run48": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 48;"), ("constexpr int kS2Cap = 96;", "constexpr int kS2Cap = 112;")],
@@ -82,7 +98,11 @@ VARIANTS = {
                         '                         :: "s"(push_m), "v"(slot), "v"(e) : "memory");',
                         '            asm volatile("" :: "s"(push_m), "v"(slot), "v"(e));'),
                        ("constexpr int kS1Cap = 320;", "constexpr int kS1Cap = 16;"),
-                       ('static_assert(kS2Cap >= kS2Run - 1 + 64 && kS1Cap >= 63 + 256, "a stack must take one more pass of pushes");', "")],
+                       ('static_assert(kS2Cap >= kS2Run - 1 + 64 && kS1Cap >= 63 + 256, "a stack must take one more pass of pushes");', ""),
+             # never write beyond the stack (entries are lost instead: wrong counts, valid addresses)
+             ("            const uint32_t slot = (s1_lds + ((uint32_t)s1_top << 4)) + ((uint32_t)lane_rank(push_m) << 4);",
+              "            const uint32_t slot = s1_lds + (umin((uint32_t)s1_top + (uint32_t)lane_rank(push_m), (uint32_t)kS1Cap - 1u) << 4);"),
+             ("            s1_top += __popcll(push_m);", "            s1_top += __popcll(push_m); s1_top = s1_top < kS1Cap ? s1_top : kS1Cap;")],
 }
 
 
