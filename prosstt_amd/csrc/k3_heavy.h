@@ -34,7 +34,7 @@ struct HeavyLds {
 // and every sample of the matrix is redone here instead: slow, but any parameter set stays correct.
 __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
     HeavyList heavy, uint32_t regions, int32_t strips, int32_t strip_cells,
-    const float* __restrict__ means,
+    const float* __restrict__ means, int64_t rows,
     int32_t G, const int32_t* __restrict__ row_of_cell, const float* __restrict__ scal,
     const float* __restrict__ ga, const float* __restrict__ gbm1, int64_t N, uint32_t k0, uint32_t k1,
     uint64_t cell_offset, const int64_t* __restrict__ cell_index, int32_t* __restrict__ out, int64_t ld)
@@ -212,6 +212,7 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
         int32_t row = 0;
         if (has) {
             row = row_of_cell[n];
+            row = row < 0 ? 0 : (row >= rows ? (int32_t)(rows - 1) : row);     // as cellinfo_kernel: never a wild read
             const prnb::Params P = prnb::make_params(means[(int64_t)row * G + g], scal[n], ga[g], gbm1[g]);
             light = P.valid && P.light;
             heavy = P.valid && !P.light;

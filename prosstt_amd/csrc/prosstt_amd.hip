@@ -133,7 +133,7 @@ __global__ void prep_params_kernel(const double* __restrict__ scaling, int64_t N
 
 // Per-cell record of the streaming kernel (k3::CellInfo); N + 4 entries, the last cell repeated.
 __global__ void cellinfo_kernel(const int32_t* __restrict__ row_of_cell, const float* __restrict__ scal,
-                                int64_t N, int32_t G, uint64_t cell_offset,
+                                int64_t N, int32_t G, int64_t rows, uint64_t cell_offset,
                                 const int64_t* __restrict__ cell_index, int32_t strip_cells,
                                 k3::CellInfo* __restrict__ info)
 {
@@ -142,7 +142,9 @@ __global__ void cellinfo_kernel(const int32_t* __restrict__ row_of_cell, const f
     const int64_t n = i < N ? i : N - 1;
     const uint64_t cell = cell_index ? (uint64_t)cell_index[n] : cell_offset + (uint64_t)n;
     k3::CellInfo c;
-    c.row_bytes = (uint64_t)row_of_cell[n] * (uint64_t)G * 4u;
+    // an index outside the tensor (the caller's bug; the checked mode reports it) must not become a wild read
+    const int64_t row = row_of_cell[n] < 0 ? 0 : (row_of_cell[n] >= rows ? rows - 1 : row_of_cell[n]);
+    c.row_bytes = (uint64_t)row * (uint64_t)G * 4u;
     c.s = scal[n];
     c.cell_lo = (uint32_t)cell;
     c.cell_hi = (uint32_t)(cell >> 32);
@@ -446,7 +448,8 @@ __global__ void domain_rows_kernel(const int32_t* __restrict__ row_of_cell, cons
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < N) {
         const int64_t r = row_of_cell[i];
-        if (r >= 0 && r < rows) rows_used[r] = 1;      // (an index outside the tensor is the caller's bug; never write there)
+        if (r >= 0 && r < rows) rows_used[r] = 1;
+        else flagp[1] = 1;                             // an index outside the tensor: reported as EINVAL, never written through
         if (!(scal[i] > 0.0f)) flagp[0] = 1;
     }
     if (i < G && (!(ga[i] >= 0.0f) || !(gbm1[i] >= 0.0f))) flagp[2] = 1;     // needs the full test
@@ -695,7 +698,7 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
             return fail(PROSSTT_AMD_EINVAL, "too many tiles; chunk the cells");
         if ((uint64_t)rows * (uint64_t)G >= ((uint64_t)1 << 61)) return fail(PROSSTT_AMD_EINVAL, "mean tensor too large");
         cellinfo_kernel<<<dim3((unsigned)((N + 4 + 255) / 256)), dim3(256), 0, c->stream>>>(
-            A.row_of_cell, A.scal, N, G, cell_offset, cell_index, (int32_t)strip_cells, cellinfo);
+            A.row_of_cell, A.scal, N, G, rows, cell_offset, cell_index, (int32_t)strip_cells, cellinfo);
         const dim3 grid((unsigned)(groups * tiles_g)), block(k3::kBlock);
         if (ev_start) HIP_TRY(hipEventRecord(ev_start, c->stream));    // the dominant kernel is timed alone
         if (vec)
@@ -710,7 +713,7 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
         if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, c->stream));   // the dominant kernel is timed alone
         // every wave takes whole regions of the list
         k3::sample_counts_heavy_kernel<<<dim3(2048), dim3(k3::kHeavyBlock), 0, c->stream>>>(
-            heavy, (uint32_t)regions, (int32_t)strips, (int32_t)strip_cells, A.means, G, A.row_of_cell, A.scal, A.ga,
+            heavy, (uint32_t)regions, (int32_t)strips, (int32_t)strip_cells, A.means, rows, G, A.row_of_cell, A.scal, A.ga,
             A.gbm1, N, k0, k1, cell_offset, cell_index, d_out, ld_out);
         ev_stop = nullptr;
         if (flags & PROSSTT_AMD_CHECK_DOMAIN) {
@@ -730,8 +733,10 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
         HIP_TRY(hipMemcpy2DAsync(out, (size_t)ld_out * 4, d_out, (size_t)ld_out * 4, (size_t)G * 4, (size_t)N,
                                  hipMemcpyDeviceToHost, c->stream));
     if (flags & PROSSTT_AMD_CHECK_DOMAIN) {
-        HIP_TRY(hipMemcpyAsync(c->h_scratch, c->scratch, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->h_scratch, c->scratch, 16, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->h_scratch[1])
+            return fail(PROSSTT_AMD_EINVAL, "row_of_cell holds an index outside [0,%lld)", (long long)rows);
         if (c->h_scratch[0])
             return fail(PROSSTT_AMD_EDOMAIN, "Domain error in arguments: a mean <= 0 or alpha*m + beta < 1");
     } else if (flags & (PROSSTT_AMD_HOST_OUTPUT | PROSSTT_AMD_HOST_INPUTS)) {

@@ -96,12 +96,9 @@ class Context:
             cell_index = self.tensor(cell_index, torch.int64)
             if cell_index.numel() != N:
                 raise ValueError("cell_index must have one entry per cell")
-        if check_domain and N:
-            # the kernels index the mean tensor with row_of_cell unchecked (device pointers are the
-            # caller's contract in the C ABI); the checked mode of this layer pays one small reduction
-            lo, hi = int(row_of_cell.min()), int(row_of_cell.max())
-            if lo < 0 or hi >= rows:
-                raise ValueError("row_of_cell outside [0, %d): min %d, max %d" % (rows, lo, hi))
+        # (row_of_cell indexes the mean tensor unchecked in the kernels -- device pointers are the caller's
+        # contract in the C ABI; with check_domain the library's domain pass also reports an index outside
+        # the tensor, as PROSSTT_AMD_EINVAL)
         flags = (_native.CHECK_DOMAIN if check_domain else 0) | (_native.TIME_KERNEL if time_kernel else 0)
         if os.environ.get("PROSSTT_AMD_KERNEL", "") == "tiled":      # A/B switch; same results
             flags |= _native.KERNEL_TILED

@@ -245,3 +245,17 @@ def test_chunking_offset_and_determinism(ctx):
         * torch.as_tensor(sc, device=full.device, dtype=torch.float32)[:, None]
     ratio = float(full.sum(dtype=torch.float64) / mu.sum(dtype=torch.float64))
     assert abs(ratio - 1) < 2e-3
+
+
+def test_row_index_outside_the_tensor_is_reported(ctx):
+    """A row_of_cell entry outside the mean tensor: the checked mode reports it (EINVAL), nothing is read
+    or written outside the tensor in either mode."""
+    from prosstt_amd import _native
+    means = np.ones((3, 16), np.float32)
+    sc = np.ones(4)
+    for bad in (3, -1, 2 ** 30):
+        roc = np.array([0, 1, bad, 2], np.int32)
+        with pytest.raises(_native.NativeError):
+            ctx.sample_counts(means, roc, sc, np.full(16, 0.2), np.full(16, 2.0), seed=1)
+        out = ctx.sample_counts(means, roc, sc, np.full(16, 0.2), np.full(16, 2.0), seed=1, check_domain=False)
+        assert tuple(out.shape) == (4, 16)
