@@ -6,7 +6,7 @@ from prosstt_amd import device, workloads
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
 ctx = device.get_context()
 w = workloads.build(cfg)
-pt, br, sc, rows = w.plan()
+pt, br, sc, rows = w.plan(int(os.environ["KBENCH_CELLS"]) if "KBENCH_CELLS" in os.environ else (125000 if cfg == "C5" else None))
 sc = sc * float(os.environ.get('KBENCH_SCALE', '1'))
 G = w.tree.G
 dm = w.tree.device_means(); dr = ctx.tensor(rows, torch.int32); ds = ctx.tensor(sc, torch.float64)
