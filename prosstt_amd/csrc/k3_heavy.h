@@ -39,11 +39,11 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
     const float* __restrict__ ga, const float* __restrict__ gbm1, int64_t N, uint32_t k0, uint32_t k1,
     uint64_t cell_offset, const int64_t* __restrict__ cell_index, int32_t* __restrict__ out, int64_t ld)
 {
-    __shared__ float inv_k[prnb::kKTab];
+    __shared__ __attribute__((aligned(16))) float inv_k[prnb::kKTab + 8];   // 0 from the sentinel (k = KTAB-1) on
     __shared__ HeavyLds lds_all[kHeavyBlock / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     HeavyLds& L = lds_all[wv];
-    for (int k = tid; k < prnb::kKTab; k += kHeavyBlock) inv_k[k] = (k && k < prnb::kKTab - 1) ? 1.0f / (float)k : 0.0f;
+    for (int k = tid; k < prnb::kKTab + 8; k += kHeavyBlock) inv_k[k] = (k && k < prnb::kKTab - 1) ? 1.0f / (float)k : 0.0f;
     __syncthreads();
 
     int hg_top = 0, hp_top = 0, hl_top = 0;      // wave-uniform

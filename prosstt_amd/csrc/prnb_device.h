@@ -182,6 +182,40 @@ __device__ __forceinline__ int32_t chop_down(uint32_t w, float p0, float mp, flo
     }
 }
 
+// chop_down with the groups of four terms unrolled: the same operations in the same order (so the
+// same result), but one aligned 16-byte read of four reciprocals per group instead of a dependent
+// 4-byte read per term.  inv_k must be 16-byte aligned with at least 4 zero entries behind the
+// sentinel (K3h's redo walks run hundreds of terms, each waiting for its read).
+__device__ __forceinline__ int32_t chop_down_grouped(uint32_t w, float p0, float mp, float q,
+                                                     const float* inv_k)
+{
+    float p = __builtin_fminf(p0, 0.99999994f);
+    float num = mp;
+    uint32_t rem = w;
+    // k = 0, 1, 2 as chop_down does them
+    for (int k = 0; k < 3; ++k) {
+        const uint32_t pf = (uint32_t)(p * 4294967296.0f);
+        if (rem < pf) return k;
+        if (pf == 0u) return 2;
+        rem -= pf;
+        p = (p * num) * inv_k[k + 1];
+        num = (k == 2) ? PRNB_FMA(3.0f, q, mp) : num + q;
+    }
+    for (int k = 3;; k += 4) {
+        const float4 inv = *reinterpret_cast<const float4*>(__builtin_assume_aligned(inv_k + k + 1, 16));
+        const float iv[4] = {inv.x, inv.y, inv.z, inv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t pf = (uint32_t)(p * 4294967296.0f);
+            if (rem < pf) return k + j;
+            if (pf == 0u) return k + 3;
+            rem -= pf;
+            p = (p * num) * iv[j];
+            num = (j == 3) ? PRNB_FMA((float)(k + 4), q, mp) : num + q;
+        }
+    }
+}
+
 __device__ __forceinline__ float logfact_small(int k)
 {
     // log(k!) for k < 10, binary32-rounded
@@ -327,7 +361,7 @@ __device__ __forceinline__ Params make_params(float M, float s, float a, float b
 __device__ __forceinline__ int32_t light_draw(const Params& P, uint32_t w, const float* inv_k)
 {
     const float q = P.theta * P.inv_u1;
-    return chop_down(w, det_exp(-P.t), P.m * P.inv_u1, q, inv_k);
+    return chop_down_grouped(w, det_exp(-P.t), P.m * P.inv_u1, q, inv_k);
 }
 
 // Heavy path: Poisson(theta * Gamma(r)).

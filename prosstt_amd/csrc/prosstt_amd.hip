@@ -169,7 +169,7 @@ __global__ __launch_bounds__(kBlock) void sample_counts_kernel(
     int64_t N, uint32_t k0, uint32_t k1, uint64_t cell_offset, const int64_t* __restrict__ cell_index,
     int32_t* __restrict__ out, int64_t ld, int64_t* __restrict__ domain_flag, int32_t tiles_c)
 {
-    __shared__ float inv_k[prnb::kKTab];
+    __shared__ __attribute__((aligned(16))) float inv_k[prnb::kKTab + 8];   // 0 from the sentinel (k = KTAB-1) on
     __shared__ int32_t tile[kTileC][kTileG];
     __shared__ uint16_t queue[kTileC * kTileG];
     __shared__ int q_count;
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(kBlock) void sample_counts_kernel(
     const int32_t g0 = tile_g * kTileG + ql * 4;
     const int64_t n0 = (int64_t)tile_c * kTileC;
 
-    for (int k = tid; k < prnb::kKTab; k += kBlock) inv_k[k] = (k && k < prnb::kKTab - 1) ? 1.0f / (float)k : 0.0f;
+    for (int k = tid; k < prnb::kKTab + 8; k += kBlock) inv_k[k] = (k && k < prnb::kKTab - 1) ? 1.0f / (float)k : 0.0f;
     if (tid == 0) q_count = 0;
     __syncthreads();
 

@@ -68,9 +68,9 @@ VARIANTS = {
     "k3h_noredo": [("            light = P.valid && P.light;\n", "            light = false;\n")],
     "k3h_noheavy": [("            heavy = P.valid && !P.light;\n", "            heavy = false;\n")],
     "k3h_none": [("            light = P.valid && P.light;\n", "            light = false;\n"), ("            heavy = P.valid && !P.light;\n", "            heavy = false;\n")],
-    "k3h_grid256": [("k3::sample_counts_heavy_kernel<<<dim3(2048),", "k3::sample_counts_heavy_kernel<<<dim3(256),")],
-    "k3h_grid512": [("k3::sample_counts_heavy_kernel<<<dim3(2048),", "k3::sample_counts_heavy_kernel<<<dim3(512),")],
     "k3h_grid1024": [("k3::sample_counts_heavy_kernel<<<dim3(2048),", "k3::sample_counts_heavy_kernel<<<dim3(1024),")],
+    "k3h_grid4096": [("k3::sample_counts_heavy_kernel<<<dim3(2048),", "k3::sample_counts_heavy_kernel<<<dim3(4096),")],
+    "k3h_grid8192": [("k3::sample_counts_heavy_kernel<<<dim3(2048),", "k3::sample_counts_heavy_kernel<<<dim3(8192),")],
     # occupancy experiment: S1 too small for the worst case (fine on C3 in practice): 5 blocks per CU instead of 4
     "occ5": [("constexpr int kS1Cap = 320;", "constexpr int kS1Cap = 200;"), ("constexpr int kLateCap = 128;", "constexpr int kLateCap = 112;"),
              ('static_assert(kS2Cap >= kS2Run - 1 + 64 && kS1Cap >= 63 + 256, "a stack must take one more pass of pushes");', ""),
