@@ -198,10 +198,13 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
         }
         late_top = 0;
     };
+    // (Wave-level tests are written on 64-bit lane masks taken BEFORE any divergent region of the
+    // pass: the ballot of one compare is then that compare's SGPR result; behind a divergent region,
+    // or of a composite predicate, the compiler re-forms it with two more VALU instructions.)
     auto deliver = [&](uint32_t p, int32_t res) {
         const bool late = (int32_t)p <= flushed_pos;
+        const unsigned long long ml = __builtin_amdgcn_ballot_w64(res > 0) & __builtin_amdgcn_ballot_w64(late);
         if ((res > 0) & !late) L.ring[p & (kRing * 256 - 1)] = (uint16_t)res;   // slot = cell % kRing, gene-in-tile
-        const unsigned long long ml = __builtin_amdgcn_ballot_w64((res > 0) & late);
         if (ml != 0ull) {
             const int cnt = __popcll(ml);
             if (late_top + cnt > kLateCap) flush_late();
@@ -223,10 +226,10 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
         h_cnt += (uint32_t)__popcll(mp_);
         hpend = kNoHeavy;
     };
-    // every lane of the wave calls this; `mine` lanes leave sample `p` to K3h
-    auto list_sample = [&](bool mine_, uint32_t p) {
-        if (__builtin_amdgcn_ballot_w64(mine_) != 0ull) {
-            if (__builtin_amdgcn_ballot_w64(mine_ & (hpend != kNoHeavy)) != 0ull) flush_heavy();
+    // every lane of the wave calls this; the lanes of `mine_m` (= `mine_`) leave sample `p` to K3h
+    auto list_sample = [&](unsigned long long mine_m, bool mine_, uint32_t p) {
+        if (mine_m != 0ull) {
+            if ((mine_m & __builtin_amdgcn_ballot_w64(hpend != kNoHeavy)) != 0ull) flush_heavy();
             if (mine_) hpend = p;
         }
     };
@@ -283,8 +286,9 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
         const bool any = hit0 | hit1 | hit2 | hit3;
         const bool done = any | (pf3 == 0u) | close;
         const int32_t res = (done & !close) ? k + (hit0 ? 0 : (hit1 ? 1 : (hit2 ? 2 : 3))) : 0;
+        const unsigned long long close_m = __builtin_amdgcn_ballot_w64(near < 2u * dl);
         deliver(pos, res);
-        list_sample(close, pos);
+        list_sample(close_m, close, pos);
         rem = rem4;
         ps = done ? 0.0f : (ps3 * num3) * inv.w;
         dl = done ? 0u : dl + 4u * kMarginPerTerm;
@@ -299,69 +303,75 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
     // P0 = 2^-t2; mp and q by PRNB-2's own arithmetic (they multiply into every term of a walk).  What the approximation cannot decide -- the class of a sample with t within
     // 2^-16 of 19, a threshold within the margin -- goes to K3h's list.
     auto stage2_pass = [&]() {
+        // Straight-line for every lane (a lane beyond the entries reads the stack's bottom entry and is
+        // masked out): every wave-level test below is a lane mask formed outside divergent control flow.
         const int cnt = s1_top < 64 ? s1_top : 64;
-        const bool mine = lane < cnt;
-        bool push = false, give_up = false;
-        int32_t res = 0;
-        S2Entry e2;
-        uint32_t p2 = 0u, pd2 = 0u;
-        e2.ps = 0.0f; e2.mp = 0.0f; e2.q = 0.0f; e2.rem = 0u;
-        if (mine) {
-            const S1Entry e = L.s1[s1_top - 1 - lane];
-            p2 = e.pos;
-            // (m <= 0 or theta <= 0: the count is 0 by definition; stage 1 does not test that)
-            const bool valid = (e.m > 0.0f) & (e.theta > 0.0f);
-            const float theta = __builtin_fmaxf(e.theta, prnb::kThetaMin);
-            const float u1 = 1.0f + theta;
-            const float dm1 = u1 - 1.0f;
-            const float inv_u1 = prnb::det_rcp(theta * u1) * theta;
-            const float qq = theta * inv_u1;
-            const float mpp = e.m * inv_u1;
-            // t2 = -log2 P(X = 0) = m * log2(1+theta)/theta; theta below 2^-24: the Poisson limit m * log2(e)
-            const float f2 = dm1 > 0.0f ? __builtin_amdgcn_logf(u1) * __builtin_amdgcn_rcpf(dm1) : 1.44269504f;
-            const float t2 = e.m * f2;
-            // inversion class for sure: theta <= 16 and t = t2 * ln 2 below 19 by more than the two
-            // evaluations can differ (NaN: not); every other valid sample is K3h's
-            const bool light = (theta <= prnb::kLightTheta) & (t2 < kT2Sure);
-            const float p0 = __builtin_fminf(__builtin_amdgcn_exp2f(-t2), 0.99999994f);
-            const float ps0 = p0 * 4294967296.0f;       // pmf scaled by 2^32 (exact scaling)
-            const uint32_t pf0 = (uint32_t)ps0;
-            // threshold margin of this sample at k = 2 (in units of 2^-32), a multiple of 256
-            const uint32_t d2 = ((uint32_t)PRNB_FMA(t2, kMarginPerT2, kMargin0 + 2.0f * kMarginPerTerm + 255.0f)) & ~255u;
-            const uint32_t rem1 = e.w - pf0;
-            const float ps1 = ps0 * mpp;                  // (* 1/1)
-            const float num1 = mpp + qq;
-            const uint32_t pf1 = (uint32_t)ps1;
-            const uint32_t rem2 = rem1 - pf1;
-            const float ps2 = (ps1 * num1) * 0.5f;
-            const float num2 = num1 + qq;
-            const uint32_t pf2 = (uint32_t)ps2;
-            const uint32_t rem3 = rem2 - pf2;
-            const bool close = umin(umin(rem1 + d2, rem2 + d2), rem3 + d2) < 2u * d2;
-            give_up = valid & (!light | close);
-            if (valid & light & !close & (e.w >= pf0)) {  // k >= 1
-                const bool hit1 = rem1 < pf1;
-                const bool hit2 = rem2 < pf2;
-                // no hit and the pmf gone: the group's last k (prnb::chop_down)
-                res = hit1 ? 1 : ((hit2 | (pf2 == 0u)) ? 2 : 0);
-                push = (res == 0);
-                e2.rem = rem3;
-                e2.ps = (ps2 * num2) * 0.33333334f;       // pmf at k = 3 (the 1/k table's 1/3)
-                e2.mp = mpp;
-                e2.q = qq;
-                pd2 = p2 | (((d2 + 4u * kMarginPerTerm) >> 8) << 16);   // margin of the terms k = 3..6
-            }
-        }
+        const int at = s1_top - 1 - lane;
+        const S1Entry e = L.s1[at > 0 ? at : 0];
+        const uint32_t p2 = e.pos;
+        // Each predicate twice: as a per-lane bool (selects, exec) and as a lane mask (wave-level tests);
+        // both come from the same compare instructions.
+#define K3_MASK(x) __builtin_amdgcn_ballot_w64(x)
+        // (m <= 0 or theta <= 0: the count is 0 by definition; stage 1 does not test that)
+        const bool valid = (lane < cnt) & (e.m > 0.0f) & (e.theta > 0.0f);
+        const unsigned long long valid_m = K3_MASK(lane < cnt) & K3_MASK(e.m > 0.0f) & K3_MASK(e.theta > 0.0f);
+        const float theta = __builtin_fmaxf(e.theta, prnb::kThetaMin);
+        const float u1 = 1.0f + theta;
+        const float dm1 = u1 - 1.0f;
+        const float inv_u1 = prnb::det_rcp(theta * u1) * theta;
+        const float qq = theta * inv_u1;
+        const float mpp = e.m * inv_u1;
+        // t2 = -log2 P(X = 0) = m * log2(1+theta)/theta; theta below 2^-24: the Poisson limit m * log2(e)
+        const float f2 = dm1 > 0.0f ? __builtin_amdgcn_logf(u1) * __builtin_amdgcn_rcpf(dm1) : 1.44269504f;
+        const float t2 = e.m * f2;
+        // inversion class for sure: theta <= 16 and t = t2 * ln 2 below 19 by more than the two
+        // evaluations can differ (NaN: not); every other valid sample is K3h's
+        const bool light = (theta <= prnb::kLightTheta) & (t2 < kT2Sure);
+        const unsigned long long light_m = K3_MASK(theta <= prnb::kLightTheta) & K3_MASK(t2 < kT2Sure);
+        const float p0 = __builtin_fminf(__builtin_amdgcn_exp2f(-t2), 0.99999994f);
+        const float ps0 = p0 * 4294967296.0f;       // pmf scaled by 2^32 (exact scaling)
+        const uint32_t pf0 = (uint32_t)ps0;
+        // threshold margin of this sample at k = 2 (in units of 2^-32), a multiple of 256
+        const uint32_t d2 = ((uint32_t)PRNB_FMA(t2, kMarginPerT2, kMargin0 + 2.0f * kMarginPerTerm + 255.0f)) & ~255u;
+        const uint32_t rem1 = e.w - pf0;
+        const float ps1 = ps0 * mpp;                  // (* 1/1)
+        const float num1 = mpp + qq;
+        const uint32_t pf1 = (uint32_t)ps1;
+        const uint32_t rem2 = rem1 - pf1;
+        const float ps2 = (ps1 * num1) * 0.5f;
+        const float num2 = num1 + qq;
+        const uint32_t pf2 = (uint32_t)ps2;
+        const uint32_t rem3 = rem2 - pf2;
+        const uint32_t near = umin(umin(rem1 + d2, rem2 + d2), rem3 + d2);
+        const bool close = near < 2u * d2;
+        const unsigned long long close_m = K3_MASK(near < 2u * d2);
+        const bool give_up = valid & (!light | close);
+        const unsigned long long give_m = valid_m & (~light_m | close_m);
+        // k >= 1 among the samples decided here
+        const bool walks = valid & light & !close & (e.w >= pf0);
+        const unsigned long long walk_m = valid_m & light_m & ~close_m & K3_MASK(e.w >= pf0);
+        const bool hit1 = rem1 < pf1;
+        const bool hit2 = rem2 < pf2;
+        // no hit and the pmf gone: the group's last k (prnb::chop_down)
+        const int32_t res12 = hit1 ? 1 : ((hit2 | (pf2 == 0u)) ? 2 : 0);
+        const int32_t res = walks ? res12 : 0;
+        const bool push = walks & (res12 == 0);
+        const unsigned long long push_m = walk_m & K3_MASK(res12 == 0);
+#undef K3_MASK
         deliver(p2, res);
-        list_sample(give_up, p2);
+        list_sample(give_m, give_up, p2);
         s1_top -= cnt;
-        const unsigned long long m2 = __builtin_amdgcn_ballot_w64(push);
         if (push) {
-            const int slot = s2_top + lane_rank(m2);
+            const int slot = s2_top + lane_rank(push_m);
+            S2Entry e2;
+            e2.rem = rem3;
+            e2.ps = (ps2 * num2) * 0.33333334f;       // pmf at k = 3 (the 1/k table's 1/3)
+            e2.mp = mpp;
+            e2.q = qq;
             L.s2[slot] = e2;
-            L.s2pos[slot] = pd2;
+            L.s2pos[slot] = p2 | (((d2 + 4u * kMarginPerTerm) >> 8) << 16);   // margin of the terms k = 3..6
         }
-        s2_top += __popcll(m2);
+        s2_top += __popcll(push_m);
     };
 
     // ---- stage 1 over the strip ----------------------------------------------------------------

@@ -87,6 +87,14 @@ VARIANTS = {
               ("        ps = done ? 0.0f : (ps3 * num3) * inv.w;\n", "        ps = done ? 0.0f : ps3 * PRNB_FMA(cq, inv.w, q);\n"),
               ("        kf = kf + 4.0f;\n", "")],
     "rcpu1": [("            const float inv_u1 = prnb::det_rcp(theta * u1) * theta;", "            const float inv_u1 = prnb::det_rcp(u1);")],
+    # what the threshold margins cost (no sample is ever given up: wrong in 1e-3 of the walks)
+    "s3_nomargin": [("        const uint32_t near = umin(umin(rem1 + dl, rem2 + dl), umin(rem3 + dl, rem4 + dl));\n        const bool close = near < 2u * dl;               // never for an idle lane: its dl is 0\n",
+                     "        const bool close = false;\n")],
+    "s23_nomargin": [("        const uint32_t near = umin(umin(rem1 + dl, rem2 + dl), umin(rem3 + dl, rem4 + dl));\n        const bool close = near < 2u * dl;               // never for an idle lane: its dl is 0\n",
+                      "        const bool close = false;\n"),
+                     ("            const bool close = umin(umin(rem1 + d2, rem2 + d2), rem3 + d2) < 2u * d2;\n", "            const bool close = false;\n")],
+    # stage 3 without the delivery of results
+    "s3_nodeliver": [("        deliver(pos, res);\n        list_sample(close, pos);", "        asm volatile(\"\" :: \"v\"(res), \"v\"(pos));\n        list_sample(close, pos);")],
     # real variants (correct results): tuning constants
     "run16": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 16;")],
     "run48": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 48;"), ("constexpr int kS2Cap = 96;", "constexpr int kS2Cap = 112;")],
