@@ -32,28 +32,21 @@ VARIANTS = {
     # stages 1 + 2: what stage 2 pushes on S2 is dropped
     "s12": [(RUN_23, "        while (s1_top >= 64) { stage2_pass(); s2_top = 0; }\n        cur = nxt;")],
     # no late results (they are dropped instead of listed)
-    "nolate": [("        const unsigned long long ml = __builtin_amdgcn_ballot_w64((res > 0) & late);",
-                "        const unsigned long long ml = 0ull; asm volatile(\"\" :: \"v\"(late));")],
+    "nolate": [("        const unsigned long long ml = __builtin_amdgcn_ballot_w64(res > 0) & __builtin_amdgcn_ballot_w64(late);",
+                "        const unsigned long long ml = 0ull; asm volatile(\"\" :: \"v\"((int)late));")],
     # stage 1 without the Philox call (a 2-instruction hash stands in)
     "s1_nophilox": [(RUN_23, "        s1_top = 0;\n        cur = nxt;"),
                     ("        const prnb::Words W = prnb::philox4x32_10<2>(c_lo, c_hi, (uint32_t)g0 >> 2, 0u, k0, k1);",
                      "        prnb::Words W; W.w[0] = (c_lo * 2654435761u) ^ ((uint32_t)g0 * 40503u); W.w[1] = W.w[0] * 3u + k0;\n"
                      "        W.w[2] = W.w[1] ^ 0x9E3779B9u; W.w[3] = W.w[2] + W.w[0];")],
     # stage 1 without the S1 push
-    "s1_nopush": [(RUN_23, "        s1_top = 0;\n        cur = nxt;"),
-                  ('            asm volatile("s_mov_b64 exec, %0\\n\\tds_write_b128 %1, %2\\n\\ts_mov_b64 exec, -1"\n'
-                   '                         :: "s"(push_m), "v"(slot), "v"(e) : "memory");',
-                   '            asm volatile("" :: "s"(push_m), "v"(slot), "v"(e));')],
     # stages 1 + 2 without the listing of given-up samples
     "s12_nolist": [(RUN_23, "        while (s1_top >= 64) { stage2_pass(); s2_top = 0; }\n        cur = nxt;"),
-                   ("        list_sample(give_up, p2);", "        asm volatile(\"\" :: \"v\"((int)give_up));")],
+                   ("        list_sample(give_m, give_up, p2);", "        asm volatile(\"\" :: \"v\"((int)give_up), \"s\"(give_m));")],
     # stages 1 + 2 with plain multiplies standing in for v_rcp / v_log / v_exp
-    "s12_nohw": [(RUN_23, "        while (s1_top >= 64) { stage2_pass(); s2_top = 0; }\n        cur = nxt;"),
-                 ("__builtin_amdgcn_rcpf(u1)", "(u1 * 0.3f)"), ("__builtin_amdgcn_rcpf(dm1)", "(dm1 * 0.7f)"),
-                 ("__builtin_amdgcn_logf(u1)", "(u1 * 0.9f)"), ("__builtin_amdgcn_exp2f(-t2)", "(t2 * 0.01f)")],
     # stages 1 + 2 without deliver
     "s12_nodeliver": [(RUN_23, "        while (s1_top >= 64) { stage2_pass(); s2_top = 0; }\n        cur = nxt;"),
-                      ("        deliver(p2, res);\n        list_sample(give_up, p2);", "        asm volatile(\"\" :: \"v\"(res), \"v\"(p2));\n        list_sample(give_up, p2);")],
+                      ("        deliver(p2, res);\n        list_sample(give_m, give_up, p2);", "        asm volatile(\"\" :: \"v\"(res), \"v\"(p2));\n        list_sample(give_m, give_up, p2);")],
     # stage 1 only, rows not stored (pure issue time of stage 1)
     "s1_nostore": [(RUN_23, "        s1_top = 0;\n        cur = nxt;"),
                    ("        if (g0 < G) {\n            if (VEC) {", "        if (g0 < G && v[0] == 12345) {\n            if (VEC) {")],
@@ -72,29 +65,16 @@ VARIANTS = {
     "k3h_grid4096": [("k3::sample_counts_heavy_kernel<<<dim3(2048),", "k3::sample_counts_heavy_kernel<<<dim3(4096),")],
     "k3h_grid8192": [("k3::sample_counts_heavy_kernel<<<dim3(2048),", "k3::sample_counts_heavy_kernel<<<dim3(8192),")],
     # occupancy experiment: S1 too small for the worst case (fine on C3 in practice): 5 blocks per CU instead of 4
-    "occ5": [("constexpr int kS1Cap = 320;", "constexpr int kS1Cap = 200;"), ("constexpr int kLateCap = 128;", "constexpr int kLateCap = 112;"),
-             ('static_assert(kS2Cap >= kS2Run - 1 + 64 && kS1Cap >= 63 + 256, "a stack must take one more pass of pushes");', ""),
-             # never write beyond the stack (entries are lost instead: wrong counts, valid addresses)
-             ("            const uint32_t slot = (s1_lds + ((uint32_t)s1_top << 4)) + ((uint32_t)lane_rank(push_m) << 4);",
-              "            const uint32_t slot = s1_lds + (umin((uint32_t)s1_top + (uint32_t)lane_rank(push_m), (uint32_t)kS1Cap - 1u) << 4);"),
-             ("            s1_top += __popcll(push_m);", "            s1_top += __popcll(push_m); s1_top = s1_top < kS1Cap ? s1_top : kS1Cap;")],
     # candidate changes of the sampler's definition, timing only (the model is not changed along)
     "philox7": [("    for (int round = 0; round < 10; ++round) {\n        // one 32x32->64 product", "    for (int round = 0; round < 7; ++round) {\n        // one 32x32->64 product")],
-    "ratio": [("        const float num = PRNB_FMA(kf, q, mp);          // the group's first numerator by fma, the others by addition\n", "        const float cq = mp - q;\n"),
-              ("        const float ps1 = (ps * num) * inv.x;\n        const float num1 = num + q;\n", "        const float ps1 = ps * PRNB_FMA(cq, inv.x, q);\n"),
-              ("        const float ps2 = (ps1 * num1) * inv.y;\n        const float num2 = num1 + q;\n", "        const float ps2 = ps1 * PRNB_FMA(cq, inv.y, q);\n"),
-              ("        const float ps3 = (ps2 * num2) * inv.z;\n        const float num3 = num2 + q;\n", "        const float ps3 = ps2 * PRNB_FMA(cq, inv.z, q);\n"),
-              ("        ps = done ? 0.0f : (ps3 * num3) * inv.w;\n", "        ps = done ? 0.0f : ps3 * PRNB_FMA(cq, inv.w, q);\n"),
-              ("        kf = kf + 4.0f;\n", "")],
-    "rcpu1": [("            const float inv_u1 = prnb::det_rcp(theta * u1) * theta;", "            const float inv_u1 = prnb::det_rcp(u1);")],
     # what the threshold margins cost (no sample is ever given up: wrong in 1e-3 of the walks)
     "s3_nomargin": [("        const uint32_t near = umin(umin(rem1 + dl, rem2 + dl), umin(rem3 + dl, rem4 + dl));\n        const bool close = near < 2u * dl;               // never for an idle lane: its dl is 0\n",
-                     "        const bool close = false;\n")],
+                     "        const bool close = false; const uint32_t near = 0xffffffffu;\n")],
     "s23_nomargin": [("        const uint32_t near = umin(umin(rem1 + dl, rem2 + dl), umin(rem3 + dl, rem4 + dl));\n        const bool close = near < 2u * dl;               // never for an idle lane: its dl is 0\n",
-                      "        const bool close = false;\n"),
-                     ("            const bool close = umin(umin(rem1 + d2, rem2 + d2), rem3 + d2) < 2u * d2;\n", "            const bool close = false;\n")],
+                      "        const bool close = false; const uint32_t near = 0xffffffffu;\n"),
+                     ("        const uint32_t near = umin(umin(rem1 + d2, rem2 + d2), rem3 + d2);\n", "        const uint32_t near = 0xffffffffu;\n")],
     # stage 3 without the delivery of results
-    "s3_nodeliver": [("        deliver(pos, res);\n        list_sample(close, pos);", "        asm volatile(\"\" :: \"v\"(res), \"v\"(pos));\n        list_sample(close, pos);")],
+    "s3_nodeliver": [("        deliver(pos, res);\n        list_sample(close_m, close, pos);", "        asm volatile(\"\" :: \"v\"(res), \"v\"(pos));\n        list_sample(close_m, close, pos);")],
     # real variants (correct results): tuning constants
     "run16": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 16;")],
     "run48": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 48;"), ("constexpr int kS2Cap = 96;", "constexpr int kS2Cap = 112;")],
