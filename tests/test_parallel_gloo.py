@@ -1,9 +1,10 @@
 """
-CPU tests of the N>1 path: world_size-2 gloo processes run the branch sharding, the plan
-broadcast and the row gather of prosstt_amd.parallel.  The device sampler itself cannot run
-here; a stand-in that writes f(global cell id, gene) plays its role, which is exactly the
-property the real kernel has (counts keyed by global cell id), so the reassembly is checked
-value for value.
+CPU tests of the N>1 path: world_size-2 and -3 gloo processes run the branch sharding, the plan
+broadcast, sample_density_sharded (lock-step host draws, replica digest check) and the chunked
+row gather of prosstt_amd.parallel.  The device sampler itself cannot run here; a stand-in that
+writes f(global cell id, gene) plays its role, which is exactly the property the real kernel has
+(counts keyed by global cell id), so the reassembly is checked value for value.  The real kernel
+under 2/4/8 ranks' shards is covered on one GPU by tests/test_gpu_sharding.py.
 """
 import os
 import socket
