@@ -16,7 +16,8 @@
 //                       undecided is pushed on S2 with the pmf state at k = 3;
 //   stage 3 (lanes pull from S2)  four pmf steps per lane per pass; a lane that finishes
 //                       writes its count into the LDS row ring and pulls the next entry;
-//   output              the last kRing rows of the strip live in LDS, 16 bits per count; a row
+//   output              the last kRing rows of the strip live in LDS, 8 bits per count (a count above
+//                       255 -- 1 in 10^4 -- is left to K3h); a row
 //                       is stored (one coalesced 1 KiB store per wave) kRing cells after stage 1
 //                       started it.  The few counts that arrive later than that (long walks)
 //                       are collected in LDS and written in bursts of 4-B stores -- a store per
@@ -57,7 +58,7 @@ constexpr int kS1Cap = 320;        // < 64 left over + 256 pushed by one pass
 constexpr int kS2Cap = 96;         // < 32 left over + 64 pushed by one stage-2 pass
 constexpr int kS2Run = 32;         // stage 3 runs while S2 holds at least this many entries (8, 16: 3-5 % slower)
 static_assert(kS2Cap >= kS2Run - 1 + 64 && kS1Cap >= 63 + 256, "a stack must take one more pass of pushes");
-constexpr int kRing = 4;           // rows of the strip kept in LDS (16 bits per count) before they are stored; a power of 2
+constexpr int kRing = 8;           // rows of the strip kept in LDS (8 bits per count) before they are stored; a power of 2
 // Threshold margins of the hardware-math evaluation, in units of 2^-32 (see the header): about
 // three times the worst-case distance between the two evaluations of a running pmf sum C_k --
 //   P0:  |t_exact - t_hw| <= (6.1e-7 + 3.5e-7) * t  (det_log1p 2.5e-7, det_rcp 1.2e-7, four roundings |
@@ -85,7 +86,7 @@ struct WaveLds {
     S1Entry s1[kS1Cap];
     S2Entry s2[kS2Cap];
     uint32_t s2pos[kS2Cap];        // pos | (threshold margin at k = 3) >> 8 << 16
-    uint16_t ring[kRing * 256];    // [row slot][gene-in-tile]: a walk ends below the 1/k table's 511 entries
+    uint8_t ring[kRing * 256];     // [row slot][gene-in-tile]; a count of 256 or more is left to K3h
     uint32_t late[kLateCap];       // (pos << 16) | count of results whose row has left the ring already
 };
 
@@ -163,15 +164,15 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
     const uint32_t ld32 = (uint32_t)ld;              // strip rows * ld < 2^32, checked by the host
     // pos of the last sample whose row has already left the ring (wave-uniform; -1: none)
     int32_t flushed_pos = -1;
-    for (int i = lane; i < kRing * 128; i += 64) reinterpret_cast<uint32_t*>(L.ring)[i] = 0u;
+    for (int i = lane; i < kRing * 64; i += 64) reinterpret_cast<uint32_t*>(L.ring)[i] = 0u;
 
     // store row `cl` of the strip from ring slot cl % kRing and clear the slot
     auto flush_row = [&](int cl, int32_t* row_ptr) {
-        uint2* slot = reinterpret_cast<uint2*>(L.ring + (cl & (kRing - 1)) * 256) + lane;
-        const uint2 packed = *slot;
-        *slot = make_uint2(0u, 0u);
-        const int32_t v[4] = {(int32_t)(packed.x & 0xffffu), (int32_t)(packed.x >> 16),
-                              (int32_t)(packed.y & 0xffffu), (int32_t)(packed.y >> 16)};
+        uint32_t* slot = reinterpret_cast<uint32_t*>(L.ring + (cl & (kRing - 1)) * 256) + lane;
+        const uint32_t packed = *slot;
+        *slot = 0u;
+        const int32_t v[4] = {(int32_t)(packed & 0xffu), (int32_t)((packed >> 8) & 0xffu),
+                              (int32_t)((packed >> 16) & 0xffu), (int32_t)(packed >> 24)};
         int32_t* dst = row_ptr + lane * 4;
         if (g0 < G) {
             if (VEC) {
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
     auto deliver = [&](uint32_t p, int32_t res) {
         const bool late = (int32_t)p <= flushed_pos;
         const unsigned long long ml = __builtin_amdgcn_ballot_w64(res > 0) & __builtin_amdgcn_ballot_w64(late);
-        if ((res > 0) & !late) L.ring[p & (kRing * 256 - 1)] = (uint16_t)res;   // slot = cell % kRing, gene-in-tile
+        if ((res > 0) & !late) L.ring[p & (kRing * 256 - 1)] = (uint8_t)res;    // slot = cell % kRing, gene-in-tile; res < 256
         if (ml != 0ull) {
             const int cnt = __popcll(ml);
             if (late_top + cnt > kLateCap) flush_late();
@@ -285,10 +286,13 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
         const bool close = near < 2u * dl;               // never for an idle lane: its dl is 0
         const bool any = hit0 | hit1 | hit2 | hit3;
         const bool done = any | (pf3 == 0u) | close;
-        const int32_t res = (done & !close) ? k + (hit0 ? 0 : (hit1 ? 1 : (hit2 ? 2 : 3))) : 0;
-        const unsigned long long close_m = __builtin_amdgcn_ballot_w64(near < 2u * dl);
+        const int32_t res_k = (done & !close) ? k + (hit0 ? 0 : (hit1 ? 1 : (hit2 ? 2 : 3))) : 0;
+        // a count that does not fit the ring's 8 bits (1 in 10^4 of the counts) is K3h's as well
+        const bool big = res_k > 255;
+        const int32_t res = big ? 0 : res_k;
+        const unsigned long long close_m = __builtin_amdgcn_ballot_w64(near < 2u * dl) | __builtin_amdgcn_ballot_w64(res_k > 255);
         deliver(pos, res);
-        list_sample(close_m, close, pos);
+        list_sample(close_m, close | big, pos);
         rem = rem4;
         ps = done ? 0.0f : (ps3 * num3) * inv.w;
         dl = done ? 0u : dl + 4u * kMarginPerTerm;
