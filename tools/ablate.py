@@ -55,6 +55,9 @@ VARIANTS = {
                    ("        const prnb::Words W = prnb::philox4x32_10<2>(c_lo, c_hi, (uint32_t)g0 >> 2, 0u, k0, k1);",
                     "        prnb::Words W; W.w[0] = (c_lo * 2654435761u) ^ ((uint32_t)g0 * 40503u); W.w[1] = W.w[0] * 3u + k0;\n"
                     "        W.w[2] = W.w[1] ^ 0x9E3779B9u; W.w[3] = W.w[2] + W.w[0];")],
+    # everything, mean segments not loaded (constant means): is the row stores' cost the wait they share with the loads?
+    "noload": [("            const float4 v = *reinterpret_cast<const float4*>(rowp + gload);",
+                "            const float4 v = make_float4(0.4f, 1.1f, 0.05f, 2.5f); asm volatile(\"\" :: \"v\"(rowp + gload));")],
     # everything, rows not stored
     "nostore": [("        if (g0 < G) {\n            if (VEC) {", "        if (g0 < G && v[0] == 12345) {\n            if (VEC) {")],
     # K3h without the redo walks / without the gamma-Poisson samples
@@ -74,7 +77,7 @@ VARIANTS = {
                       "        const bool close = false; const uint32_t near = 0xffffffffu;\n"),
                      ("        const uint32_t near = umin(umin(rem1 + d2, rem2 + d2), rem3 + d2);\n", "        const uint32_t near = 0xffffffffu;\n")],
     # stage 3 without the delivery of results
-    "s3_nodeliver": [("        deliver(pos, res);\n        list_sample(close_m, close, pos);", "        asm volatile(\"\" :: \"v\"(res), \"v\"(pos));\n        list_sample(close_m, close, pos);")],
+    "s3_nodeliver": [("        deliver(pos, res);\n        list_sample(close_m, close | big, pos);", "        asm volatile(\"\" :: \"v\"(res), \"v\"(pos));\n        list_sample(close_m, close | big, pos);")],
     # real variants (correct results): tuning constants
     "run16": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 16;")],
     "run48": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 48;"), ("constexpr int kS2Cap = 96;", "constexpr int kS2Cap = 112;")],
