@@ -78,6 +78,18 @@ VARIANTS = {
                      ("        const uint32_t near = umin(umin(rem1 + d2, rem2 + d2), rem3 + d2);\n", "        const uint32_t near = 0xffffffffu;\n")],
     # stage 3 without the delivery of results
     "s3_nodeliver": [("        deliver(pos, res);\n        list_sample(close_m, close | big, pos);", "        asm volatile(\"\" :: \"v\"(res), \"v\"(pos));\n        list_sample(close_m, close | big, pos);")],
+    # wave priority: stage 1 (memory issue) above stages 2/3, or the other way round
+    "prio_s1": [("        const float M[4] = {cur.M[0], cur.M[1], cur.M[2], cur.M[3]};\n", "        __builtin_amdgcn_s_setprio(2);\n        const float M[4] = {cur.M[0], cur.M[1], cur.M[2], cur.M[3]};\n"),
+                ("        while (s1_top >= 64) {\n            stage2_pass();\n            while (s2_top >= kS2Run) stage3_pass();\n        }\n        cur = nxt;",
+                 "        __builtin_amdgcn_s_setprio(0);\n        while (s1_top >= 64) {\n            stage2_pass();\n            while (s2_top >= kS2Run) stage3_pass();\n        }\n        cur = nxt;")],
+    "prio_s23": [("        const float M[4] = {cur.M[0], cur.M[1], cur.M[2], cur.M[3]};\n", "        __builtin_amdgcn_s_setprio(0);\n        const float M[4] = {cur.M[0], cur.M[1], cur.M[2], cur.M[3]};\n"),
+                 ("        while (s1_top >= 64) {\n            stage2_pass();\n            while (s2_top >= kS2Run) stage3_pass();\n        }\n        cur = nxt;",
+                  "        __builtin_amdgcn_s_setprio(2);\n        while (s1_top >= 64) {\n            stage2_pass();\n            while (s2_top >= kS2Run) stage3_pass();\n        }\n        cur = nxt;")],
+    # block order: gene tiles fastest (concurrent blocks write few rows of the count matrix, all their tiles)
+    "tilefast": [("    const int32_t tile_g = blockIdx.x / groups;\n    const int32_t strip = (blockIdx.x - tile_g * groups) * 4 + wv;",
+                  "    const int32_t tiles_all = (G + kTileG - 1) / kTileG;\n    const int32_t grp_ = blockIdx.x / tiles_all;\n    const int32_t tile_g = blockIdx.x - grp_ * tiles_all;\n    const int32_t strip = grp_ * 4 + wv;"),
+                 ("            const int32_t tile_g = blk / groups;\n            const int64_t n0 = (int64_t)((blk - tile_g * groups) * 4 + (int32_t)(r & 3)) * strip_cells;",
+                  "            const int32_t tiles_all = (G + kTileG - 1) / kTileG;\n            const int32_t grp_ = blk / tiles_all;\n            const int32_t tile_g = blk - grp_ * tiles_all;\n            const int64_t n0 = (int64_t)(grp_ * 4 + (int32_t)(r & 3)) * strip_cells;")],
     # real variants (correct results): tuning constants
     "run16": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 16;")],
     "run48": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 48;"), ("constexpr int kS2Cap = 96;", "constexpr int kS2Cap = 112;")],
