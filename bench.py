@@ -4,6 +4,7 @@ bench.py -- simulated cells x genes / second of the PROSSTT sampling hot path on
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3] [--scaling weak|strong]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+(run without a launcher, ``--gpus N`` with N > 1 starts that launcher itself as a child process)
 
 Workload (BASELINE.json metric): config C3 -- 8-branch tree (T = 50 per branch, K = 25
 programs), 20 000 genes, 50 000 cells PER GPU; the tree goes through the product's own
@@ -13,7 +14,9 @@ from the tree's density.  A *step* = one pass of the fused count sampler
 rank's cells, all inputs resident in HBM, output left in HBM.  With N GPUs the plan is sharded by
 branch (prosstt_amd.parallel), no collective on the data path: 50 000 x N cells under
 ``--scaling weak`` (default), the configuration's own cell count under ``--scaling strong``
-(e.g. ``--config C4 --scaling strong``: 200 000 cells over the N GPUs).
+(e.g. ``--config C4 --scaling strong``: 200 000 cells over the N GPUs).  With N > 1 the line also
+carries ``gather_ms`` (the one exchange of the path: count rows to rank 0, point-to-point) and
+``strong_scaling``: C4 (200 000 cells) and C5 (1 000 000 cells) split over the N GPUs.
 
 One JSON line on rank 0.
  * ``ms_per_step`` / ``value``: the sampler as bench.py calls it (no domain check);
@@ -179,57 +182,82 @@ def cpu_baseline_all_cores(work, pt, br, sc, cells, procs):
                 host_cpus=os.cpu_count())
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4", "C5"])
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: --cells-per-gpu (default: the config's cell count) on every GPU; "
-                         "strong: the config's cell count in all, split over the GPUs")
-    ap.add_argument("--cells-per-gpu", type=int, default=None)
-    ap.add_argument("--cpu-cells", type=int, default=10000, help="cells timed by the CPU baseline (0 = skip)")
-    ap.add_argument("--cpu-procs", type=int, default=-1,
-                    help="host processes of the all-cores CPU baseline (-1: one per physical core, 0: skip)")
-    ap.add_argument("--strict-steps", type=int, default=5, help="steps timed with the domain check on (0 = skip)")
-    ap.add_argument("--gather", action="store_true", help="also time the optional row gather to rank 0")
-    args = ap.parse_args()
+def _free_port():
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
 
-    import torch
-    import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                     "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d" % (args.gpus, args.gpus))
-    # functional test of the N > 1 path on a 1-GPU box: PROSSTT_BENCH_BACKEND=gloo PROSSTT_BENCH_ONE_GPU=1
-    backend = os.environ.get("PROSSTT_BENCH_BACKEND", "nccl")
-    if os.environ.get("PROSSTT_BENCH_ONE_GPU") == "1":
-        local = 0
-    torch.cuda.set_device(local)
-    use_dist = world > 1 or os.environ.get("PROSSTT_BENCH_FORCE_DIST") == "1"   # the latter: RCCL path on 1 GPU
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
 
-    from prosstt_amd import device, parallel, workloads
-    ctx = device.get_context(local)
+def launch_ranks(gpus, argv, script=None):
+    """``python bench.py --gpus N`` outside a launcher: start the N ranks as a CHILD process
+    (``python -m torch.distributed.run``; nothing in this parent has touched the GPU, and it never
+    replaces itself), let rank 0's JSON line through on the inherited stdout, return the child's
+    exit code."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           script or os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
 
-    # ---- build the tree through the product's lineage stage (not part of the metric) -------
-    work = workloads.build(args.config)
+
+class Job:
+    """What every case of one bench.py process shares: ranks, device context, fences."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.args = torch, dist, args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        # functional test of the N > 1 path on a 1-GPU box: PROSSTT_BENCH_BACKEND=gloo PROSSTT_BENCH_ONE_GPU=1
+        self.backend = os.environ.get("PROSSTT_BENCH_BACKEND", "nccl")
+        if os.environ.get("PROSSTT_BENCH_ONE_GPU") == "1":
+            local = 0
+        torch.cuda.set_device(local)
+        self.use_dist = self.world > 1 or os.environ.get("PROSSTT_BENCH_FORCE_DIST") == "1"   # the latter: RCCL path on 1 GPU
+        if self.use_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            else:
+                dist.init_process_group(self.backend)
+        from prosstt_amd import device
+        self.ctx = device.get_context(local)
+        self.red_dev = self.ctx.torch_device if self.backend == "nccl" else torch.device("cpu")
+
+    def fence(self):
+        if self.use_dist:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        t = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self.red_dev)
+        if self.use_dist:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.use_dist:
+            self.dist.destroy_process_group()
+
+
+def run_case(job, config, scaling, cells_per_gpu, steps, warmup, strict_steps, gather):
+    """One workload on the job's ranks: W untimed + K timed passes of the count sampler over each rank's
+    shard (barrier + synchronize on both sides, max over ranks), optionally the row gather to rank 0."""
+    from prosstt_amd import parallel, workloads
+    torch, ctx, world, rank = job.torch, job.ctx, job.world, job.rank
+    work = workloads.build(config)          # the tree goes through the product's lineage stage (not part of the metric)
     tree, G = work.tree, work.tree.G
-    rows_total = work.info["rows"]
-    if args.scaling == "strong":
-        n_total = args.cells_per_gpu * world if args.cells_per_gpu else work.cfg["N"]
+    if scaling == "strong":
+        n_total = cells_per_gpu * world if cells_per_gpu else work.cfg["N"]
         per_gpu = n_total // world
     else:
-        per_gpu = args.cells_per_gpu or work.cfg["N"]
+        per_gpu = cells_per_gpu or work.cfg["N"]
         n_total = per_gpu * world
     pt, br, sc, rows = work.plan(n_total)
     mine, owner = parallel.shard_cells(br, rank, world)
@@ -246,98 +274,161 @@ def main():
         ctx.sample_counts(means, d_rows, d_sc, d_al, d_be, seed=seed, out=out, cell_index=d_idx,
                           check_domain=strict, time_kernel=timed)
 
-    def fence():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(1000 + i)
-    fence()
+    job.fence()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         step(i, timed=True)                    # HIP events bracket K3 on the launch stream
-    fence()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = [ctx.last_kernel_ms()]         # mean over the K launches of the timed region
-    red_dev = ctx.torch_device if backend == "nccl" else torch.device("cpu")
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-    k_max = torch.tensor([float(np.mean(kernel_ms))], dtype=torch.float64, device=red_dev)
-    if use_dist:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-        dist.all_reduce(k_max, op=dist.ReduceOp.MAX)
-    elapsed = float(t_max.item())
-    ms_per_step = elapsed / args.steps * 1e3
-    value = n_total * G / (elapsed / args.steps)
+    job.fence()
+    elapsed = job.max_over_ranks(time.perf_counter() - t0)
+    kms = job.max_over_ranks(ctx.last_kernel_ms())      # mean over the K launches of the timed region
+    res = dict(work=work, plan=(pt, br, sc), G=G, n_total=n_total, per_gpu=per_gpu, cells_on_rank=int(len(mine)),
+               ms_per_step=elapsed / steps * 1e3, value=n_total * G / (elapsed / steps), kernel_ms=kms,
+               rows_total=work.info["rows"], ms_strict=None, gather_ms=None)
 
     # the product API's default: with the domain check of the reference's scipy call
-    ms_strict = None
-    if args.strict_steps > 0:
+    if strict_steps > 0:
         step(99, strict=True)
-        fence()
+        job.fence()
         t0 = time.perf_counter()
-        for i in range(args.strict_steps):
+        for i in range(strict_steps):
             step(i, strict=True)
-        fence()
-        t_s = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
-        if use_dist:
-            dist.all_reduce(t_s, op=dist.ReduceOp.MAX)
-        ms_strict = float(t_s.item()) / args.strict_steps * 1e3
+        job.fence()
+        res["ms_strict"] = job.max_over_ranks(time.perf_counter() - t0) / strict_steps * 1e3
 
-    gather_ms = None
-    if args.gather:
-        fence()
+    # the one exchange of the path: count rows to rank 0 (point-to-point over xGMI), timed on its own.
+    # Bounded so that root's copy of the whole matrix plus its own shard stays far inside 288 GB.
+    if gather and world > 1 and 4 * n_total * G <= 64e9:
+        small = min(64, len(mine))
+        parallel.gather_rows(out[:small], mine[:small], n_total)        # connections come up outside the timed region
+        job.fence()
         t0 = time.perf_counter()
         full = parallel.gather_rows(out, mine, n_total)
-        fence()
-        gather_ms = (time.perf_counter() - t0) * 1e3
+        job.fence()
+        res["gather_ms"] = job.max_over_ranks(time.perf_counter() - t0) * 1e3
         del full
 
     # sanity inside the bench: first moment of this rank's shard (catches a silently dead kernel)
     mu_sum = float((means.double().sum(dim=1)[d_rows.long()] * d_sc).sum())
-    x_sum = float(out.sum(dtype=torch.float64))
-    ratio = x_sum / mu_sum
+    res["ratio"] = float(out.sum(dtype=torch.float64)) / mu_sum if mu_sum > 0 else float("nan")
+    res["tree"] = tree
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4", "C5"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --cells-per-gpu (default: the config's cell count) on every GPU; "
+                         "strong: the config's cell count in all, split over the GPUs")
+    ap.add_argument("--cells-per-gpu", type=int, default=None)
+    ap.add_argument("--cpu-cells", type=int, default=10000, help="cells timed by the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-procs", type=int, default=-1,
+                    help="host processes of the all-cores CPU baseline (-1: one per physical core, 0: skip)")
+    ap.add_argument("--strict-steps", type=int, default=5, help="steps timed with the domain check on (0 = skip)")
+    ap.add_argument("--strong-configs", default="C4,C5",
+                    help="with N > 1: configurations also run at their own cell count split over the GPUs "
+                         "(reported under 'strong_scaling'; '' = none)")
+    ap.add_argument("--no-gather", action="store_true", help="do not time the row gather to rank 0 (N > 1)")
+    ap.add_argument("--no-end-to-end", action="store_true",
+                    help="skip the end-to-end time of the drop-in sample_density call (N = 1)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))      # before anything here has touched torch.cuda
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world_env:
+        sys.exit("--gpus %d but the launcher started %d rank(s)" % (args.gpus, world_env))
+
+    job = Job(args)
+    world, rank = job.world, job.rank
+    main_case = run_case(job, args.config, args.scaling, args.cells_per_gpu, args.steps, args.warmup,
+                         args.strict_steps, gather=not args.no_gather)
+    work, G, n_total = main_case["work"], main_case["G"], main_case["n_total"]
+    pt, br, sc = main_case["plan"]
+
+    end_to_end = None
+    if world == 1 and not args.no_end_to_end and rank == 0:
+        end_to_end = end_to_end_ms(main_case["tree"], work, n_total)
+
+    strong = []
+    if world > 1:
+        for cfg in [c for c in args.strong_configs.split(",") if c]:
+            case = run_case(job, cfg, "strong", None, max(3, args.steps // 2), 2, 0, gather=not args.no_gather)
+            strong.append({"config": cfg, "cells_total": case["n_total"], "genes": case["G"],
+                           "cells_on_rank_0": case["cells_on_rank"], "value": case["value"], "unit": "cells*genes/s",
+                           "ms_per_step": case["ms_per_step"], "kernel_ms_max_over_ranks": case["kernel_ms"],
+                           "gather_ms": case["gather_ms"], "lineage_s": round(case["work"].info["lineage_s"], 3),
+                           "lineage_attempts": case["work"].info["attempts"],
+                           "sum_counts_over_sum_means": round(case["ratio"], 5)})
+            del case
 
     if rank == 0:
-        kms = float(np.mean(kernel_ms))
-        abytes = algorithmic_bytes(len(mine), G, rows_total)
+        kms = main_case["kernel_ms"]
+        abytes = algorithmic_bytes(main_case["cells_on_rank"], G, main_case["rows_total"])
         achieved = abytes / (kms * 1e-3)
-        default_shape = args.config == "C3" and args.cells_per_gpu is None and args.scaling == "weak"
-        traffic, traffic_src = profiled_traffic() if default_shape else (None, "profiles are of the default C3 run")
+        ms_per_step = main_case["ms_per_step"]
+        default_shape = args.config == "C3" and args.cells_per_gpu is None and args.scaling == "weak" and world == 1
+        traffic, traffic_src = profiled_traffic() if default_shape else (None, "profiles are of the default 1-GPU C3 run")
         line = {
             "metric": "simulated cells*genes per second (count sampling: sample_density -> draw_counts)",
-            "value": value, "unit": "cells*genes/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "ms_per_step_strict": ms_strict,
+            "value": main_case["value"], "unit": "cells*genes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "ms_per_step_strict": main_case["ms_strict"],
             "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %d-branch tree (T=50, K=25), %d genes, %d cells per GPU "
                                    "(%d total), density sampling; lineage via the product pipeline"
-                                   % (args.config, work.info["branches"], G, per_gpu, n_total),
-                       "cells_on_rank_0": int(len(mine)),
+                                   % (args.config, work.info["branches"], G, main_case["per_gpu"], n_total),
+                       "cells_on_rank_0": main_case["cells_on_rank"],
                        "parallelism": "cells sharded by branch, %d rank(s), no data-path collective" % world,
                        "lineage_attempts": work.info["attempts"], "lineage_s": round(work.info["lineage_s"], 3),
-                       "sum_counts_over_sum_means": round(ratio, 5)},
+                       "sum_counts_over_sum_means": round(main_case["ratio"], 5)},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k3::sample_counts_stream_kernel<true>", "kernel_ms": kms,
                          "frac_whole_step": abytes / (ms_per_step * 1e-3) / HBM_PEAK,
                          "algorithmic_bytes_per_launch": abytes, "kernel_source_sha": kernel_source_sha(),
-                         "note": "frac = algorithmic bytes / the dominant kernel's mean duration (HIP events); "
-                                 "frac_whole_step prices them against ms_per_step (K3h, prep kernels, gaps). "
+                         "note": "frac = algorithmic bytes / the dominant kernel's mean duration (HIP events, max over "
+                                 "ranks); frac_whole_step prices them against ms_per_step (K3h, prep kernels, gaps). "
                                  "VALU-issue-bound sampler: DESIGN.md section 6 and profiles/"},
         }
-        if gather_ms is not None:
-            line["gather_ms"] = gather_ms
+        if main_case["gather_ms"] is not None:
+            line["gather_ms"] = main_case["gather_ms"]
+        if strong:
+            line["strong_scaling"] = strong
+        if end_to_end is not None:
+            line["end_to_end_ms"] = end_to_end
         if world == 1 and args.cpu_cells > 0:
             line["cpu_baseline"] = cpu_baseline(work, pt, br, sc, min(args.cpu_cells, n_total))
-            line["speedup_vs_cpu_1core"] = value / line["cpu_baseline"]["value"]
+            line["speedup_vs_cpu_1core"] = main_case["value"] / line["cpu_baseline"]["value"]
         procs = physical_cores() if args.cpu_procs < 0 else args.cpu_procs
         if world == 1 and args.cpu_cells > 0 and procs > 1:
             line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(
                 work, pt, br, sc, min(max(args.cpu_cells, 250 * procs), n_total), procs)
-        print(json.dumps(line))
-    if use_dist:
-        dist.destroy_process_group()
+        print(json.dumps(line), flush=True)
+    job.close()
+
+
+def end_to_end_ms(tree, work, n_cells):
+    """Wall time of the drop-in call a reference user makes -- ``simulation.sample_density`` returning the
+    reference's (N, G) int64 ndarray: host plan, kernels, domain check, and the device-to-host copy of the
+    widened matrix (PCIe-inclusive; never ``value``).  Second of two calls (the first sizes the pinned
+    staging buffers)."""
+    from prosstt_amd import simulation as sim
+    best = None
+    for _ in range(2):
+        np.random.seed(work.cfg["seed"] + 1)
+        t0 = time.perf_counter()
+        x = sim.sample_density(tree, n_cells, alpha=work.alpha, beta=work.beta)[0]
+        dt = (time.perf_counter() - t0) * 1e3
+        assert x.shape == (n_cells, tree.G) and x.dtype == np.int64
+        del x
+        best = dt
+    return best
 
 
 if __name__ == "__main__":

@@ -184,6 +184,28 @@ class Context:
         return out
 
 
+def host_fingerprint(arrays):
+    """Identity and content fingerprint of host arrays that a device tensor mirrors: the caches of
+    ``Tree.device_means`` and of ``simulate_lineage`` compare it before they trust their device copy,
+    so that the caller's arrays stay writable (as the reference's are) and an in-place edit is seen.
+    One pass at memory speed (64 MB in ~6 ms)."""
+    try:
+        from xxhash import xxh3_64_intdigest as digest
+    except ImportError:                              # position-blind, still catches any single edit
+        def digest(buf):
+            flat = np.frombuffer(buf, dtype=np.uint8)
+            head = flat[:flat.size // 8 * 8].view(np.uint64)
+            return int(head.sum(dtype=np.uint64)) ^ (int(flat[head.size * 8:].sum()) << 1)
+    out = []
+    for a in arrays:
+        if isinstance(a, np.ndarray):
+            c = a if a.flags.c_contiguous else np.ascontiguousarray(a)
+            out.append((id(a), a.shape, a.dtype.str, digest(c.data if c.size else b"")))
+        else:
+            out.append((id(a), None, None, None))
+    return tuple(out)
+
+
 def to_host_int64(counts):
     """int32 device counts -> the reference's int64 ndarray.  Widening on the device and copying
     8 B per count is several times faster than a host-side ``astype`` of a multi-GB matrix."""

@@ -61,14 +61,52 @@ def shard_cells(branch_of_cell, rank, world_size):
     return np.nonzero(owner_of_cell == rank)[0].astype(np.int64), owner
 
 
+def _comm_device(group=None):
+    """Where collective buffers live: the current GPU under RCCL ("nccl"), the host under gloo."""
+    import torch
+    if _dist().get_backend(group) == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
 def broadcast_plan(plan, group=None, src=0):
-    """Make every rank use rank ``src``'s (pseudotime, branches, scalings)."""
+    """Make every rank use rank ``src``'s ``(pseudotime, branches, scalings, seed)``.
+
+    Tensor broadcasts, not pickles: a header (N, number of distinct labels, the two halves of the
+    seed), then pseudotime (int64), branch codes (int32) and scalings (float64) -- 20 B per cell; only
+    the handful of distinct branch labels travels as Python objects.  ``src`` is a rank of ``group``."""
+    import torch
+    dist = _dist()
     rank, size = world(group)
     if size == 1:
         return plan
-    box = [plan if rank == src else None]
-    _dist().broadcast_object_list(box, src=src, group=group)
-    return box[0]
+    dev = _comm_device(group)
+    gsrc = dist.get_global_rank(group, src) if group is not None else src
+    if rank == src:
+        pt, br, sc, seed = plan
+        labels, codes = np.unique(np.asarray(br), return_inverse=True)
+        head = torch.tensor([len(pt), len(labels), int(seed) & 0xffffffff, (int(seed) >> 32) & 0xffffffff],
+                            dtype=torch.int64, device=dev)
+    else:
+        head = torch.zeros(4, dtype=torch.int64, device=dev)
+    dist.broadcast(head, src=gsrc, group=group)
+    n, n_labels, lo, hi = (int(v) for v in head.tolist())
+    box = [list(labels) if rank == src else None]
+    dist.broadcast_object_list(box, src=gsrc, group=group)            # a few labels (str or int), not the plan
+    labels = np.asarray(box[0])
+    if rank == src:
+        t_pt = torch.as_tensor(np.ascontiguousarray(pt, dtype=np.int64)).to(dev)
+        t_br = torch.as_tensor(np.ascontiguousarray(codes, dtype=np.int32)).to(dev)
+        t_sc = torch.as_tensor(np.ascontiguousarray(sc, dtype=np.float64)).to(dev)
+    else:
+        t_pt = torch.empty(n, dtype=torch.int64, device=dev)
+        t_br = torch.empty(n, dtype=torch.int32, device=dev)
+        t_sc = torch.empty(n, dtype=torch.float64, device=dev)
+    for t in (t_pt, t_br, t_sc):
+        dist.broadcast(t, src=gsrc, group=group)
+    if rank == src:
+        return plan
+    return t_pt.cpu().numpy(), labels[t_br.cpu().numpy()], t_sc.cpu().numpy(), lo | (hi << 32)
 
 
 def _digest(*arrays):
@@ -84,12 +122,20 @@ def _digest(*arrays):
 
 def assert_replicas_agree(tree, alpha, beta, group=None):
     """Every rank must hold the same tree and per-gene parameters (the lineage is replicated, not
-    exchanged): compare a digest of (row sums of the device mean tensor, alpha, beta) across ranks."""
+    exchanged): compare a digest of (row sums of the device mean tensor, alpha, beta) across ranks.
+    The digest (a device reduction and a small copy back) is computed once per mean tensor and cached
+    on the tree; what is exchanged per call is the 16-character digest -- control path, not data path."""
     rank, size = world(group)
     if size == 1:
         return
-    row_sums = tree.device_means().double().sum(dim=1).cpu().numpy()
-    mine = _digest(row_sums, np.asarray(alpha, np.float64), np.asarray(beta, np.float64))
+    means = tree.device_means()
+    ab = _digest(np.asarray(alpha, np.float64), np.asarray(beta, np.float64))
+    key = (id(means), means.data_ptr(), tuple(means.shape))
+    cached = getattr(tree, "_replica_digest", None)
+    if cached is None or cached[0] != key:
+        cached = (key, _digest(means.double().sum(dim=1).cpu().numpy()))
+        tree._replica_digest = cached
+    mine = cached[1] + ab
     seen = [None] * size
     _dist().all_gather_object(seen, mine, group=group)
     if len(set(seen)) != 1:
@@ -129,14 +175,15 @@ def sample_density_sharded(tree, no_cells, alpha=0.3, beta=2, scale=True, scale_
     return counts, mine, pt, br, sc
 
 
-def gather_rows(local_rows, cell_index, total_rows, group=None, dst=0, chunk_rows=8192):
-    """Collect row shards on rank ``dst`` into a (total_rows, G) tensor in global order.
+def gather_rows(local_rows, cell_index, total_rows, group=None, dst=0, chunk_rows=None, chunk_bytes=256 << 20):
+    """Collect row shards on rank ``dst`` (a rank of ``group``) into a (total_rows, G) tensor in global order.
 
     ``local_rows`` (n_local, G) and ``cell_index`` (n_local,) of every rank; returns the full
     tensor on ``dst`` and None elsewhere.  Point-to-point (shards are unequal, so not a gather
-    collective), in rounds of ``chunk_rows`` rows per sender: the root posts the receives of a
-    round from ALL senders at once (``batch_isend_irecv``: every xGMI link of the root carries
-    data at the same time) and scatters round r with ``index_copy_`` while round r + 1 is in
+    collective), in rounds of ``chunk_rows`` rows per sender (default: ``chunk_bytes`` = 256 MB per
+    sender, so the root stages 2 rounds x (size - 1) x 256 MB whatever G is): the root posts the
+    receives of a round from ALL senders at once (``batch_isend_irecv``: every xGMI link of the root
+    carries data at the same time) and scatters round r with ``index_copy_`` while round r + 1 is in
     flight.  A rank may own no rows."""
     import torch
     dist = _dist()
@@ -147,6 +194,12 @@ def gather_rows(local_rows, cell_index, total_rows, group=None, dst=0, chunk_row
         out = torch.empty((total_rows, G), dtype=local_rows.dtype, device=local_rows.device)
         out.index_copy_(0, index, local_rows)
         return out
+    if chunk_rows is None:
+        chunk_rows = max(1, int(chunk_bytes) // max(1, G * local_rows.element_size()))
+
+    def peer(r):                     # P2POp addresses GLOBAL ranks
+        return dist.get_global_rank(group, r) if group is not None else r
+
     sizes = [None] * size
     dist.all_gather_object(sizes, int(local_rows.shape[0]), group=group)
     rounds = max((n + chunk_rows - 1) // chunk_rows for n in sizes) if max(sizes) else 0
@@ -156,8 +209,8 @@ def gather_rows(local_rows, cell_index, total_rows, group=None, dst=0, chunk_row
             lo, hi = r * chunk_rows, min((r + 1) * chunk_rows, sizes[rank])
             if lo >= hi:
                 break
-            ops = [dist.P2POp(dist.isend, index[lo:hi].contiguous(), dst, group),
-                   dist.P2POp(dist.isend, rows[lo:hi], dst, group)]
+            ops = [dist.P2POp(dist.isend, index[lo:hi].contiguous(), peer(dst), group),
+                   dist.P2POp(dist.isend, rows[lo:hi], peer(dst), group)]
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
         return None
@@ -174,7 +227,7 @@ def gather_rows(local_rows, cell_index, total_rows, group=None, dst=0, chunk_row
             idx = torch.empty(n, dtype=torch.int64, device=local_rows.device)
             buf = torch.empty((n, G), dtype=local_rows.dtype, device=local_rows.device)
             bufs.append((idx, buf))
-            ops += [dist.P2POp(dist.irecv, idx, src, group), dist.P2POp(dist.irecv, buf, src, group)]
+            ops += [dist.P2POp(dist.irecv, idx, peer(src), group), dist.P2POp(dist.irecv, buf, peer(src), group)]
         return bufs, (dist.batch_isend_irecv(ops) if ops else [])
 
     pending = post(0) if rounds else ([], [])

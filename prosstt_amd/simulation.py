@@ -124,12 +124,23 @@ def _stack_rows(tree, per_branch):
     return np.concatenate([np.asarray(per_branch[b], dtype=np.float64) for b in tree.branches], axis=0)
 
 
-def _device_rel(tree, relative_means):
-    """(sum T_b, G) binary64 device tensor of ``relative_means``; the tensor that
-    simulate_lineage left on the device is reused when these are the arrays it returned."""
-    import torch
+def _lineage_cache(tree, relative_means):
+    """The device tensors simulate_lineage left behind, if ``relative_means`` are the very arrays it
+    returned AND their contents are untouched (fingerprint); else None -- the caller uploads."""
     cache = tree._lineage
-    if cache is not None and all(relative_means[b] is cache["host"][b] for b in tree.branches):
+    if cache is None or not all(relative_means[b] is cache["host"][b] for b in tree.branches):
+        return None
+    if _device.host_fingerprint([cache["host"][b] for b in tree.branches]) != cache["print"]:
+        return None
+    return cache
+
+
+def _device_rel(tree, relative_means):
+    """(sum T_b, G) binary64 device tensor of ``relative_means``; the tensor that simulate_lineage
+    left on the device is reused when these are the unmodified arrays it returned."""
+    import torch
+    cache = _lineage_cache(tree, relative_means)
+    if cache is not None:
         return cache["rel"]
     ctx = _device.get_context()
     return ctx.tensor(_stack_rows(tree, relative_means), torch.float64)
@@ -139,8 +150,8 @@ def _device_gene_max(tree, relative_means):
     """(G,) device tensor: max over branches and time of the relative means (log of
     sim_utils.max_relat_exp reduced over branches, sim_utils.py:460-461)."""
     import torch
-    cache = tree._lineage
-    if cache is not None and all(relative_means[b] is cache["host"][b] for b in tree.branches):
+    cache = _lineage_cache(tree, relative_means)
+    if cache is not None:
         return cache["gene_max"]
     ctx = _device.get_context()
     rel = ctx.tensor(_stack_rows(tree, relative_means), torch.float64)
@@ -232,11 +243,10 @@ def simulate_lineage(tree, rel_exp_cutoff=8, intra_branch_tol=0.5, inter_branch_
         ctx.lineage_commit(programs[branch], H, rel[at:at + int(tree.time[key])], gene_max)
     host = rel.cpu().numpy()
     # the device keeps `rel` for simulate_base_gene_exp / add_genes, which recognise these arrays by
-    # identity: read-only, so that an in-place edit raises instead of being silently ignored (pass
-    # modified COPIES to those functions: they are uploaded afresh)
-    host.flags.writeable = False
+    # identity and fingerprint: writable like the reference's; edited arrays are uploaded afresh
     rel_means = {b: host[offsets[b]:offsets[b] + int(tree.time[b])] for b in tree.branches}
-    tree._lineage = dict(rel=rel, gene_max=gene_max, host=rel_means, H=H)
+    tree._lineage = dict(rel=rel, gene_max=gene_max, host=rel_means, H=H,
+                         print=_device.host_fingerprint([rel_means[b] for b in tree.branches]))
     ordered = {}
     for branch in programs:                      # keep the reference's insertion (BFS) order
         ordered[branch] = rel_means[_plain_label(tree, branch)]

@@ -37,6 +37,7 @@ class Tree(object):
         self.branches = list(time.keys())
         self._host_means = None        # dict label -> (T_b, G) float64, or None
         self._dev_means = None         # torch float32 (sum T_b, G), or None
+        self._dev_print = None         # fingerprint of _host_means when _dev_means was made from / mirrored to it
         self._lineage = None           # device cache left by simulate_lineage
         if modules is None:
             # consumes one draw of the global stream, as tree.py:67-68 does
@@ -143,39 +144,47 @@ class Tree(object):
 
     @property
     def means(self):
-        """dict branch -> (T_b, G) float64 (tree.py:64, 213).  Materialised from the
-        device tensor on first access when the means were computed there (the values are the
-        binary32 ones the sampler uses).  These arrays are READ-ONLY views of that tensor's copy:
-        the sampler reads the device tensor, so an in-place edit would silently not take effect --
-        assign a new dict to ``tree.means`` (or call ``add_genes``) to change the means."""
+        """dict branch -> (T_b, G) float64 (tree.py:64, 213).  Materialised from the device tensor
+        on first access when the means were computed there (the values are the binary32 ones the
+        sampler uses).  The arrays are ordinary writable arrays, as in the reference: the sampler
+        reads the device tensor, which ``device_means`` refreshes whenever this dict or the contents
+        of its arrays have changed since the last upload (a fingerprint is compared)."""
         if self._host_means is None and self._dev_means is not None:
             host = self._dev_means.cpu().numpy().astype(np.float64)
-            host.flags.writeable = False
             offsets, _ = self.row_offsets()
             self._host_means = {b: host[offsets[b]:offsets[b] + int(self.time[b])] for b in self.branches}
+            self._dev_print = self._means_fingerprint()
         return self._host_means
 
     @means.setter
     def means(self, value):
         self._host_means = value
         self._dev_means = None
+        self._dev_print = None
+
+    def _means_fingerprint(self):
+        return _device.host_fingerprint([self._host_means.get(b) if hasattr(self._host_means, "get")
+                                         else self._host_means[b] for b in self.branches])
 
     def device_means(self):
-        """(sum T_b, G) float32 device tensor; uploads the host dict if that is all there is."""
+        """(sum T_b, G) float32 device tensor.  When the host dict exists (the caller assigned it,
+        or read ``tree.means``), its fingerprint decides whether the device copy is current:
+        ``tree.means[b] = array`` and in-place edits both lead to a fresh upload; the caller's
+        arrays are never frozen or modified."""
+        if self._host_means is not None:
+            now = self._means_fingerprint()
+            if self._dev_means is None or now != self._dev_print:
+                ctx = _device.get_context()
+                import torch
+                stacked = np.concatenate([np.asarray(self._host_means[b], dtype=np.float64)
+                                          for b in self.branches], axis=0)
+                as32 = stacked.astype(np.float32)
+                tiny = np.float32(1.17549435e-38)      # positive means stay positive in binary32 (see means_from_rel)
+                as32[(stacked > 0) & (as32 < tiny)] = tiny
+                self._dev_means = ctx.tensor(as32, torch.float32)     # a private copy goes up
+                self._dev_print = now
         if self._dev_means is None:
-            if self._host_means is None:
-                raise ValueError("the tree has no gene expression yet: call add_genes first")
-            ctx = _device.get_context()
-            import torch
-            stacked = np.concatenate([np.asarray(self._host_means[b], dtype=np.float64)
-                                      for b in self.branches], axis=0)
-            as32 = stacked.astype(np.float32)
-            tiny = np.float32(1.17549435e-38)      # positive means stay positive in binary32 (see means_from_rel)
-            as32[(stacked > 0) & (as32 < tiny)] = tiny
-            self._dev_means = ctx.tensor(as32, torch.float32)
-            for b in self.branches:                  # the upload is now what the sampler reads: freeze the source
-                if isinstance(self._host_means[b], np.ndarray):
-                    self._host_means[b].flags.writeable = False
+            raise ValueError("the tree has no gene expression yet: call add_genes first")
         return self._dev_means
 
     def add_genes(self, *args):
@@ -204,6 +213,7 @@ class Tree(object):
         base = ctx.tensor(np.asarray(base_gene_expr, dtype=np.float64), torch.float64)
         self._dev_means = ctx.means_from_rel(rel, base)
         self._host_means = None
+        self._dev_print = None
 
     def _add_genes_from_average(self, average_expression):
         """tree.py:186-213, with the reference's shape checks."""

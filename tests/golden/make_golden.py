@@ -329,6 +329,66 @@ def g10_written_files():
     save("g10_written_files", **out)
 
 
+# --------------------------------------------------------------------- G11
+class _Node:
+    """Stand-in for a node of the third-party ``newick`` package (absent here): exactly the attributes
+    tree_utils.parse_newick reads -- name, length, descendants, ancestor, walk() in pre-order."""
+    def __init__(self, name, length):
+        self.name, self.length, self.descendants, self.ancestor = name, length, [], None
+
+    def walk(self):
+        yield self
+        for child in self.descendants:
+            yield from child.walk()
+
+
+def _nodes_from_table(names, lengths, parents):
+    nodes = [_Node(str(n), float(l)) for n, l in zip(names, lengths)]
+    for node, parent in zip(nodes, parents):
+        if parent >= 0:
+            node.ancestor = nodes[parent]
+            nodes[parent].descendants.append(node)
+    return nodes
+
+
+def g11_velocity_and_newick():
+    """Tree.set_velocity -> density (tree.py:241-264, tree_utils.py:176-242; numpy 2 dropped the ``np.Inf``
+    the reference spells, restored here as an alias) and tree_utils.parse_newick (tree_utils.py:10-56) on
+    node tables (name, length, parent) that the test turns into the same stand-in nodes."""
+    from prosstt import tree_utils as rtut
+    np.Inf = np.inf
+    out = {}
+    rng = np.random.default_rng(11)
+    for tname in ("bifurcation", "unequal"):
+        spec = TREES[tname]
+        for vname, lo in (("pos", 0.2), ("neg", -1.5)):        # the second set dips below zero: sanitize_velocity shifts it
+            t = build_tree(spec, 4, 3)
+            vel = {b: rng.uniform(lo, 3.0, size=spec["time"][b]) for b in spec["time"]}
+            out.update({"vel_%s_%s_in_%s" % (tname, vname, b): vel[b].copy() for b in vel})
+            t.set_velocity({b: vel[b].copy() for b in vel})
+            out.update({"vel_%s_%s_density_%s" % (tname, vname, b): np.asarray(t.density[b]) for b in vel})
+        out["vel_%s_tree" % tname] = tree_json(spec, 4, 3)
+    # parse_newick: (name, length, parent index) tables in pre-order; 0 = "no length given" -> def_time,
+    # fractional lengths are truncated by int()
+    tables = {
+        "bif": (["A", "B", "C"], [50, 30, 0], [-1, 0, 0], "(B:30,C)A:50;"),
+        "deep": (["root", "x", "x1", "x2", "y", "y1", "y1a", "y1b", "z"], [0, 12.7, 5, 0, 40, 8.2, 3, 3.9, 60],
+                 [-1, 0, 1, 1, 0, 4, 5, 5, 0], "((x1:5,x2)x:12.7,((y1a:3,y1b:3.9)y1:8.2)y:40,z:60)root;"),
+        "single": (["only"], [17], [-1], "only:17;"),
+    }
+    for name, (names, lengths, parents, text) in tables.items():
+        nodes = _nodes_from_table(names, lengths, parents)
+        top, time, branches, bpoints, root = rtut.parse_newick([nodes[0]], 40)
+        out.update({"nw_%s_names" % name: np.array(names), "nw_%s_lengths" % name: np.array(lengths, float),
+                    "nw_%s_parents" % name: np.array(parents), "nw_%s_text" % name: np.array(text),
+                    "nw_%s_topology" % name: np.array(top).reshape(-1, 2) if top else np.zeros((0, 2), "<U1"),
+                    "nw_%s_time_keys" % name: np.array(list(time.keys())),
+                    "nw_%s_time_vals" % name: np.array(list(time.values())),
+                    "nw_%s_counts" % name: np.array([branches, bpoints]),
+                    "nw_%s_root" % name: np.array("" if root is None else root)})
+    save("g11_velocity_newick", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:                      # regenerate selected fixtures only, e.g. `make_golden.py g7_nb_tables`
         for name in sys.argv[1:]:
@@ -343,4 +403,5 @@ if __name__ == "__main__":
     g7_nb_tables()
     g9_helpers()
     g10_written_files()
+    g11_velocity_and_newick()
     g8_end_to_end()

@@ -331,3 +331,72 @@ def test_writers_reproduce_the_reference_files(tmp_path):
     np.testing.assert_array_equal(back["umsB"], uMs["B"])
     with pytest.raises(ValueError):
         tut.save_matrices_npz("job", d, np.array([[2 ** 40]]))
+
+
+def test_host_arrays_stay_writable_and_edits_reach_the_device(monkeypatch):
+    """The caller's mean arrays are never frozen; ``tree.means[b] = array`` and an in-place edit both
+    invalidate the device copy (a fingerprint is compared), an untouched dict does not re-upload."""
+    from prosstt_amd import device
+
+    class Fake:
+        torch_device = "cpu"
+        uploads = 0
+
+        def tensor(self, host, dtype):
+            import torch
+            Fake.uploads += 1
+            return torch.as_tensor(np.array(host)).to(dtype)
+
+    monkeypatch.setattr(device, "get_context", lambda *a, **k: Fake())
+    t = ptree.Tree(topology=[["A", "B"]], time={"A": 4, "B": 3}, num_branches=2, branch_points=0, modules=2, G=5)
+    mine = {"A": np.full((4, 5), 2.0), "B": np.full((3, 5), 3.0)}
+    t.means = mine
+    d0 = t.device_means()
+    assert Fake.uploads == 1 and t.device_means() is d0 and Fake.uploads == 1
+    assert all(a.flags.writeable for a in mine.values())            # caller-owned arrays are left alone
+    mine["A"][1, 2] = 7.0                                            # in-place edit of the caller's array
+    d1 = t.device_means()
+    assert Fake.uploads == 2 and float(d1[1, 2]) == 7.0
+    t.means["B"] = np.full((3, 5), 9.0)                              # the reference's idiom: item assignment
+    d2 = t.device_means()
+    assert Fake.uploads == 3 and float(d2[4, 0]) == 9.0 and float(d2[1, 2]) == 7.0
+    assert t.device_means() is d2 and Fake.uploads == 3
+    # fingerprints: identity and content both count, non-contiguous arrays are fine
+    a = np.arange(12.0).reshape(3, 4)
+    f = device.host_fingerprint([a, a[:, ::2]])
+    assert f == device.host_fingerprint([a, a[:, ::2]])[:1] + f[1:] and f[0][3] != f[1][3]
+    a[2, 3] += 1
+    assert device.host_fingerprint([a])[0] != f[0]
+    assert device.host_fingerprint([a.copy()])[0][0] != device.host_fingerprint([a])[0][0]
+
+
+def test_velocity_and_newick_against_reference_fixtures():
+    """Tree.set_velocity -> density and tree_utils.parse_newick against outputs of the reference
+    (fixture g11: tree.py:241-264, tree_utils.py:10-56, 176-242).  parse_newick is fed the stand-in
+    nodes the fixture describes AND the product's own Newick reader on the same text."""
+    from prosstt_amd import _newick
+    g = load_golden("g11_velocity_newick")
+    for tname in ("bifurcation", "unequal"):
+        spec = tree_spec(str(g["vel_%s_tree" % tname]))
+        for vname in ("pos", "neg"):
+            t = ptree.Tree(topology=spec["topology"], time=spec["time"], num_branches=len(spec["time"]),
+                           branch_points=spec["branch_points"], modules=spec["modules"], G=spec["G"])
+            vel = {b: g["vel_%s_%s_in_%s" % (tname, vname, b)].copy() for b in t.branches}
+            if vname == "neg":
+                assert min(v.min() for v in vel.values()) < 0
+            t.set_velocity(vel)
+            for b in t.branches:
+                np.testing.assert_allclose(t.density[b], g["vel_%s_%s_density_%s" % (tname, vname, b)],
+                                           rtol=1e-13, atol=0)
+    for name in ("bif", "deep", "single"):
+        nodes = [_newick.Node(str(n), float(l)) for n, l in zip(g["nw_%s_names" % name], g["nw_%s_lengths" % name])]
+        for node, parent in zip(nodes, g["nw_%s_parents" % name]):
+            if parent >= 0:
+                nodes[int(parent)].add(node)
+        for parsed in ([nodes[0]], _newick.loads(str(g["nw_%s_text" % name]))):
+            top, time, branches, bpoints, root = tu.parse_newick(parsed, 40)
+            assert [list(map(str, row)) for row in g["nw_%s_topology" % name]] == top
+            assert list(time.keys()) == [str(k) for k in g["nw_%s_time_keys" % name]]
+            assert list(time.values()) == [int(v) for v in g["nw_%s_time_vals" % name]]
+            assert [branches, bpoints] == g["nw_%s_counts" % name].tolist()
+            assert (root or "") == str(g["nw_%s_root" % name])

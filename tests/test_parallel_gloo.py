@@ -175,3 +175,51 @@ def test_three_ranks_sharded_sampling_and_gather(tmp_path, same_seed):
     port = _free_port()
     mp.spawn(_worker_sharded, args=(3, port, str(tmp_path), same_seed), nprocs=3, join=True)
     assert all(os.path.exists(tmp_path / ("ok%d" % r)) for r in range(3))
+
+
+def _worker_subgroup(rank, world_size, port, tmpdir):
+    """Ranks 1 and 2 of a 3-rank world form a sub-group: broadcast_plan from the group's rank 0
+    (global rank 1) with string labels, gather_rows to the group's rank 1 (global rank 2)."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    from prosstt_amd import parallel
+    try:
+        sub = dist.new_group([1, 2])               # every rank of the world takes part in creating it
+        if rank > 0:
+            N, G = 57, 4
+            if dist.get_rank(sub) == 0:
+                rng = np.random.default_rng(3)
+                plan = (rng.integers(0, 90, N), rng.choice(np.array(["root", "left", "right-branch"]), N),
+                        rng.random(N), (1 << 63) + 12345)
+            else:
+                plan = None
+            pt, br, sc, seed = parallel.broadcast_plan(plan, group=sub)
+            rng = np.random.default_rng(3)
+            np.testing.assert_array_equal(pt, rng.integers(0, 90, N))
+            np.testing.assert_array_equal(br, rng.choice(np.array(["root", "left", "right-branch"]), N))
+            np.testing.assert_array_equal(sc, rng.random(N))
+            assert seed == (1 << 63) + 12345 and pt.dtype == np.int64 and sc.dtype == np.float64
+            mine, _ = parallel.shard_cells(br, dist.get_rank(sub), 2)
+            fake = (torch.as_tensor(mine)[:, None] * 10 + torch.arange(G)[None, :]).to(torch.int32)
+            full = parallel.gather_rows(fake, mine, N, group=sub, dst=1)      # default chunking: a byte budget
+            if dist.get_rank(sub) == 1:
+                assert torch.equal(full, (torch.arange(N)[:, None] * 10 + torch.arange(G)[None, :]).to(torch.int32))
+            else:
+                assert full is None
+            full = parallel.gather_rows(fake, mine, N, group=sub, dst=0, chunk_bytes=64)   # 4 rows per round
+            assert (full is not None) == (dist.get_rank(sub) == 0)
+        dist.barrier()
+        open(os.path.join(tmpdir, "ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_plan_broadcast_and_gather_inside_a_subgroup(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker_subgroup, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    assert all(os.path.exists(tmp_path / ("ok%d" % r)) for r in range(3))
