@@ -303,15 +303,25 @@ def run_case(job, config, scaling, cells_per_gpu, steps, warmup, strict_steps, g
         small = min(64, len(mine))
         parallel.gather_rows(out[:small], mine[:small], n_total)        # connections come up outside the timed region
         job.fence()
-        t0 = time.perf_counter()
-        full = parallel.gather_rows(out, mine, n_total)
-        job.fence()
-        res["gather_ms"] = job.max_over_ranks(time.perf_counter() - t0) * 1e3
-        del full
+        if job.backend == "nccl":
+            t0 = time.perf_counter()
+            full = parallel.gather_rows(out, mine, n_total)
+            job.fence()
+            res["gather_ms"] = job.max_over_ranks(time.perf_counter() - t0) * 1e3
+            del full
+        else:
+            # functional run on another backend (gloo stages device tensors through the host at ~25 MB/s):
+            # the exchange is exercised on 2048 rows per rank and not timed
+            part = min(2048, len(mine))
+            full = parallel.gather_rows(out[:part], mine[:part], n_total)
+            job.fence()
+            res["gather_rows_functional"] = int(job.max_over_ranks(part))
+            del full
 
     # sanity inside the bench: first moment of this rank's shard (catches a silently dead kernel)
     mu_sum = float((means.double().sum(dim=1)[d_rows.long()] * d_sc).sum())
-    res["ratio"] = float(out.sum(dtype=torch.float64)) / mu_sum if mu_sum > 0 else float("nan")
+    x_sum = sum(int(out[lo:lo + 16384].sum(dtype=torch.int64)) for lo in range(0, len(mine), 16384))   # bounded temporaries
+    res["ratio"] = x_sum / mu_sum if mu_sum > 0 else float("nan")
     res["tree"] = tree
     return res
 
@@ -357,7 +367,14 @@ def main():
 
     strong = []
     if world > 1:
+        from prosstt_amd import workloads
+        sharing = world if os.environ.get("PROSSTT_BENCH_ONE_GPU") == "1" else 1    # ranks on one device (functional test)
         for cfg in [c for c in args.strong_configs.split(",") if c]:
+            spec = workloads.CONFIGS[cfg]
+            per_device = 4.0 * spec["N"] * spec["G"] / world * sharing
+            if per_device > 0.35 * job.torch.cuda.get_device_properties(job.ctx.device).total_memory:
+                strong.append({"config": cfg, "skipped": "%.0f GB of counts per device" % (per_device / 1e9)})
+                continue
             case = run_case(job, cfg, "strong", None, max(3, args.steps // 2), 2, 0, gather=not args.no_gather)
             strong.append({"config": cfg, "cells_total": case["n_total"], "genes": case["G"],
                            "cells_on_rank_0": case["cells_on_rank"], "value": case["value"], "unit": "cells*genes/s",
@@ -398,6 +415,9 @@ def main():
         }
         if main_case["gather_ms"] is not None:
             line["gather_ms"] = main_case["gather_ms"]
+        if "gather_rows_functional" in main_case:
+            line["gather_ms"] = None
+            line["gather_note"] = "backend %s: gather exercised on %d rows per rank, not timed" % (job.backend, main_case["gather_rows_functional"])
         if strong:
             line["strong_scaling"] = strong
         if end_to_end is not None:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PROSSTT_AMD_VERSION 200 /* 0.2.0: PRNB-2 sampler, prosstt_amd_lineage_attempt_batch */
+#define PROSSTT_AMD_VERSION 300 /* 0.3.0: PRNB-3 sampler (binary32 remainder), prosstt_amd_last_list; the tile-per-block kernel is gone */
 
 enum {
     PROSSTT_AMD_OK = 0,
@@ -43,8 +43,6 @@ enum {
 #define PROSSTT_AMD_HOST_OUTPUT  2u /* every output array is a host pointer */
 #define PROSSTT_AMD_CHECK_DOMAIN 4u /* synchronise and return EDOMAIN like scipy's argument check */
 #define PROSSTT_AMD_TIME_KERNEL  8u /* bracket the main kernel with HIP events (last_kernel_ms) */
-#define PROSSTT_AMD_KERNEL_TILED 16u /* sample_counts: use the tile-per-block kernel instead of the
-                                        streaming one (same results; kept for A/B measurements) */
 
 typedef struct prosstt_amd_ctx prosstt_amd_ctx;
 
@@ -68,7 +66,7 @@ int prosstt_amd_last_kernel_ms(prosstt_amd_ctx* ctx, float* ms);
  *   scipy.stats.nbinom(n=r, p=1-p).rvs()        simulation.py:647-648
  * out[n*ld_out + g] ~ NB(mean m, variance alpha*m^2 + beta*m),
  *   m = means[row_of_cell[n]*G + g] * scaling[n],
- * drawn by the PRNB-2 counter-based sampler keyed by
+ * drawn by the PRNB-3 counter-based sampler keyed by
  * (seed, global cell id, g); the global id of cell n is cell_index[n] when
  * cell_index is given, cell_offset + n otherwise.
  *   means        [rows][G] binary32, row-major: the (branch, time, gene) mean tensor
@@ -84,6 +82,18 @@ int prosstt_amd_sample_counts(prosstt_amd_ctx* ctx, const float* means, int64_t 
                               const double* alpha, const double* beta, int64_t N, uint64_t seed,
                               uint64_t cell_offset, const int64_t* cell_index, int32_t* out,
                               int64_t ld_out, uint32_t flags);
+
+/*
+ * The samples that the streaming kernel of the LAST prosstt_amd_sample_counts call on this ctx left
+ * to its second kernel (K3h): the gamma-Poisson class, inversion walks whose hardware-math
+ * evaluation came within its margin of a threshold, counts above 255.  Decoded to (cell, gene)
+ * pairs, cells[i] indexing that call's arrays; at most `cap` pairs are written, *total receives the
+ * number listed, *overflowed whether a wave's region of the list was too small (K3h then ignores the
+ * list and redoes the whole matrix).  For tests and diagnostics: it synchronises and copies.
+ * Valid until the next call on the ctx.
+ */
+int prosstt_amd_last_list(prosstt_amd_ctx* ctx, int64_t* cells, int32_t* genes, int64_t cap,
+                          int64_t* total, int32_t* overflowed);
 
 /*
  * The deterministic intermediates of the same path (simulation.py:633-645,

@@ -3,7 +3,7 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library; prosstt_amd never does.
  *
- * Scalar C model of the *device* count sampler ("PRNB-2"): the
+ * Scalar C model of the *device* count sampler ("PRNB-3"): the
  * fused  gather * scale -> get_pr_umi -> negative-binomial draw  that replaces
  *   simulation.draw_counts           /root/reference/prosstt/simulation.py:602-651
  *   count_model.get_pr_umi           /root/reference/prosstt/count_model.py:131-161
@@ -11,7 +11,7 @@
  *
  * The reference draws from numpy's sequential MT19937 stream, which no
  * parallel device can reproduce (SURVEY.md section 0 "RNG reality check"); the count
- * law, not the stream, is the contract.  PRNB-2 is a counter-based sampler of
+ * law, not the stream, is the contract.  PRNB-3 is a counter-based sampler of
  * the SAME law  NB(n = r, p = 1-p)  with  theta = a*m + b - 1,  r = m/theta,
  * p = theta/(1+theta)  (the algebraic form of get_pr_umi), defined so that
  * every sample is a pure function of (M, s, a, b, seed, cell, gene):
@@ -36,7 +36,7 @@
 #define PRNB_CLONES
 #endif
 
-/* ---- sampler constants (part of the PRNB-2 definition) ------------------ */
+/* ---- sampler constants (part of the PRNB-3 definition) ------------------ */
 #define PRNB_LIGHT_T      19.0f        /* inversion iff theta <= 16 and t = -log P(X=0) <= 19: P0 * 2^32 >= 24 */
 #define PRNB_LIGHT_THETA  16.0f        /* tail ratio theta/(1+theta) <= 16/17: the walk ends far below the 1/k table's 511 entries */
 #define PRNB_THETA_MIN    8.6736174e-19f /* 2^-60: below this NB == Poisson in binary32 */
@@ -178,25 +178,29 @@ __attribute__((constructor)) static void prnb_init(void)
 }
 
 /*
- * Inversion by chop-down in 0.32 fixed point.  pmf recurrence
+ * Inversion by chop-down on a binary32 remainder.  pmf recurrence
  *   P(k+1) = P(k) * num_k / (k+1),   num_k = mp + k*q
- * (NB: mp = m/(1+theta), q = theta/(1+theta);  Poisson: mp = lambda, q = 0).
- * `w` is the 32-bit uniform.  If the pmf falls below 2^-32 before w is used up -- mass lost
- * to rounding, < 1e-6, or the 0 sentinel that ends the 1/k table -- the draw is the tail
- * value at which the walk stops, counted in the groups the device walks in (k = 0..2, then
- * four terms at a time): the last k of the group in which the pmf vanished.
+ * (NB: mp = m/(1+theta), q = theta/(1+theta);  Poisson: mp = lambda, q = 0), carried scaled by 2^32.
+ * `w` is the 32-bit uniform; the remainder starts as (float)w (round to nearest: 24 significant bits,
+ * full resolution below 2^24) and every term is subtracted from it in binary32; the draw is the first k
+ * whose subtraction leaves the remainder negative.  Terms come in the groups the device walks in
+ * (k = 0..2, then four at a time); when a group ends without a negative remainder and its LAST term is
+ * below 1 -- the pmf has fallen under 2^-32: mass lost to rounding, < 1e-6, or the 0 sentinel that ends
+ * the 1/k table -- the draw is that group's last k.
+ * (PRNB-2 kept the remainder as a 32-bit integer and subtracted floor(term): one float->int conversion
+ * per term; PRNB-3's terms are pure binary32 multiply/add/subtract, which the device's float pipe runs
+ * beside its integer pipe.)
  */
 static inline int32_t chop_down(uint32_t w, float p0, float mp, float q)
 {
-    float p = fminf(p0, 0.99999994f);
+    float ps = fminf(p0, 0.99999994f) * 4294967296.0f;      /* exact scaling */
     float num = mp;
-    uint32_t rem = w;
+    float rem = (float)w;
     for (int k = 0; ; ) {
-        uint32_t pf = (uint32_t)(p * 4294967296.0f);
-        if (rem < pf) return k;
-        if (pf == 0u) return ((k + 1) | 3) - 1;
-        rem -= pf;
-        p = (p * num) * g_inv_k[k + 1];
+        rem = rem - ps;
+        if (rem < 0.0f) return k;
+        if ((k & 3) == 2 && ps < 1.0f) return k;          /* k = 2, 6, 10, ...: a group's last term */
+        ps = (ps * num) * g_inv_k[k + 1];
         ++k;
         /* numerator mp + k*q: one fma where a group of four terms starts (k = 3, 7, ...), by addition
          * inside a group -- summing q term after term would let its rounding errors pile up over a

@@ -2,7 +2,7 @@
 // on its own strip of the count matrix, with LDS stacks between the stages so that every
 // stage executes with (nearly) all 64 lanes busy.
 //
-// The scalar algorithm (PRNB-2, prnb_device.h) has very different costs per sample:
+// The scalar algorithm (PRNB-3, prnb_device.h) has very different costs per sample:
 //   ~65 % of the samples of the headline workload are zeros that a 6-instruction bound
 //         settles (exp(-m * phi_gene) <= P(X = 0), prnb::zero_test_factor);
 //   the rest need P(X = 0) exactly (reciprocal + log1p + exp, ~100 VALU), and
@@ -12,7 +12,7 @@
 //   stage 1 (uniform)   one count-matrix row segment per wave pass: 16-B mean load, one
 //                       Philox call per lane, the bound test as a compare mask; survivors are
 //                       pushed on stack S1 under exec = mask;
-//   stage 2 (64 of S1)  P(X = 0) and the class test, then the terms k = 1, 2; what is still
+//   stage 2 (64 of S1)  P(X = 0) and the class test, then the terms k = 0, 1, 2; what is still
 //                       undecided is pushed on S2 with the pmf state at k = 3;
 //   stage 3 (lanes pull from S2)  four pmf steps per lane per pass; a lane that finishes
 //                       writes its count into the LDS row ring and pulls the next entry;
@@ -29,23 +29,26 @@
 //   serialises them); sample_counts_heavy_kernel (k3_heavy.h) draws them afterwards.
 //
 // Stages 2 and 3 evaluate P(X = 0) with the hardware's v_rcp/v_log/v_exp (each within 1.2e-7 of
-// the true value on gfx950, tools/hwmath_probe.hip) instead of PRNB-2's deterministic binary32
+// the true value on gfx950, tools/hwmath_probe.hip) instead of PRNB-3's deterministic binary32
 // arithmetic -- a third of the instructions.  The result must still be the model's, bit for bit:
-// a walk's answer is the first k with w < C_k (the running sum of the scaled pmf), so it can
-// only differ from the exact evaluation's when w lies within the two evaluations' distance of
-// some C_k.  Every lane therefore tracks how close w came to a threshold and, when that is
-// within a margin of about three times the worst-case distance (2^-20 + t*2^-19 + k*2^-22 of 2^32,
+// a walk's answer is the first k whose subtraction leaves the remainder negative, so it can
+// only differ from the exact evaluation's when a remainder lies within the two evaluations' distance
+// of 0.  Every lane therefore tracks how close its remainders came to 0 and, when that is
+// within a margin of about three times the worst-case distance (2^-20 + t*2^-19 + k*2^-21 of 2^32,
 // t = -log2 P0), gives the sample up: it goes on the same list, and K3h redoes it with the
-// exact arithmetic (about 1 in 10^4 of the walks).  So does a sample whose class the
-// approximate t cannot decide.
+// exact arithmetic (about 1 in 10^3 of the walks).  So does a sample whose class the
+// approximate t cannot decide, and a walk whose end-of-pmf test (a term against 1) is too close to call.
 // Results are pure functions of (sample parameters, seed, global cell id, gene), so the
 // order in which the stacks are drained cannot change them.
 //
-// Written against the issue costs measured on gfx950 (tools/microbench4.hip): a scalar
-// instruction costs a wave as much as a vector one, every VALU instruction that touches an
-// SGPR or a lane mask is ~1.7x a plain VOP2, and the kernel is VALU-issue-bound -- hence the
-// scalar per-cell loads, the compare masks written straight to SGPR pairs, and no exec
-// save/restore around the pushes.
+// Written against the issue model measured on gfx950 (tools/microbench5.hip, microbench6.hip;
+// DESIGN.md section 6): a SIMD issues one vector instruction per ~2.4 cycles; binary32
+// mul/add/sub/fma run beside everything else, the other kinds (compare, select, convert, min/max,
+// left shift, mbcnt, 3-operand integer forms, 64-bit multiply) occupy a second unit for ~4.3 cycles
+// each (simple integer add/xor/and/or/right shift ~2.4 there, transcendentals ~8.3), and scalar
+// instructions issue beside both.  The kernel is bound by that second unit, so the walk is pure
+// binary32 arithmetic on a binary32 remainder (PRNB-3), hits are counted from sign bits, wave-level
+// tests are lane masks formed by ONE compare each, and per-cell values arrive by scalar loads.
 #pragma once
 #include "prnb_device.h"
 
@@ -65,9 +68,13 @@ constexpr int kRing = 8;           // rows of the strip kept in LDS (8 bits per 
 //        log2(u1)*rcp(u1-1) 2.9e-7 measured over (0, 16], one rounding), exp 2.0e-7 + 0.9e-7;
 //   numerators: none (mp and q are formed by PRNB-2's own arithmetic here), so a term adds only
 //        the two paths' rounding differences, 2 * 2^-24 each at most.
-constexpr float kMargin0 = 4096.0f;          // 2^-20        (worst case 2.9e-7 = 1245 units)
+//   the remainder itself: both paths subtract their terms from a binary32 remainder below 2^32, so
+//        each subtraction can round differently by up to ulp(2^32)/2 = 256 units -- far less for the
+//        small remainders of a walk that is about to end, but the margin does not rely on that.
+constexpr float kMargin0 = 4096.0f;          // 2^-20        (worst case 2.9e-7 = 1245 units, + 256)
 constexpr float kMarginPerT2 = 8192.0f;      // 2^-19 per unit of t2 = t / ln 2   (worst case 9.6e-7 * ln 2 = 2858 units)
-constexpr uint32_t kMarginPerTerm = 1024u;   // 2^-22 per term                   (worst case 1.2e-7 = 515 units)
+constexpr float kMarginPerTerm = 2048.0f;    // 2^-21 per term                   (worst case 1.2e-7 = 515 units, + 256)
+constexpr float kTailBand = 9.765625e-4f;    // a group's last term within 2^-10 of 1: the end-of-pmf test is K3h's
 constexpr float kT2Sure = 27.41120f * (1.0f - 1.53e-5f);   // 19 / ln 2, less 2^-16: surely t <= 19
 constexpr int kLateCap = 128;      // results that missed their row wait here for one burst of stores (< 64 left + 64)
 
@@ -79,13 +86,15 @@ constexpr int kLateCap = 128;      // results that missed their row wait here fo
 struct CellInfo { uint64_t row_bytes; float s; uint32_t cell_lo, cell_hi, pos_base, pad1, pad2; };
 static_assert(sizeof(CellInfo) == 32, "one s_load_dwordx8");
 
-struct S1Entry { float m, theta; uint32_t w, pos; };   // theta = a*m + b - 1, not yet clamped
-struct S2Entry { float ps, mp, q; uint32_t rem; };    // pmf (x 2^32) at k = 3; the numerator of step k is mp + k*q
+struct S1Entry { float m, theta, wf; uint32_t pos; };  // theta = a*m + b - 1, not yet clamped; wf = (float)(32-bit uniform)
+struct S2Entry { float ps, mp, q, rem; };             // pmf (x 2^32) at k = 3 and what is left of wf; the numerator of step k is mp + k*q
+// S2 meta word: the threshold margin of the terms k = 3..6 (binary32, rounded up to 16 significant bits
+// -- it is a bound, and the model knows nothing of it) with pos in the 16 bits that frees
 
 struct WaveLds {
     S1Entry s1[kS1Cap];
     S2Entry s2[kS2Cap];
-    uint32_t s2pos[kS2Cap];        // pos | (threshold margin at k = 3) >> 8 << 16
+    uint32_t s2m[kS2Cap];
     uint8_t ring[kRing * 256];     // [row slot][gene-in-tile]; a count of 256 or more is left to K3h
     uint32_t late[kLateCap];       // (pos << 16) | count of results whose row has left the ring already
 };
@@ -105,7 +114,7 @@ __device__ __forceinline__ int lane_rank(unsigned long long mask)
 }
 
 template <bool VEC>
-__global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
+__global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
     const float* __restrict__ means, int32_t G, const CellInfo* __restrict__ cellinfo,
     const float* __restrict__ ga, const float* __restrict__ gbm1, const float* __restrict__ gphi,
     int64_t N, uint32_t k0, uint32_t k1, int32_t* __restrict__ out, int64_t ld, int32_t strips,
@@ -154,7 +163,8 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
     uint32_t hpend = kNoHeavy;                       // pos of the sample this lane holds for the next append to K3h's list
     // stage-3 lane state
     float ps = 0.0f, mp = 0.0f, q = 0.0f, kf = 0.0f;   // kf = (float)k of a busy lane
-    uint32_t rem = 0u, pos = 0u, dl = 0u;            // dl: this lane's threshold margin (grows with k)
+    float rem = 0.0f, dl = 0.0f;                     // what is left of wf; this lane's threshold margin (grows with k)
+    uint32_t pos = 0u;
     constexpr int kIdle = -5;        // k + 1 = 0 mod 4 (the aligned read of four reciprocals), k + 3 < 0 (no result)
     int k = kIdle;
     float4 inv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // 1/(k+1) .. 1/(k+4): read one pass ahead
@@ -199,17 +209,24 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
         }
         late_top = 0;
     };
-    // (Wave-level tests are written on 64-bit lane masks taken BEFORE any divergent region of the
-    // pass: the ballot of one compare is then that compare's SGPR result; behind a divergent region,
-    // or of a composite predicate, the compiler re-forms it with two more VALU instructions.)
-    auto deliver = [&](uint32_t p, int32_t res) {
-        const bool late = (int32_t)p <= flushed_pos;
-        const unsigned long long ml = __builtin_amdgcn_ballot_w64(res > 0) & __builtin_amdgcn_ballot_w64(late);
-        if ((res > 0) & !late) L.ring[p & (kRing * 256 - 1)] = (uint8_t)res;    // slot = cell % kRing, gene-in-tile; res < 256
+    // (Wave-level tests are written on 64-bit lane masks, each the SGPR result of ONE compare taken
+    // outside divergent control flow; masks are combined on the scalar unit and applied as exec.)
+#define K3_MASK(x) __builtin_amdgcn_ballot_w64(x)
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)&L.ring[0];
+    const uint32_t late_lds = (uint32_t)(uintptr_t)&L.late[0];
+    // Every lane of the wave calls this; the lanes of `ok_m` deliver count `res` (1..255) of sample `p`:
+    // into the row ring while the row is still there, else (rare) onto the late list.
+    auto deliver = [&](unsigned long long ok_m, uint32_t p, uint32_t res) {
+        const unsigned long long late_m = K3_MASK((int32_t)p <= flushed_pos);
+        // slot = cell % kRing, gene-in-tile
+        asm volatile("s_mov_b64 exec, %0\n\tds_write_b8 %1, %2\n\ts_mov_b64 exec, -1"
+                     :: "s"(ok_m & ~late_m), "v"(ring_lds + (p & (uint32_t)(kRing * 256 - 1))), "v"(res) : "memory");
+        const unsigned long long ml = ok_m & late_m;
         if (ml != 0ull) {
             const int cnt = __popcll(ml);
             if (late_top + cnt > kLateCap) flush_late();
-            if ((res > 0) & late) L.late[late_top + lane_rank(ml)] = (p << 16) | (uint32_t)res;
+            asm volatile("s_mov_b64 exec, %0\n\tds_write_b32 %1, %2\n\ts_mov_b64 exec, -1"
+                         :: "s"(ml), "v"(late_lds + (uint32_t)((late_top + lane_rank(ml)) << 2)), "v"((p << 16) | res) : "memory");
             late_top += cnt;
         }
     };
@@ -219,7 +236,7 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
     uint32_t* const my_list = heavy.list + (uint64_t)region * heavy.cap;
     uint32_t h_cnt = 0u;                              // wave-uniform
     auto flush_heavy = [&]() {
-        const unsigned long long mp_ = __builtin_amdgcn_ballot_w64(hpend != kNoHeavy);
+        const unsigned long long mp_ = K3_MASK(hpend != kNoHeavy);
         if (hpend != kNoHeavy) {
             const uint32_t slot = h_cnt + (uint32_t)lane_rank(mp_);
             if (slot < heavy.cap) my_list[slot] = hpend;
@@ -227,22 +244,24 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
         h_cnt += (uint32_t)__popcll(mp_);
         hpend = kNoHeavy;
     };
-    // every lane of the wave calls this; the lanes of `mine_m` (= `mine_`) leave sample `p` to K3h
-    auto list_sample = [&](unsigned long long mine_m, bool mine_, uint32_t p) {
+    // every lane of the wave calls this; the lanes of `mine_m` leave sample `p` to K3h
+    auto list_sample = [&](unsigned long long mine_m, uint32_t p) {
         if (mine_m != 0ull) {
-            if ((mine_m & __builtin_amdgcn_ballot_w64(hpend != kNoHeavy)) != 0ull) flush_heavy();
-            if (mine_) hpend = p;
+            if ((mine_m & K3_MASK(hpend != kNoHeavy)) != 0ull) flush_heavy();
+            asm volatile("s_mov_b64 exec, %1\n\tv_mov_b32 %0, %2\n\ts_mov_b64 exec, -1" : "+v"(hpend) : "s"(mine_m), "v"(p));
         }
     };
     // ---- stage 3: four pmf steps for every busy lane; idle lanes pull from S2 ------------------
-    // A lane is idle iff k == kIdle, and an idle lane keeps ps = 0: its steps end without a hit
-    // and its "result" k + 3 is negative, so the arithmetic below never asks which lanes are busy.
-    // The pmf falls once it is under 2^-32 (it can only get there beyond the mode), so "the first
-    // hit, else the group's last k when the last of the four terms is 0" is the sequential walk's
-    // answer (prnb::chop_down).  A walk enters at k = 3 and advances by 4: the four reciprocals
-    // 1/(k+1)..1/(k+4) are one aligned 16-byte LDS read.
-    // Margin (see the header): rem_j + dl < 2*dl (unsigned) iff w is within dl of the threshold C_j,
-    // on either side; a lane that comes that close stops and leaves its sample to K3h.
+    // A lane is idle iff k == kIdle, and an idle lane keeps ps = 0: its "count" k + 3 is negative,
+    // which keeps it out of every mask below, so the arithmetic never asks which lanes are busy.
+    // PRNB-3's walk (prnb::chop_down): the terms are subtracted from a binary32 remainder, the count
+    // is the first k whose subtraction leaves it negative; when a group of four ends without that
+    // and its last term is under 1 (the pmf has fallen under 2^-32) the count is the group's last k.
+    // A walk enters at k = 3 and advances by 4: the four reciprocals 1/(k+1)..1/(k+4) are one aligned
+    // 16-byte LDS read.  The remainders only fall, so there is a hit iff the last one is negative, and
+    // the hit is at term 4 - (number of negative remainders): sign bits, no compares.
+    // Margin (see the header): a remainder within dl of 0, or the last term within 2^-10 of 1, may come
+    // out differently in the exact arithmetic: the lane stops and leaves its sample to K3h.
     auto stage3_pass = [&]() {
         unsigned long long idle_m;
         asm("v_cmp_eq_u32 %0, -5, %1" : "=s"(idle_m) : "v"(k));
@@ -253,9 +272,9 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
                 const int idx = s2_top - 1 - rank;
                 const S2Entry e = L.s2[idx];
                 ps = e.ps; mp = e.mp; q = e.q; rem = e.rem;
-                const uint32_t pd = L.s2pos[idx];
-                pos = pd & 0xffffu;
-                dl = (pd >> 16) << 8;
+                const uint32_t md = L.s2m[idx];
+                pos = md & 0xffffu;
+                dl = prnb::u2f(md);                   // pos rides in the low bits: the margin only grows by it
                 k = 3;
                 kf = 3.0f;
                 inv = *reinterpret_cast<const float4*>(&inv_k[4]);
@@ -264,48 +283,49 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
             s2_top = left > 0 ? left : 0;
         }
         const float num = PRNB_FMA(kf, q, mp);          // the group's first numerator by fma, the others by addition
-        const uint32_t pf0 = (uint32_t)ps;
-        const bool hit0 = rem < pf0;
-        const uint32_t rem1 = rem - pf0;
+        const float r1 = rem - ps;
         const float ps1 = (ps * num) * inv.x;
         const float num1 = num + q;
-        const uint32_t pf1 = (uint32_t)ps1;
-        const bool hit1 = rem1 < pf1;
-        const uint32_t rem2 = rem1 - pf1;
+        const float r2 = r1 - ps1;
         const float ps2 = (ps1 * num1) * inv.y;
         const float num2 = num1 + q;
-        const uint32_t pf2 = (uint32_t)ps2;
-        const bool hit2 = rem2 < pf2;
-        const uint32_t rem3 = rem2 - pf2;
+        const float r3 = r2 - ps2;
         const float ps3 = (ps2 * num2) * inv.z;
         const float num3 = num2 + q;
-        const uint32_t pf3 = (uint32_t)ps3;
-        const bool hit3 = rem3 < pf3;
-        const uint32_t rem4 = rem3 - pf3;
-        const uint32_t near = umin(umin(rem1 + dl, rem2 + dl), umin(rem3 + dl, rem4 + dl));
-        const bool close = near < 2u * dl;               // never for an idle lane: its dl is 0
-        const bool any = hit0 | hit1 | hit2 | hit3;
-        const bool done = any | (pf3 == 0u) | close;
-        const int32_t res_k = (done & !close) ? k + (hit0 ? 0 : (hit1 ? 1 : (hit2 ? 2 : 3))) : 0;
-        // a count that does not fit the ring's 8 bits (1 in 10^4 of the counts) is K3h's as well
-        const bool big = res_k > 255;
-        const int32_t res = big ? 0 : res_k;
-        const unsigned long long close_m = __builtin_amdgcn_ballot_w64(near < 2u * dl) | __builtin_amdgcn_ballot_w64(res_k > 255);
-        deliver(pos, res);
-        list_sample(close_m, close | big, pos);
-        rem = rem4;
-        ps = done ? 0.0f : (ps3 * num3) * inv.w;
-        dl = done ? 0u : dl + 4u * kMarginPerTerm;
+        const float r4 = r3 - ps3;
+        const unsigned long long hit_m = K3_MASK(r4 < 0.0f);
+        const unsigned long long tail_m = K3_MASK(ps3 < 1.0f);
+        const float near = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fabsf(r1), __builtin_fabsf(r2)),
+                                                           __builtin_fabsf(r3)), __builtin_fabsf(r4));
+        const unsigned long long close_m = K3_MASK(near < dl) | K3_MASK(__builtin_fabsf(ps3 - 1.0f) < kTailBand);
+        const uint32_t nneg = (prnb::f2u(r1) >> 31) + (prnb::f2u(r2) >> 31) + (prnb::f2u(r3) >> 31) + (prnb::f2u(r4) >> 31);
+        const int k4 = k + 4;
+        // a hit at term 4 - nneg: k + 4 - nneg; no hit: the group's last k = k + 3 (taken when the tail test ends the walk)
+        const int32_t res_k = k4 - (int32_t)(nneg > 1u ? nneg : 1u);
+        const unsigned long long busy_m = K3_MASK(res_k > 0);          // an idle lane's is -2
+        const unsigned long long big_m = K3_MASK(res_k > 255);         // does not fit the ring's 8 bits (1 in 10^4): K3h's as well
+        const unsigned long long done_m = hit_m | tail_m | close_m;    // (idle lanes: their ps3 = 0 is under 1)
+        const unsigned long long give_m = (close_m | (big_m & (hit_m | tail_m))) & busy_m;
+        deliver(done_m & busy_m & ~close_m & ~big_m, pos, (uint32_t)res_k);
+        list_sample(give_m, pos);
+        rem = r4;
+        const float ps4 = (ps3 * num3) * inv.w;
         kf = kf + 4.0f;
-        k = done ? kIdle : k + 4;
+        dl = dl + 4.0f * kMarginPerTerm;
+        // done lanes go idle (ps = 0, k = kIdle)
+        asm("v_cndmask_b32 %0, %1, 0, %2" : "=v"(ps) : "v"(ps4), "s"(done_m));
+        asm("v_cndmask_b32 %0, %1, -5, %2" : "=v"(k) : "v"(k4), "s"(done_m));
         inv = *reinterpret_cast<const float4*>(__builtin_assume_aligned(&inv_k[k + 1], 16));   // k + 1 = 0 mod 4
     };
 
-    // ---- stage 2: P(X = 0), class test, then the terms k = 1, 2, for up to 64 entries of S1 -------
+    // ---- stage 2: P(X = 0), class test, then the terms k = 0, 1, 2, for up to 64 entries of S1 -------
     // prnb::make_params with the hardware's log2, reciprocal and exp2 for P(X = 0):
     // log1p(theta)/theta = log(u1)/(u1 - 1) (u1 = fl(1 + theta): the rounding of the sum cancels),
-    // P0 = 2^-t2; mp and q by PRNB-2's own arithmetic (they multiply into every term of a walk).  What the approximation cannot decide -- the class of a sample with t within
-    // 2^-16 of 19, a threshold within the margin -- goes to K3h's list.
+    // P0 = 2^-t2; mp and q by PRNB-3's own arithmetic (they multiply
+    // into every term of a walk).  What the approximation cannot decide -- the class of a sample with t within
+    // 2^-16 of 19, a remainder within the margin -- goes to K3h's list.
+    const uint32_t s2_lds = (uint32_t)(uintptr_t)&L.s2[0];
+    const uint32_t s2m_lds = (uint32_t)(uintptr_t)&L.s2m[0];
     auto stage2_pass = [&]() {
         // Straight-line for every lane (a lane beyond the entries reads the stack's bottom entry and is
         // masked out): every wave-level test below is a lane mask formed outside divergent control flow.
@@ -313,70 +333,60 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
         const int at = s1_top - 1 - lane;
         const S1Entry e = L.s1[at > 0 ? at : 0];
         const uint32_t p2 = e.pos;
-        // Each predicate twice: as a per-lane bool (selects, exec) and as a lane mask (wave-level tests);
-        // both come from the same compare instructions.
-#define K3_MASK(x) __builtin_amdgcn_ballot_w64(x)
+        const unsigned long long in_m = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);     // the lanes that hold an entry
         // (m <= 0 or theta <= 0: the count is 0 by definition; stage 1 does not test that)
-        const bool valid = (lane < cnt) & (e.m > 0.0f) & (e.theta > 0.0f);
-        const unsigned long long valid_m = K3_MASK(lane < cnt) & K3_MASK(e.m > 0.0f) & K3_MASK(e.theta > 0.0f);
+        const unsigned long long valid_m = in_m & K3_MASK(e.m > 0.0f) & K3_MASK(e.theta > 0.0f);
         const float theta = __builtin_fmaxf(e.theta, prnb::kThetaMin);
         const float u1 = 1.0f + theta;
-        const float dm1 = u1 - 1.0f;
         const float inv_u1 = prnb::det_rcp(theta * u1) * theta;
         const float qq = theta * inv_u1;
         const float mpp = e.m * inv_u1;
-        // t2 = -log2 P(X = 0) = m * log2(1+theta)/theta; theta below 2^-24: the Poisson limit m * log2(e)
-        const float f2 = dm1 > 0.0f ? __builtin_amdgcn_logf(u1) * __builtin_amdgcn_rcpf(dm1) : 1.44269504f;
-        const float t2 = e.m * f2;
+        // t2 = -log2 P(X = 0) = m * log2(1+theta)/theta; below 2^-23, where 1 + theta is 1 in binary32, the
+        // quotient is taken at 2^-23 (it is log2(e) * (1 - theta/2 + ...): 6e-8 off, well inside the margins)
+        const float u1q = 1.0f + __builtin_fmaxf(e.theta, 1.1920929e-7f);
+        const float t2 = e.m * (__builtin_amdgcn_logf(u1q) * __builtin_amdgcn_rcpf(u1q - 1.0f));
         // inversion class for sure: theta <= 16 and t = t2 * ln 2 below 19 by more than the two
         // evaluations can differ (NaN: not); every other valid sample is K3h's
-        const bool light = (theta <= prnb::kLightTheta) & (t2 < kT2Sure);
         const unsigned long long light_m = K3_MASK(theta <= prnb::kLightTheta) & K3_MASK(t2 < kT2Sure);
-        const float p0 = __builtin_fminf(__builtin_amdgcn_exp2f(-t2), 0.99999994f);
-        const float ps0 = p0 * 4294967296.0f;       // pmf scaled by 2^32 (exact scaling)
-        const uint32_t pf0 = (uint32_t)ps0;
-        // threshold margin of this sample at k = 2 (in units of 2^-32), a multiple of 256
-        const uint32_t d2 = ((uint32_t)PRNB_FMA(t2, kMarginPerT2, kMargin0 + 2.0f * kMarginPerTerm + 255.0f)) & ~255u;
-        const uint32_t rem1 = e.w - pf0;
+        const float ps0 = __builtin_amdgcn_exp2f(-t2) * 4294967296.0f;       // pmf scaled by 2^32 (exact scaling)
+        // threshold margin of this sample at k = 2 (in units of 2^-32)
+        const float d2 = PRNB_FMA(t2, kMarginPerT2, kMargin0 + 2.0f * kMarginPerTerm);
+        const float r0 = e.wf - ps0;
         const float ps1 = ps0 * mpp;                  // (* 1/1)
         const float num1 = mpp + qq;
-        const uint32_t pf1 = (uint32_t)ps1;
-        const uint32_t rem2 = rem1 - pf1;
+        const float r1 = r0 - ps1;
         const float ps2 = (ps1 * num1) * 0.5f;
         const float num2 = num1 + qq;
-        const uint32_t pf2 = (uint32_t)ps2;
-        const uint32_t rem3 = rem2 - pf2;
-        const uint32_t near = umin(umin(rem1 + d2, rem2 + d2), rem3 + d2);
-        const bool close = near < 2u * d2;
-        const unsigned long long close_m = K3_MASK(near < 2u * d2);
-        const bool give_up = valid & (!light | close);
-        const unsigned long long give_m = valid_m & (~light_m | close_m);
-        // k >= 1 among the samples decided here
-        const bool walks = valid & light & !close & (e.w >= pf0);
-        const unsigned long long walk_m = valid_m & light_m & ~close_m & K3_MASK(e.w >= pf0);
-        const bool hit1 = rem1 < pf1;
-        const bool hit2 = rem2 < pf2;
-        // no hit and the pmf gone: the group's last k (prnb::chop_down)
-        const int32_t res12 = hit1 ? 1 : ((hit2 | (pf2 == 0u)) ? 2 : 0);
-        const int32_t res = walks ? res12 : 0;
-        const bool push = walks & (res12 == 0);
-        const unsigned long long push_m = walk_m & K3_MASK(res12 == 0);
-#undef K3_MASK
-        deliver(p2, res);
-        list_sample(give_m, give_up, p2);
+        const float r2 = r1 - ps2;
+        const unsigned long long hit_m = K3_MASK(r2 < 0.0f);
+        const unsigned long long tail_m = K3_MASK(ps2 < 1.0f);
+        const float near = __builtin_fminf(__builtin_fminf(__builtin_fabsf(r0), __builtin_fabsf(r1)), __builtin_fabsf(r2));
+        const unsigned long long close_m = K3_MASK(near < d2) | K3_MASK(__builtin_fabsf(ps2 - 1.0f) < kTailBand);
+        const uint32_t nneg = (prnb::f2u(r0) >> 31) + (prnb::f2u(r1) >> 31) + (prnb::f2u(r2) >> 31);
+        // a hit at term 3 - nneg; no hit: 2 if the tail test ends the walk here
+        const uint32_t res = 3u - (nneg > 1u ? nneg : 1u);
+        const unsigned long long walk_m = valid_m & light_m & ~close_m;       // decided by this kernel
+        const unsigned long long nz_m = K3_MASK(res != 0u);
+        deliver(walk_m & (hit_m | tail_m) & nz_m, p2, res);
+        list_sample(valid_m & ~walk_m, p2);
         s1_top -= cnt;
-        if (push) {
-            const int slot = s2_top + lane_rank(push_m);
-            S2Entry e2;
-            e2.rem = rem3;
-            e2.ps = (ps2 * num2) * 0.33333334f;       // pmf at k = 3 (the 1/k table's 1/3)
-            e2.mp = mpp;
-            e2.q = qq;
-            L.s2[slot] = e2;
-            L.s2pos[slot] = p2 | (((d2 + 4u * kMarginPerTerm) >> 8) << 16);   // margin of the terms k = 3..6
+        const unsigned long long push_m = walk_m & ~(hit_m | tail_m);
+        {
+            const uint32_t slot = (uint32_t)s2_top + (uint32_t)lane_rank(push_m);
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            f32x4 e2;
+            e2.x = (ps2 * num2) * 0.33333334f;       // pmf at k = 3 (the 1/k table's 1/3)
+            e2.y = mpp;
+            e2.z = qq;
+            e2.w = r2;
+            // margin of the terms k = 3..6, rounded up to 16 significant bits, | pos
+            const uint32_t m2 = ((prnb::f2u(d2 + 4.0f * kMarginPerTerm) + 0xffffu) & 0xffff0000u) | p2;
+            asm volatile("s_mov_b64 exec, %0\n\tds_write_b128 %1, %2\n\tds_write_b32 %3, %4\n\ts_mov_b64 exec, -1"
+                         :: "s"(push_m), "v"(s2_lds + (slot << 4)), "v"(e2), "v"(s2m_lds + (slot << 2)), "v"(m2) : "memory");
         }
         s2_top += __popcll(push_m);
     };
+#undef K3_MASK
 
     // ---- stage 1 over the strip ----------------------------------------------------------------
     // What a pass needs per cell is wave-uniform and arrives by scalar loads issued one pass (the
@@ -442,12 +452,13 @@ __global__ __launch_bounds__(kBlock) void sample_counts_stream_kernel(
             // The compare mask goes straight into an SGPR pair (every lane is active here, so it is
             // the ballot), the push is one LDS store under exec = mask: no branch, no exec save.
             // (The stage-1 loop must stay wave-uniform: the asm below ends with exec = -1.)
+            const float wf = (float)W.w[j];                    // PRNB-3's remainder starts as this
             unsigned long long push_m;
-            asm("v_cmp_nlt_f32 %0, %1, %2" : "=s"(push_m) : "v"((float)W.w[j]), "v"(bound32));   // not settled as 0 (or NaN)
-            u32x4 e;                                           // S1Entry {m, theta, w, pos}
+            asm("v_cmp_nlt_f32 %0, %1, %2" : "=s"(push_m) : "v"(wf), "v"(bound32));   // not settled as 0 (or NaN)
+            u32x4 e;                                           // S1Entry {m, theta, wf, pos}
             e.x = __float_as_uint(m);
             e.y = __float_as_uint(PRNB_FMA(a[j], m, bm1[j]));
-            e.z = W.w[j];
+            e.z = __float_as_uint(wf);
             e.w = posbase | (lane4 + j);
             const uint32_t slot = (s1_lds + ((uint32_t)s1_top << 4)) + ((uint32_t)lane_rank(push_m) << 4);
             asm volatile("s_mov_b64 exec, %0\n\tds_write_b128 %1, %2\n\ts_mov_b64 exec, -1"

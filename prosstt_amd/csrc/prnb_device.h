@@ -1,4 +1,4 @@
-// PRNB-2 count sampler, device side (gfx950).  DESIGN.md section 4 defines it; this is
+// PRNB-3 count sampler, device side (gfx950).  DESIGN.md section 4 defines it; this is
 // the product implementation.  Replaces, per (cell, gene):
 //   count_model.get_pr_umi                 /root/reference/prosstt/count_model.py:131-161
 //   scipy.stats.nbinom(n=r,p=1-p).rvs()    /root/reference/prosstt/simulation.py:647-648
@@ -158,23 +158,24 @@ __device__ __forceinline__ float unif(uint32_t w) { return ((float)w + 0.5f) * 2
 
 __device__ __forceinline__ float det_sqrt(float x) { return __builtin_sqrtf(x); }  // IEEE (see Makefile)
 
-// Inversion by chop-down in 0.32 fixed point; inv_k = LDS table of 1/k (0 sentinel at the end).
-// P(k+1) = P(k) * num_k / (k+1), num_k = mp + k*q.  When the pmf falls below
-// 2^-32 before w is used up (mass lost to rounding, < 1e-6) the draw is the last k of the group
-// of terms (k = 0..2, then four at a time: the streaming kernel's passes) in which it vanished.
+// Inversion by chop-down on a binary32 remainder; inv_k = LDS table of 1/k (0 sentinel at the end).
+// P(k+1) = P(k) * num_k / (k+1), num_k = mp + k*q, carried scaled by 2^32.  The remainder starts as
+// (float)w and every term is subtracted from it; the draw is the first k whose subtraction leaves it
+// negative.  Terms come in groups (k = 0..2, then four at a time: the streaming kernel's passes); when
+// a group ends without a negative remainder and its last term is below 1 (the pmf has fallen under
+// 2^-32 before w is used up: mass lost to rounding, < 1e-6) the draw is that group's last k.
 __device__ __forceinline__ int32_t chop_down(uint32_t w, float p0, float mp, float q,
                                              const float* inv_k)
 {
-    float p = __builtin_fminf(p0, 0.99999994f);
+    float ps = __builtin_fminf(p0, 0.99999994f) * 4294967296.0f;
     float num = mp;
-    uint32_t rem = w;
+    float rem = (float)w;
     int k = 0;
     for (;;) {
-        const uint32_t pf = (uint32_t)(p * 4294967296.0f);
-        if (rem < pf) return k;
-        if (pf == 0u) return ((k + 1) | 3) - 1;
-        rem -= pf;
-        p = (p * num) * inv_k[k + 1];
+        rem = rem - ps;
+        if (rem < 0.0f) return k;
+        if ((k & 3) == 2 && ps < 1.0f) return k;
+        ps = (ps * num) * inv_k[k + 1];
         ++k;
         // numerator mp + k*q: one fma where a group of four terms starts (k = 3, 7, ...), by
         // addition inside a group (the rounding errors of a running sum would pile up over a long walk)
@@ -189,16 +190,15 @@ __device__ __forceinline__ int32_t chop_down(uint32_t w, float p0, float mp, flo
 __device__ __forceinline__ int32_t chop_down_grouped(uint32_t w, float p0, float mp, float q,
                                                      const float* inv_k)
 {
-    float p = __builtin_fminf(p0, 0.99999994f);
+    float ps = __builtin_fminf(p0, 0.99999994f) * 4294967296.0f;
     float num = mp;
-    uint32_t rem = w;
+    float rem = (float)w;
     // k = 0, 1, 2 as chop_down does them
     for (int k = 0; k < 3; ++k) {
-        const uint32_t pf = (uint32_t)(p * 4294967296.0f);
-        if (rem < pf) return k;
-        if (pf == 0u) return 2;
-        rem -= pf;
-        p = (p * num) * inv_k[k + 1];
+        rem = rem - ps;
+        if (rem < 0.0f) return k;
+        if (k == 2 && ps < 1.0f) return 2;
+        ps = (ps * num) * inv_k[k + 1];
         num = (k == 2) ? PRNB_FMA(3.0f, q, mp) : num + q;
     }
     for (int k = 3;; k += 4) {
@@ -206,11 +206,10 @@ __device__ __forceinline__ int32_t chop_down_grouped(uint32_t w, float p0, float
         const float iv[4] = {inv.x, inv.y, inv.z, inv.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t pf = (uint32_t)(p * 4294967296.0f);
-            if (rem < pf) return k + j;
-            if (pf == 0u) return k + 3;
-            rem -= pf;
-            p = (p * num) * iv[j];
+            rem = rem - ps;
+            if (rem < 0.0f) return k + j;
+            if (j == 3 && ps < 1.0f) return k + 3;
+            ps = (ps * num) * iv[j];
             num = (j == 3) ? PRNB_FMA((float)(k + 4), q, mp) : num + q;
         }
     }

@@ -1,8 +1,9 @@
 // libprosstt_amd.so -- HIP kernels (gfx950) and the C ABI of include/prosstt_amd.h.
 //
 // Kernels
-//   prep_params_kernel      binary64 scaling/alpha/beta -> binary32 sampler parameters
-//   sample_counts_kernel    K3: fused gather * scale -> get_pr_umi -> NB draw
+//   prep_kernel             binary64 scaling/alpha/beta -> binary32 sampler parameters, per-cell records, flag words
+//   k3::sample_counts_stream_kernel + k3::sample_counts_heavy_kernel (k3_stream.h, k3_heavy.h)
+//                           K3: fused gather * scale -> get_pr_umi -> NB draw
 //                           (simulation.py:602-651, count_model.py:131-161)
 //   nb_params_kernel        the deterministic intermediates of the same path
 //   lineage_attempt_kernel  K2a: max(programs@H) and per-sibling anticorrelated-gene
@@ -57,6 +58,12 @@ struct prosstt_amd_ctx {
     int64_t* h_scratch = nullptr;  // pinned mirror
     std::vector<hipEvent_t> events;  // (start, stop) pairs of kernels launched with TIME_KERNEL
     size_t events_used = 0;
+    // the K3h list of the last sample_counts call (inside `ws`; read by prosstt_amd_last_list)
+    uint32_t* list = nullptr;
+    uint32_t* list_count = nullptr;
+    uint64_t list_regions = 0;
+    uint32_t list_cap = 0;
+    int64_t list_groups = 0, list_strip_cells = 0;
 };
 
 // next (start, stop) event pair of the ctx's pool
@@ -114,13 +121,19 @@ struct Staging {
 
 // ------------------------------------------------------------------ kernels
 
-__global__ void prep_params_kernel(const double* __restrict__ scaling, int64_t N,
-                                   const double* __restrict__ alpha,
-                                   const double* __restrict__ beta, int32_t G,
-                                   float* __restrict__ scal_f, float* __restrict__ a_f,
-                                   float* __restrict__ bm1_f, float* __restrict__ phi_f)
+// One launch prepares a sample_counts call: binary64 scaling/alpha/beta -> the binary32 sampler
+// parameters (and the zero-test factor), the per-cell records of the streaming kernel (k3::CellInfo;
+// N + 4 entries, the last cell repeated; skipped when `info` is NULL), and the call's flag words.
+__global__ void prep_kernel(const double* __restrict__ scaling, int64_t N,
+                            const double* __restrict__ alpha, const double* __restrict__ beta, int32_t G,
+                            float* __restrict__ scal_f, float* __restrict__ a_f,
+                            float* __restrict__ bm1_f, float* __restrict__ phi_f,
+                            const int32_t* __restrict__ row_of_cell, int64_t rows, uint64_t cell_offset,
+                            const int64_t* __restrict__ cell_index, int32_t strip_cells,
+                            k3::CellInfo* __restrict__ info, int64_t* __restrict__ flags)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (flags && i < 4) flags[i] = 0;      // [0] domain flag, [1] row index outside the tensor, [2] full-test request, [3] list overflow
     if (i < N) scal_f[i] = (float)scaling[i];
     if (i < G) {
         const float a = (float)alpha[i];
@@ -129,143 +142,28 @@ __global__ void prep_params_kernel(const double* __restrict__ scaling, int64_t N
         bm1_f[i] = bm1;
         phi_f[i] = prnb::zero_test_factor(a, bm1);
     }
-}
-
-// Per-cell record of the streaming kernel (k3::CellInfo); N + 4 entries, the last cell repeated.
-__global__ void cellinfo_kernel(const int32_t* __restrict__ row_of_cell, const float* __restrict__ scal,
-                                int64_t N, int32_t G, int64_t rows, uint64_t cell_offset,
-                                const int64_t* __restrict__ cell_index, int32_t strip_cells,
-                                k3::CellInfo* __restrict__ info)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N + 4) return;
-    const int64_t n = i < N ? i : N - 1;
-    const uint64_t cell = cell_index ? (uint64_t)cell_index[n] : cell_offset + (uint64_t)n;
-    k3::CellInfo c;
-    // an index outside the tensor (the caller's bug; the checked mode reports it) must not become a wild read
-    const int64_t row = row_of_cell[n] < 0 ? 0 : (row_of_cell[n] >= rows ? rows - 1 : row_of_cell[n]);
-    c.row_bytes = (uint64_t)row * (uint64_t)G * 4u;
-    c.s = scal[n];
-    c.cell_lo = (uint32_t)cell;
-    c.cell_hi = (uint32_t)(cell >> 32);
-    c.pos_base = (uint32_t)(n % strip_cells) << 8;
-    c.pad1 = c.pad2 = 0u;
-    info[i] = c;
-}
-
-constexpr int kTileG = 256;   // genes per tile = 64 lanes x 4
-constexpr int kTileC = 16;    // cells per tile = 4 waves x 4 steps
-constexpr int kBlock = 256;
-
-// One block = one (cell tile, gene tile).  A wave owns one cell per step and its 64
-// lanes own 4 consecutive genes each, so every global access is a 1 KiB contiguous
-// row segment.  Samples whose parameters need the gamma-Poisson path are queued in
-// LDS and handled afterwards by all 256 threads (compaction instead of divergence);
-// the tile is staged in LDS so that both paths land in one coalesced store.
-template <bool VEC>
-__global__ __launch_bounds__(kBlock) void sample_counts_kernel(
-    const float* __restrict__ means, int32_t G, const int32_t* __restrict__ row_of_cell,
-    const float* __restrict__ scal, const float* __restrict__ ga, const float* __restrict__ gbm1,
-    int64_t N, uint32_t k0, uint32_t k1, uint64_t cell_offset, const int64_t* __restrict__ cell_index,
-    int32_t* __restrict__ out, int64_t ld, int64_t* __restrict__ domain_flag, int32_t tiles_c)
-{
-    __shared__ __attribute__((aligned(16))) float inv_k[prnb::kKTab + 8];   // 0 from the sentinel (k = KTAB-1) on
-    __shared__ int32_t tile[kTileC][kTileG];
-    __shared__ uint16_t queue[kTileC * kTileG];
-    __shared__ int q_count;
-
-    const int tid = threadIdx.x;
-    const int ql = tid & 63, wv = tid >> 6;
-    const int32_t tile_g = blockIdx.x / tiles_c;
-    const int32_t tile_c = blockIdx.x - tile_g * tiles_c;
-    const int32_t g0 = tile_g * kTileG + ql * 4;
-    const int64_t n0 = (int64_t)tile_c * kTileC;
-
-    for (int k = tid; k < prnb::kKTab + 8; k += kBlock) inv_k[k] = (k && k < prnb::kKTab - 1) ? 1.0f / (float)k : 0.0f;
-    if (tid == 0) q_count = 0;
-    __syncthreads();
-
-    float a[4], bm1[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const bool in = g0 + j < G;
-        a[j] = in ? ga[g0 + j] : 0.0f;
-        bm1[j] = in ? gbm1[g0 + j] : 0.0f;
-    }
-
-    bool bad = false;
-#pragma unroll 1
-    for (int step = 0; step < kTileC / 4; ++step) {
-        const int cl = step * 4 + wv;
-        const int64_t n = n0 + cl;
-        if (n >= N || g0 >= G) continue;
-        const int64_t row = row_of_cell[n];
-        const float s = scal[n];
+    if (info && i < N + 4) {
+        const int64_t n = i < N ? i : N - 1;
         const uint64_t cell = cell_index ? (uint64_t)cell_index[n] : cell_offset + (uint64_t)n;
-        const uint32_t c0 = (uint32_t)cell, c1 = (uint32_t)(cell >> 32);
-        float M[4];
-        if (VEC) {
-            const float4 v = *reinterpret_cast<const float4*>(means + row * G + g0);
-            M[0] = v.x; M[1] = v.y; M[2] = v.z; M[3] = v.w;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) M[j] = (g0 + j < G) ? means[row * G + g0 + j] : 0.0f;
-        }
-        const prnb::Words W = prnb::philox4x32_10(c0, c1, (uint32_t)g0 >> 2, 0u, k0, k1);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int32_t res = 0;
-            if (g0 + j < G) {
-                const prnb::Params P = prnb::make_params(M[j], s, a[j], bm1[j]);
-                if (!P.valid) {
-                    bad = bad || !(P.m > 0.0f) || (__builtin_fmaf(a[j], P.m, bm1[j]) < 0.0f);
-                } else if (P.light) {
-                    res = prnb::light_draw(P, W.w[j], inv_k);
-                } else {
-                    const int slot = atomicAdd(&q_count, 1);
-                    queue[slot] = (uint16_t)(cl * kTileG + ql * 4 + j);
-                }
-            }
-            tile[cl][ql * 4 + j] = res;
-        }
+        k3::CellInfo c;
+        // an index outside the tensor (the caller's bug; the checked mode reports it) must not become a wild read
+        const int64_t row = row_of_cell[n] < 0 ? 0 : (row_of_cell[n] >= rows ? rows - 1 : row_of_cell[n]);
+        c.row_bytes = (uint64_t)row * (uint64_t)G * 4u;
+        c.s = (float)scaling[n];
+        c.cell_lo = (uint32_t)cell;
+        c.cell_hi = (uint32_t)(cell >> 32);
+        c.pos_base = (uint32_t)(n % strip_cells) << 8;
+        c.pad1 = c.pad2 = 0u;
+        info[i] = c;
     }
-    __syncthreads();
-
-    const int qn = q_count;
-    for (int e = tid; e < qn; e += kBlock) {
-        const int idx = queue[e];
-        const int cl = idx >> 8, gl = idx & (kTileG - 1);
-        const int64_t n = n0 + cl;
-        const int32_t g = tile_g * kTileG + gl;
-        const uint64_t cell = cell_index ? (uint64_t)cell_index[n] : cell_offset + (uint64_t)n;
-        const prnb::Params P =
-            prnb::make_params(means[(int64_t)row_of_cell[n] * G + g], scal[n], ga[g], gbm1[g]);
-        tile[cl][gl] = prnb::heavy_draw(P, (uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)g, k0,
-                                        k1, inv_k);
-    }
-    __syncthreads();
-
-#pragma unroll 1
-    for (int step = 0; step < kTileC / 4; ++step) {
-        const int cl = step * 4 + wv;
-        const int64_t n = n0 + cl;
-        if (n >= N || g0 >= G) continue;
-        int32_t* dst = out + n * ld + g0;
-        if (VEC) {
-            *reinterpret_cast<int4*>(dst) = *reinterpret_cast<const int4*>(&tile[cl][ql * 4]);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (g0 + j < G) dst[j] = tile[cl][ql * 4 + j];
-        }
-    }
-    if (bad) *domain_flag = 1;
 }
+
+constexpr int kTileG = 256;   // genes per tile of the streaming kernel = 64 lanes x 4
 
 __global__ void nb_params_kernel(const float* __restrict__ means, int32_t G,
                                  const int32_t* __restrict__ row_of_cell,
                                  const float* __restrict__ scal, const float* __restrict__ ga,
-                                 const float* __restrict__ gbm1, int64_t N, float* __restrict__ mu,
+                                 const float* __restrict__ gbm1, int64_t N, int64_t rows, float* __restrict__ mu,
                                  float* __restrict__ p, float* __restrict__ r,
                                  int32_t* __restrict__ path)
 {
@@ -273,8 +171,9 @@ __global__ void nb_params_kernel(const float* __restrict__ means, int32_t G,
     if (i >= N * G) return;
     const int64_t n = i / G;
     const int32_t g = (int32_t)(i - n * G);
-    const prnb::Params P =
-        prnb::make_params(means[(int64_t)row_of_cell[n] * G + g], scal[n], ga[g], gbm1[g]);
+    int64_t row = row_of_cell[n];
+    row = row < 0 ? 0 : (row >= rows ? rows - 1 : row);      // device pointers are unchecked: never a wild read
+    const prnb::Params P = prnb::make_params(means[row * G + g], scal[n], ga[g], gbm1[g]);
     if (mu) mu[i] = P.m;
     if (p) p[i] = P.valid ? P.theta * P.inv_u1 : 0.0f;
     if (r) r[i] = P.valid ? P.m * P.inv_th : 0.0f;
@@ -468,9 +367,9 @@ __global__ void domain_means_kernel(const float* __restrict__ means, int64_t row
 __global__ void domain_full_kernel(const float* __restrict__ means, int32_t G,
                                    const int32_t* __restrict__ row_of_cell, const float* __restrict__ scal,
                                    const float* __restrict__ ga, const float* __restrict__ gbm1, int64_t N,
-                                   int64_t* __restrict__ flagp)
+                                   int64_t rows, int64_t* __restrict__ flagp)
 {
-    if (flagp[2] == 0) return;
+    if (flagp[2] == 0 || flagp[1] != 0) return;     // [1]: a row index outside the tensor was found (reported as EINVAL)
     const int64_t total = N * (int64_t)G;
     bool bad = false;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -567,19 +466,50 @@ PA_EXPORT int prosstt_amd_last_kernel_ms(prosstt_amd_ctx* c, float* ms)
 // converts the binary64 per-cell / per-gene parameters into the workspace.
 struct SamplerArgs {
     const float* means; const int32_t* row_of_cell;
+    const int64_t* cell_index;   // device copy (NULL: cells are numbered from cell_offset)
     float *scal, *ga, *gbm1, *gphi;
     void* extra;     // `extra_bytes` of workspace behind the parameter vectors (256-B aligned)
 };
 
+// Geometry of a streaming-kernel launch (k3_stream.h): strips of 64 cells per wave (the kernel takes up
+// to 128; shorter ones when the problem is too small to give every SIMD of the chip a few waves), four
+// strips and one 256-gene tile per block.
+struct StreamGeometry {
+    int64_t tiles_g, strip_cells, strips, groups;
+    uint64_t regions;       // one region of the K3h list per wave
+    uint32_t region_cap;    // room for one in 16 of a wave's samples (beyond that K3h redoes the matrix itself)
+    size_t list_bytes, count_bytes, rows_bytes, info_bytes;
+    size_t total() const { return list_bytes + count_bytes + rows_bytes + info_bytes + 256; }
+};
+
+static StreamGeometry stream_geometry(int64_t N, int32_t G, int64_t rows)
+{
+    StreamGeometry g;
+    g.tiles_g = ((int64_t)(G > 0 ? G : 0) + kTileG - 1) / kTileG;
+    g.strip_cells = k3::kStripCells / 2;    // 64: measured best on C3 (128: +1.7 %, 32: +2.7 %)
+    const int64_t n = N > 0 ? N : 0;
+    while (g.strip_cells > 8 && ((n + g.strip_cells - 1) / g.strip_cells) * g.tiles_g < 4 * 5 * 1024) g.strip_cells /= 2;
+    g.strips = (n + g.strip_cells - 1) / g.strip_cells;
+    g.groups = (g.strips + 3) / 4;
+    g.regions = (uint64_t)(g.groups * g.tiles_g) * 4u;
+    g.region_cap = (uint32_t)g.strip_cells * (kTileG / 16);
+    g.list_bytes = ((g.regions * (size_t)g.region_cap * 4u) + 255) & ~(size_t)255;
+    g.count_bytes = ((g.regions * 4u) + 255) & ~(size_t)255;
+    g.rows_bytes = (((size_t)(rows > 0 ? rows : 0)) + 255) & ~(size_t)255;
+    g.info_bytes = ((size_t)n + 4) * sizeof(k3::CellInfo);
+    return g;
+}
+
 static int sampler_setup(prosstt_amd_ctx* c, Staging& st, const float* means, int64_t rows, int32_t G,
                          const int32_t* row_of_cell, const double* scaling, const double* alpha,
                          const double* beta, int64_t N, uint32_t flags, SamplerArgs* A,
-                         size_t extra_bytes = 0)
+                         const StreamGeometry* geo, uint64_t cell_offset, const int64_t* cell_index)
 {
     if (!c) return fail(PROSSTT_AMD_EINVAL, "ctx is NULL");
     if (N < 0 || G < 0 || rows < 0) return fail(PROSSTT_AMD_EINVAL, "negative size");
     if (N > 0 && G > 0 && (!means || !row_of_cell || !scaling || !alpha || !beta))
         return fail(PROSSTT_AMD_EINVAL, "NULL input array");
+    if (N > 0 && G > 0 && rows == 0) return fail(PROSSTT_AMD_EINVAL, "the mean tensor has no rows");
     if ((int64_t)G * 4 > (int64_t)1 << 33) return fail(PROSSTT_AMD_EINVAL, "G too large");
     HIP_TRY(hipSetDevice(c->device));
     if (N == 0 || G == 0) return 0;
@@ -601,21 +531,29 @@ static int sampler_setup(prosstt_amd_ctx* c, Staging& st, const float* means, in
         alpha = (const double*)d;
         if ((rc = st.upload(beta, (size_t)G * 8, &d, c->stream))) return rc;
         beta = (const double*)d;
+        if (cell_index) {
+            if ((rc = st.upload(cell_index, (size_t)N * 8, &d, c->stream))) return rc;
+            cell_index = (const int64_t*)d;
+        }
     }
     const int64_t n_pad = (N + 15) & ~(int64_t)15;
     const size_t vec_bytes = ((((size_t)n_pad + 3 * (size_t)G) * sizeof(float)) + 255) & ~(size_t)255;
-    int rc = ws_reserve(c, vec_bytes + extra_bytes);
+    int rc = ws_reserve(c, vec_bytes + (geo ? geo->total() : 0));
     if (rc) return rc;
     A->means = means;
     A->row_of_cell = row_of_cell;
+    A->cell_index = cell_index;
     A->scal = (float*)c->ws;
     A->ga = A->scal + n_pad;
     A->gbm1 = A->ga + G;
     A->gphi = A->gbm1 + G;
     A->extra = (char*)c->ws + vec_bytes;
-    const int64_t span = N > G ? N : G;
-    prep_params_kernel<<<dim3((unsigned)((span + 255) / 256)), dim3(256), 0, c->stream>>>(
-        scaling, N, alpha, beta, G, A->scal, A->ga, A->gbm1, A->gphi);
+    k3::CellInfo* info = nullptr;
+    if (geo) info = (k3::CellInfo*)((char*)A->extra + geo->list_bytes + geo->count_bytes + geo->rows_bytes);
+    const int64_t span = (N + 4 > G ? N + 4 : G);
+    prep_kernel<<<dim3((unsigned)((span + 255) / 256)), dim3(256), 0, c->stream>>>(
+        scaling, N, alpha, beta, G, A->scal, A->ga, A->gbm1, A->gphi, row_of_cell, rows, cell_offset, cell_index,
+        geo ? (int32_t)geo->strip_cells : 1, info, geo ? c->scratch : nullptr);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -628,48 +566,35 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
 {
     Staging st;
     SamplerArgs A{};
-    // geometry of the streaming kernel: strips of 64 cells per wave (the kernel takes up to 128);
-    // shorter ones when the problem is too small to give every SIMD of the chip a few waves
-    const bool tiled = (flags & PROSSTT_AMD_KERNEL_TILED) != 0;
-    const int64_t tiles_g = ((int64_t)(G > 0 ? G : 0) + kTileG - 1) / kTileG;
-    int64_t strip_cells = k3::kStripCells / 2;    // 64: measured best on C3 (128: +1.7 %, 32: +2.7 %)
-    while (strip_cells > 8 && (((N > 0 ? N : 0) + strip_cells - 1) / strip_cells) * tiles_g < 4 * 5 * 1024) strip_cells /= 2;
-    const int64_t strips = ((N > 0 ? N : 0) + strip_cells - 1) / strip_cells;
-    const int64_t groups = (strips + 3) / 4;
-    // the list of samples left to K3h: every wave of the streaming kernel owns a region of it, with
-    // room for one in 16 of its samples (beyond that K3h redoes the matrix itself) and a count
-    const uint64_t regions = tiled ? 0 : (uint64_t)(groups * tiles_g) * 4u;
-    const uint32_t region_cap = (uint32_t)strip_cells * (kTileG / 16);
-    const size_t list_bytes = ((regions * (size_t)region_cap * 4u) + 255) & ~(size_t)255;
-    const size_t count_bytes = ((regions * 4u) + 255) & ~(size_t)255;
-    const size_t rows_bytes = (((size_t)(rows > 0 ? rows : 0)) + 255) & ~(size_t)255;
-    const size_t info_bytes = tiled ? 0 : ((size_t)(N > 0 ? N : 0) + 4) * sizeof(k3::CellInfo);
-    const size_t word_bytes = list_bytes + count_bytes + rows_bytes + info_bytes + 256;
-    int rc = sampler_setup(c, st, means, rows, G, row_of_cell, scaling, alpha, beta, N, flags, &A, word_bytes);
+    // everything that can be refused is refused before the workspace grows
+    if (N > 0 && G > 0) {
+        if (!out) return fail(PROSSTT_AMD_EINVAL, "out is NULL");
+        if (ld_out < G) return fail(PROSSTT_AMD_EINVAL, "ld_out %lld < G %d", (long long)ld_out, G);
+        if (ld_out * k3::kStripCells >= ((int64_t)1 << 32))
+            return fail(PROSSTT_AMD_EINVAL, "ld_out too large for 32-bit strip offsets");
+        if (N > 0x7fffffffll) return fail(PROSSTT_AMD_EINVAL, "too many cells; chunk them");
+        if ((uint64_t)(rows > 0 ? rows : 0) * (uint64_t)G >= ((uint64_t)1 << 61)) return fail(PROSSTT_AMD_EINVAL, "mean tensor too large");
+    }
+    const StreamGeometry geo = stream_geometry(N, G, rows);
+    if (geo.groups * geo.tiles_g > 0x1fffffffll) return fail(PROSSTT_AMD_EINVAL, "too many tiles; chunk the cells");
+    int rc = sampler_setup(c, st, means, rows, G, row_of_cell, scaling, alpha, beta, N, flags, &A, &geo, cell_offset,
+                           cell_index);
     if (rc) return rc;
     if (N == 0 || G == 0) return 0;
-    if (!out) return fail(PROSSTT_AMD_EINVAL, "out is NULL");
     k3::HeavyList heavy;
     heavy.list = (uint32_t*)A.extra;
-    heavy.count = (uint32_t*)((char*)A.extra + list_bytes);
-    heavy.overflow = (uint32_t*)(c->scratch + 3);           // zeroed with the flags below
-    heavy.cap = region_cap;
-    uint8_t* rows_used = (uint8_t*)A.extra + list_bytes + count_bytes;
-    k3::CellInfo* cellinfo = (k3::CellInfo*)(rows_used + rows_bytes);
-    if (ld_out < G) return fail(PROSSTT_AMD_EINVAL, "ld_out %lld < G %d", (long long)ld_out, G);
-
-    if (cell_index && (flags & PROSSTT_AMD_HOST_INPUTS)) {
-        const void* d;
-        if ((rc = st.upload(cell_index, (size_t)N * 8, &d, c->stream))) return rc;
-        cell_index = (const int64_t*)d;
-    }
+    heavy.count = (uint32_t*)((char*)A.extra + geo.list_bytes);
+    heavy.overflow = (uint32_t*)(c->scratch + 3);           // zeroed by the preparation kernel
+    heavy.cap = geo.region_cap;
+    uint8_t* rows_used = (uint8_t*)A.extra + geo.list_bytes + geo.count_bytes;
+    k3::CellInfo* cellinfo = (k3::CellInfo*)(rows_used + geo.rows_bytes);
+    const int64_t* d_cell_index = A.cell_index;
     int32_t* d_out = out;
     if (flags & PROSSTT_AMD_HOST_OUTPUT) {
         void* p = nullptr;
         if ((rc = st.alloc(&p, (size_t)N * ld_out * 4))) return rc;
         d_out = (int32_t*)p;
     }
-    HIP_TRY(hipMemsetAsync(c->scratch, 0, 32, c->stream));   // [0] domain flag, [2] full-test request, [3] list overflow
 
     const bool vec = (G % 4 == 0) && (ld_out % 4 == 0) && (((uintptr_t)A.means & 15) == 0) &&
                      (((uintptr_t)d_out & 15) == 0);
@@ -678,57 +603,39 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
     if (flags & PROSSTT_AMD_TIME_KERNEL) {
         if ((rc = next_event_pair(c, &ev_start, &ev_stop))) return rc;
     }
-    if (flags & PROSSTT_AMD_KERNEL_TILED) {
-        const int64_t tiles_c = (N + kTileC - 1) / kTileC;
-        if (tiles_c * tiles_g > 0x7fffffffll) return fail(PROSSTT_AMD_EINVAL, "too many tiles; chunk the cells");
-        if (ev_start) HIP_TRY(hipEventRecord(ev_start, c->stream));
-        const dim3 grid((unsigned)(tiles_c * tiles_g)), block(kBlock);
-        if (vec)
-            sample_counts_kernel<true><<<grid, block, 0, c->stream>>>(A.means, G, A.row_of_cell, A.scal, A.ga,
-                                                                     A.gbm1, N, k0, k1, cell_offset, cell_index,
-                                                                     d_out, ld_out, c->scratch, (int32_t)tiles_c);
-        else
-            sample_counts_kernel<false><<<grid, block, 0, c->stream>>>(A.means, G, A.row_of_cell, A.scal, A.ga,
-                                                                      A.gbm1, N, k0, k1, cell_offset, cell_index,
-                                                                      d_out, ld_out, c->scratch, (int32_t)tiles_c);
-    } else {
-        if (ld_out * k3::kStripCells >= ((int64_t)1 << 32))
-            return fail(PROSSTT_AMD_EINVAL, "ld_out too large for 32-bit strip offsets");
-        if (groups * tiles_g > 0x1fffffffll || N > 0x7fffffffll)
-            return fail(PROSSTT_AMD_EINVAL, "too many tiles; chunk the cells");
-        if ((uint64_t)rows * (uint64_t)G >= ((uint64_t)1 << 61)) return fail(PROSSTT_AMD_EINVAL, "mean tensor too large");
-        cellinfo_kernel<<<dim3((unsigned)((N + 4 + 255) / 256)), dim3(256), 0, c->stream>>>(
-            A.row_of_cell, A.scal, N, G, rows, cell_offset, cell_index, (int32_t)strip_cells, cellinfo);
-        const dim3 grid((unsigned)(groups * tiles_g)), block(k3::kBlock);
-        if (ev_start) HIP_TRY(hipEventRecord(ev_start, c->stream));    // the dominant kernel is timed alone
-        if (vec)
-            k3::sample_counts_stream_kernel<true><<<grid, block, 0, c->stream>>>(
-                A.means, G, cellinfo, A.ga, A.gbm1, A.gphi, N, k0, k1, d_out, ld_out, (int32_t)strips,
-                (int32_t)strip_cells, heavy);
-        else
-            k3::sample_counts_stream_kernel<false><<<grid, block, 0, c->stream>>>(
-                A.means, G, cellinfo, A.ga, A.gbm1, A.gphi, N, k0, k1, d_out, ld_out, (int32_t)strips,
-                (int32_t)strip_cells, heavy);
-        HIP_TRY(hipGetLastError());
-        if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, c->stream));   // the dominant kernel is timed alone
-        // every wave takes whole regions of the list
-        k3::sample_counts_heavy_kernel<<<dim3(2048), dim3(k3::kHeavyBlock), 0, c->stream>>>(
-            heavy, (uint32_t)regions, (int32_t)strips, (int32_t)strip_cells, A.means, rows, G, A.row_of_cell, A.scal, A.ga,
-            A.gbm1, N, k0, k1, cell_offset, cell_index, d_out, ld_out);
-        ev_stop = nullptr;
-        if (flags & PROSSTT_AMD_CHECK_DOMAIN) {
-            HIP_TRY(hipMemsetAsync(rows_used, 0, (size_t)rows, c->stream));
-            const int64_t span = N > G ? N : G;
-            domain_rows_kernel<<<dim3((unsigned)((span + 255) / 256)), dim3(256), 0, c->stream>>>(
-                A.row_of_cell, A.scal, N, A.ga, A.gbm1, G, rows, rows_used, c->scratch);
-            domain_means_kernel<<<dim3(2048), dim3(256), 0, c->stream>>>(A.means, rows, G, rows_used, c->scratch);
-            domain_full_kernel<<<dim3(8192), dim3(256), 0, c->stream>>>(A.means, G, A.row_of_cell, A.scal, A.ga,
-                                                                      A.gbm1, N, c->scratch);
-            HIP_TRY(hipGetLastError());
-        }
-    }
+    const dim3 grid((unsigned)(geo.groups * geo.tiles_g)), block(k3::kBlock);
+    if (ev_start) HIP_TRY(hipEventRecord(ev_start, c->stream));    // the dominant kernel is timed alone
+    if (vec)
+        k3::sample_counts_stream_kernel<true><<<grid, block, 0, c->stream>>>(
+            A.means, G, cellinfo, A.ga, A.gbm1, A.gphi, N, k0, k1, d_out, ld_out, (int32_t)geo.strips,
+            (int32_t)geo.strip_cells, heavy);
+    else
+        k3::sample_counts_stream_kernel<false><<<grid, block, 0, c->stream>>>(
+            A.means, G, cellinfo, A.ga, A.gbm1, A.gphi, N, k0, k1, d_out, ld_out, (int32_t)geo.strips,
+            (int32_t)geo.strip_cells, heavy);
     HIP_TRY(hipGetLastError());
     if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, c->stream));
+    // every wave takes whole regions of the list
+    k3::sample_counts_heavy_kernel<<<dim3(2048), dim3(k3::kHeavyBlock), 0, c->stream>>>(
+        heavy, (uint32_t)geo.regions, (int32_t)geo.strips, (int32_t)geo.strip_cells, A.means, rows, G, A.row_of_cell,
+        A.scal, A.ga, A.gbm1, N, k0, k1, cell_offset, d_cell_index, d_out, ld_out);
+    HIP_TRY(hipGetLastError());
+    c->list = heavy.list;
+    c->list_count = heavy.count;
+    c->list_regions = geo.regions;
+    c->list_cap = heavy.cap;
+    c->list_groups = geo.groups;
+    c->list_strip_cells = geo.strip_cells;
+    if (flags & PROSSTT_AMD_CHECK_DOMAIN) {
+        HIP_TRY(hipMemsetAsync(rows_used, 0, (size_t)rows, c->stream));
+        const int64_t span = N > G ? N : G;
+        domain_rows_kernel<<<dim3((unsigned)((span + 255) / 256)), dim3(256), 0, c->stream>>>(
+            A.row_of_cell, A.scal, N, A.ga, A.gbm1, G, rows, rows_used, c->scratch);
+        domain_means_kernel<<<dim3(2048), dim3(256), 0, c->stream>>>(A.means, rows, G, rows_used, c->scratch);
+        domain_full_kernel<<<dim3(8192), dim3(256), 0, c->stream>>>(A.means, G, A.row_of_cell, A.scal, A.ga,
+                                                                  A.gbm1, N, rows, c->scratch);
+        HIP_TRY(hipGetLastError());
+    }
     if (flags & PROSSTT_AMD_HOST_OUTPUT)   // G columns of every row; the caller's padding beyond G is left alone
         HIP_TRY(hipMemcpy2DAsync(out, (size_t)ld_out * 4, d_out, (size_t)ld_out * 4, (size_t)G * 4, (size_t)N,
                                  hipMemcpyDeviceToHost, c->stream));
@@ -745,6 +652,43 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
     return 0;
 }
 
+// The samples the streaming kernel of the LAST sample_counts call on this ctx left to K3h (the gamma-Poisson
+// class, walks too close to a threshold, counts above 255), decoded to (cell, gene) pairs: `cells[i]` is the
+// cell's index in that call's arrays.  At most `cap` pairs are written; `*total` receives the number listed
+// (the regions' counts are clamped to their capacity, as K3h sees them) and `*overflowed` whether a region
+// was too small, in which case K3h ignored the list.  Valid until the next call on the ctx grows its workspace.
+PA_EXPORT int prosstt_amd_last_list(prosstt_amd_ctx* c, int64_t* cells, int32_t* genes, int64_t cap,
+                                    int64_t* total, int32_t* overflowed)
+{
+    if (!c || !total) return fail(PROSSTT_AMD_EINVAL, "NULL argument");
+    if (cap > 0 && (!cells || !genes)) return fail(PROSSTT_AMD_EINVAL, "NULL output array");
+    *total = 0;
+    if (overflowed) *overflowed = 0;
+    if (!c->list || c->list_regions == 0) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<uint32_t> counts(c->list_regions);
+    HIP_TRY(hipMemcpy(counts.data(), c->list_count, counts.size() * 4, hipMemcpyDeviceToHost));
+    int64_t flagw[4];
+    HIP_TRY(hipMemcpy(flagw, c->scratch, sizeof(flagw), hipMemcpyDeviceToHost));
+    if (overflowed) *overflowed = (int32_t)((uint32_t)flagw[3] != 0u);
+    std::vector<uint32_t> entries(c->list_cap);
+    int64_t written = 0;
+    for (uint64_t r = 0; r < c->list_regions; ++r) {
+        const uint32_t n = counts[r] < c->list_cap ? counts[r] : c->list_cap;
+        *total += n;
+        if (n == 0 || written >= cap) continue;
+        HIP_TRY(hipMemcpy(entries.data(), c->list + r * c->list_cap, (size_t)n * 4, hipMemcpyDeviceToHost));
+        const int64_t blk = (int64_t)(r >> 2), tile_g = blk / c->list_groups;
+        const int64_t n0 = ((blk - tile_g * c->list_groups) * 4 + (int64_t)(r & 3)) * c->list_strip_cells;
+        for (uint32_t i = 0; i < n && written < cap; ++i, ++written) {
+            cells[written] = n0 + (entries[i] >> 8);
+            genes[written] = (int32_t)(tile_g * kTileG + (entries[i] & 255u));
+        }
+    }
+    return 0;
+}
+
 PA_EXPORT int prosstt_amd_nb_params(prosstt_amd_ctx* c, const float* means, int64_t rows, int32_t G,
                                     const int32_t* row_of_cell, const double* scaling,
                                     const double* alpha, const double* beta, int64_t N, float* mu,
@@ -752,7 +696,7 @@ PA_EXPORT int prosstt_amd_nb_params(prosstt_amd_ctx* c, const float* means, int6
 {
     Staging st;
     SamplerArgs A{};
-    int rc = sampler_setup(c, st, means, rows, G, row_of_cell, scaling, alpha, beta, N, flags, &A);
+    int rc = sampler_setup(c, st, means, rows, G, row_of_cell, scaling, alpha, beta, N, flags, &A, nullptr, 0, nullptr);
     if (rc) return rc;
     if (N == 0 || G == 0) return 0;
     const size_t bytes = (size_t)N * G * 4;
@@ -763,7 +707,7 @@ PA_EXPORT int prosstt_amd_nb_params(prosstt_amd_ctx* c, const float* means, int6
             if (h[i] && (rc = st.alloc(&d[i], bytes))) return rc;
     const int64_t total = N * (int64_t)G;
     nb_params_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream>>>(
-        A.means, G, A.row_of_cell, A.scal, A.ga, A.gbm1, N, (float*)d[0], (float*)d[1], (float*)d[2],
+        A.means, G, A.row_of_cell, A.scal, A.ga, A.gbm1, N, rows, (float*)d[0], (float*)d[1], (float*)d[2],
         (int32_t*)d[3]);
     HIP_TRY(hipGetLastError());
     if (flags & PROSSTT_AMD_HOST_OUTPUT)

@@ -100,13 +100,24 @@ class Context:
         # contract in the C ABI; with check_domain the library's domain pass also reports an index outside
         # the tensor, as PROSSTT_AMD_EINVAL)
         flags = (_native.CHECK_DOMAIN if check_domain else 0) | (_native.TIME_KERNEL if time_kernel else 0)
-        if os.environ.get("PROSSTT_AMD_KERNEL", "") == "tiled":      # A/B switch; same results
-            flags |= _native.KERNEL_TILED
         _native.check(self._lib.prosstt_amd_sample_counts(
             self._h, _ptr(means), rows, G, _ptr(row_of_cell), _ptr(scaling), _ptr(alpha), _ptr(beta),
             N, ctypes.c_uint64(seed & (2 ** 64 - 1)), ctypes.c_uint64(cell_offset), _ptr(cell_index),
             _ptr(out), out.stride(0) if N else G, flags))
         return out
+
+    def last_list(self, cap=1 << 22):
+        """(cells, genes, total, overflowed): the samples the streaming kernel of the last
+        sample_counts call left to its second kernel (see prosstt_amd_last_list)."""
+        cells = np.empty(cap, np.int64)
+        genes = np.empty(cap, np.int32)
+        total = ctypes.c_int64(0)
+        over = ctypes.c_int32(0)
+        _native.check(self._lib.prosstt_amd_last_list(
+            self._h, cells.ctypes.data_as(ctypes.c_void_p), genes.ctypes.data_as(ctypes.c_void_p), cap,
+            ctypes.byref(total), ctypes.byref(over)))
+        n = min(cap, total.value)
+        return cells[:n], genes[:n], total.value, bool(over.value)
 
     def nb_params(self, means, row_of_cell, scaling, alpha, beta):
         """(mu, p, r, path) device tensors (N, G) -- the sampler's deterministic intermediates."""
@@ -206,11 +217,53 @@ def host_fingerprint(arrays):
     return tuple(out)
 
 
-def to_host_int64(counts):
-    """int32 device counts -> the reference's int64 ndarray.  Widening on the device and copying
-    8 B per count is several times faster than a host-side ``astype`` of a multi-GB matrix."""
+PINNED_RETURN_MAX = int(os.environ.get("PROSSTT_AMD_PINNED_MAX_BYTES", str(32 << 30)))
+
+
+def to_host_int64(counts, chunk_bytes=256 << 20):
+    """int32 device counts -> the reference's int64 ndarray (simulation.py:651).
+
+    The matrix is widened on the device a chunk of rows at a time (two staging buffers) and every
+    chunk travels by an asynchronous copy on a second stream while the next one is widened.  The
+    destination is page-locked host memory from torch's caching host allocator whenever the matrix is
+    at most PROSSTT_AMD_PINNED_MAX_BYTES (default 32 GiB): DMA straight into the array that is
+    returned, no bounce buffers and no first-touch page faults; the block goes back to the allocator's
+    cache when the caller drops the array, so the pinning cost is paid once per size.  Larger results
+    (or a failed page-lock) take the same chunked path into ordinary memory."""
     torch = _torch()
-    return counts.to(torch.int64).cpu().numpy()
+    n, g = counts.shape
+    if n == 0 or g == 0:
+        return np.zeros((n, g), dtype=np.int64)
+    host = None
+    if n * g * 8 <= PINNED_RETURN_MAX:
+        try:
+            host = torch.empty((n, g), dtype=torch.int64, pin_memory=True)
+        except RuntimeError:
+            host = None
+    if host is None:
+        host = torch.empty((n, g), dtype=torch.int64)
+    rows = max(1, min(n, int(chunk_bytes) // (g * 8)))
+    dev = counts.device
+    compute = torch.cuda.current_stream(dev)
+    copier = torch.cuda.Stream(dev)
+    staging = [torch.empty((rows, g), dtype=torch.int64, device=dev) for _ in range(2 if rows < n else 1)]
+    copied = [None, None]
+    for i, lo in enumerate(range(0, n, rows)):
+        hi = min(lo + rows, n)
+        slot = i & 1
+        if copied[slot] is not None:
+            compute.wait_event(copied[slot])           # the buffer's previous chunk has left
+        stage = staging[slot][:hi - lo]
+        stage.copy_(counts[lo:hi])                      # int32 -> int64 on the device
+        widened = torch.cuda.Event()
+        widened.record(compute)
+        copier.wait_event(widened)
+        with torch.cuda.stream(copier):
+            host[lo:hi].copy_(stage, non_blocking=True)
+            copied[slot] = torch.cuda.Event()
+            copied[slot].record(copier)
+    copier.synchronize()
+    return host.numpy()
 
 
 _contexts = {}
