@@ -15,7 +15,7 @@
  * the SAME law  NB(n = r, p = 1-p)  with  theta = a*m + b - 1,  r = m/theta,
  * p = theta/(1+theta)  (the algebraic form of get_pr_umi), defined so that
  * every sample is a pure function of (M, s, a, b, seed, cell, gene):
- *   - randomness: Philox4x32-10 (Salmon et al. 2011), key = seed,
+ *   - randomness: Philox4x32-7 (Salmon et al. 2011: the fewest rounds that pass BigCrush), key = seed,
  *     counter = (cell_lo, cell_hi, gene-or-quad, domain);
  *   - arithmetic: IEEE binary32 add/mul/fma/sqrt only, plus the polynomial
  *     log/exp/cos and the Newton reciprocal below -- no libm, no hardware
@@ -51,11 +51,11 @@ static inline uint32_t f2u(float x) { uint32_t u; memcpy(&u, &x, 4); return u; }
 static inline float u2f(uint32_t u) { float x; memcpy(&x, &u, 4); return x; }
 #define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
 
-/* ---- Philox4x32-10 -------------------------------------------------------- */
-static inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                 uint32_t k0, uint32_t k1, uint32_t out[4])
+/* ---- Philox4x32-R (Salmon, Moraes, Dror, Shaw 2011) ----------------------- */
+static inline void philox4x32_r(int rounds, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                uint32_t k0, uint32_t k1, uint32_t out[4])
 {
-    for (int round = 0; round < 10; ++round) {
+    for (int round = 0; round < rounds; ++round) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -66,6 +66,19 @@ static inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+/* the library default (known-answer vectors; the device-mode lineage walk PRLW-1) */
+static inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                 uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+    philox4x32_r(10, c0, c1, c2, c3, k0, k1, out);
+}
+/* the count sampler: Philox4x32-7, the fewest rounds that pass BigCrush (Salmon et al. 2011, table 2) */
+#define PRNB_COUNT_ROUNDS 7
+static inline void philox_count(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+    philox4x32_r(PRNB_COUNT_ROUNDS, c0, c1, c2, c3, k0, k1, out);
 }
 
 /* ---- deterministic binary32 math ----------------------------------------- */
@@ -216,12 +229,12 @@ static inline int32_t poisson_draw(float lam, uint32_t c0, uint32_t c1, uint32_t
     uint32_t w[4];
     if (!(lam > 0.0f)) return 0;
     if (lam < PRNB_POIS_INV) {
-        philox4x32_10(c0, c1, gene, 0x80000000u, k0, k1, w);
+        philox_count(c0, c1, gene, 0x80000000u, k0, k1, w);
         return chop_down(w[0], det_exp(-lam), lam, 0.0f);
     }
     float slam = sqrtf(lam);
     if (!(lam < PRNB_LAM_BIG)) {               /* rounded normal; never reached with abs_max=5000 */
-        philox4x32_10(c0, c1, gene, 0x80000000u, k0, k1, w);
+        philox_count(c0, c1, gene, 0x80000000u, k0, k1, w);
         float z = sqrtf(-2.0f * det_log(unif(w[0]))) * det_cos2pi(w[1]);
         float kf = floorf(FMA(slam, z, lam) + 0.5f);
         return (int32_t)fminf(fmaxf(kf, 0.0f), 2147483520.0f);
@@ -233,7 +246,7 @@ static inline int32_t poisson_draw(float lam, uint32_t c0, uint32_t c1, uint32_t
     float vr = FMA(-3.6224f, det_rcp(bb - 2.0f), 0.9277f);
     float kf = floorf(lam);
     for (int j = 0; j < 2 * PRNB_MAX_TRIES; ++j) {
-        if ((j & 1) == 0) philox4x32_10(c0, c1, gene, 0x80000000u + (uint32_t)(j >> 1), k0, k1, w);
+        if ((j & 1) == 0) philox_count(c0, c1, gene, 0x80000000u + (uint32_t)(j >> 1), k0, k1, w);
         float U = unif(w[(j & 1) * 2]) - 0.5f;
         float V = unif(w[(j & 1) * 2 + 1]);
         float us = fmaxf(0.5f - fabsf(U), 5.8207661e-11f);       /* 2^-34 */
@@ -272,7 +285,7 @@ static inline float gamma_scaled(float r, float theta, uint32_t c0, uint32_t c1,
     for (int i = 0; i < PRNB_MAX_TRIES; ++i) {
         /* every attempt is a pure function of (i, parameters); attempt MAX_TRIES-1 is final */
         const int last = (i == PRNB_MAX_TRIES - 1);
-        philox4x32_10(c0, c1, gene, 1u + (uint32_t)i, k0, k1, w);
+        philox_count(c0, c1, gene, 1u + (uint32_t)i, k0, k1, w);
         float x = sqrtf(-2.0f * det_log(unif(w[0]))) * det_cos2pi(w[1]);
         float t = cc * x;
         float v1 = 1.0f + t;
@@ -319,7 +332,7 @@ static inline int32_t prnb_one(float M, float s, float a, float bm1, uint32_t k0
     if (theta <= PRNB_LIGHT_THETA && t <= PRNB_LIGHT_T) {
         uint32_t w[4];
         if (det) det->path = 1;
-        philox4x32_10(c0, c1, gene >> 2, 0u, k0, k1, w);
+        philox_count(c0, c1, gene >> 2, 0u, k0, k1, w);
         return chop_down(w[gene & 3u], det_exp(-t), m * inv_u1, q);
     }
     if (det) det->path = 2;
@@ -341,6 +354,13 @@ PRNB_EXPORT void prnb_philox(const uint32_t ctr[4], const uint32_t key[2], uint3
 {
     philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
 }
+
+PRNB_EXPORT void prnb_philox_rounds(int rounds, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    philox4x32_r(rounds, ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
+}
+
+PRNB_EXPORT int prnb_count_rounds(void) { return PRNB_COUNT_ROUNDS; }
 
 /* elementwise math probes: which = 0 rcp, 1 log, 2 log1p, 3 exp, 4 cos2pi(bits of x), 5 unif(bits) */
 PRNB_EXPORT PRNB_CLONES void prnb_math(int which, const float* x, float* y, int64_t n)

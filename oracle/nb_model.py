@@ -29,6 +29,9 @@ def lib():
             build()
         L = ctypes.CDLL(path)
         L.prnb_philox.argtypes = [_u32p, _u32p, _u32p]
+        L.prnb_philox_rounds.argtypes = [ctypes.c_int, _u32p, _u32p, _u32p]
+        L.prnb_philox_rounds.restype = None
+        L.prnb_count_rounds.restype = ctypes.c_int
         L.prnb_math.argtypes = [ctypes.c_int, _f32p, _f32p, ctypes.c_int64]
         L.prnb_sample_counts.argtypes = [_f32p, ctypes.c_int64, ctypes.c_int32, _i32p, _f64p, _f64p,
                                          _f64p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64,
@@ -49,6 +52,17 @@ def philox(ctr, key):
     out = np.zeros(4, np.uint32)
     lib().prnb_philox(np.asarray(ctr, np.uint32), np.asarray(key, np.uint32), out)
     return out
+
+
+def philox_rounds(rounds, ctr, key):
+    out = np.zeros(4, np.uint32)
+    lib().prnb_philox_rounds(rounds, np.asarray(ctr, np.uint32), np.asarray(key, np.uint32), out)
+    return out
+
+
+def count_rounds():
+    """Rounds of the Philox4x32 generator behind the count sampler."""
+    return lib().prnb_count_rounds()
 
 
 MATH = dict(rcp=0, log=1, log1p=2, exp=3, cos2pi=4, unif=5, log1pmx=6)

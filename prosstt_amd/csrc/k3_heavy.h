@@ -67,17 +67,17 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
             if (!(lam > 0.0f)) {
                 x = 0;
             } else if (lam < prnb::kPoisInv) {
-                const prnb::Words w = prnb::philox4x32_10(c0, c1, (uint32_t)e.g, 0x80000000u, k0, k1);
+                const prnb::Words w = prnb::philox_count(c0, c1, (uint32_t)e.g, 0x80000000u, k0, k1);
                 x = prnb::chop_down(w.w[0], prnb::det_exp(-lam), lam, 0.0f, inv_k);
             } else if (!(lam < prnb::kLamBig)) {
-                const prnb::Words w = prnb::philox4x32_10(c0, c1, (uint32_t)e.g, 0x80000000u, k0, k1);
+                const prnb::Words w = prnb::philox_count(c0, c1, (uint32_t)e.g, 0x80000000u, k0, k1);
                 const float z = prnb::det_sqrt(-2.0f * prnb::det_log(prnb::unif(w.w[0]))) * prnb::det_cos2pi(w.w[1]);
                 const float kf = __builtin_floorf(PRNB_FMA(prnb::det_sqrt(lam), z, lam) + 0.5f);
                 x = (int32_t)__builtin_fminf(__builtin_fmaxf(kf, 0.0f), 2147483520.0f);
             } else {
                 const int j = e.attempt;
                 const prnb::Words w =
-                    prnb::philox4x32_10(c0, c1, (uint32_t)e.g, 0x80000000u + (uint32_t)(j >> 1), k0, k1);
+                    prnb::philox_count(c0, c1, (uint32_t)e.g, 0x80000000u + (uint32_t)(j >> 1), k0, k1);
                 const float slam = prnb::det_sqrt(lam);
                 const float bb = PRNB_FMA(2.53f, slam, 0.931f);
                 const float aa = PRNB_FMA(0.02483f, bb, -0.059f);
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
                 const float cc = prnb::det_rcp(3.0f * prnb::det_sqrt(dd));
                 const int i = e.attempt;
                 const bool last = (i == prnb::kMaxTries - 1);
-                const prnb::Words w = prnb::philox4x32_10((uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)e.g,
+                const prnb::Words w = prnb::philox_count((uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)e.g,
                                                           1u + (uint32_t)i, k0, k1);
                 const float x = prnb::det_sqrt(-2.0f * prnb::det_log(prnb::unif(w.w[0]))) * prnb::det_cos2pi(w.w[1]);
                 const float t = cc * x;
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
             const HLEntry e = L.hl[hl_top - 1 - lane];
             const prnb::Params P = prnb::make_params(means[(int64_t)e.row * G + e.g], scal[e.n], ga[e.g], gbm1[e.g]);
             const uint64_t cell = cell_id(e.n);
-            const prnb::Words w = prnb::philox4x32_10((uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)e.g >> 2, 0u, k0, k1);
+            const prnb::Words w = prnb::philox_count((uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)e.g >> 2, 0u, k0, k1);
             const int32_t x = prnb::light_draw(P, w.w[e.g & 3], inv_k);
             if (x != 0) out[(int64_t)e.n * ld + e.g] = x;
         }

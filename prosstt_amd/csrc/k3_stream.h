@@ -447,7 +447,7 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
         const uint32_t c_lo_next = cinfo[1].cell_lo, c_hi_next = cinfo[1].cell_hi, posbase_next = cinfo[1].pos_base;
         ++cinfo;
         __builtin_amdgcn_sched_barrier(0);
-        const prnb::Words W = prnb::philox4x32_10<2>(c_lo, c_hi, (uint32_t)g0 >> 2, 0u, k0, k1);
+        const prnb::Words W = prnb::philox_count<2>(c_lo, c_hi, (uint32_t)g0 >> 2, 0u, k0, k1);
         uint32_t s1_at = s1_lds + ((uint32_t)s1_top << 4);     // LDS byte address of the stack's top (wave-uniform)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {

@@ -32,15 +32,16 @@ __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
 
 struct Words { uint32_t w[4]; };
 
-// Philox4x32-10 (Salmon, Moraes, Dror, Shaw 2011).  Rounds from kXor3From on spell the two
-// 3-input xors as one v_bitop3_b32 each (gfx950); callers whose counter is partly wave-uniform
-// leave the first two rounds to the compiler, which moves their uniform halves to the scalar unit.
-template <int kXor3From = 10>
-__device__ __forceinline__ Words philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                               uint32_t k0, uint32_t k1)
+// Philox4x32-R (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11).  Rounds
+// from kXor3From on spell the two 3-input xors as one v_bitop3_b32 each (gfx950); callers whose counter is
+// partly wave-uniform leave the first two rounds to the compiler, which moves their uniform halves to the
+// scalar unit.
+template <int kRounds, int kXor3From>
+__device__ __forceinline__ Words philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                            uint32_t k0, uint32_t k1)
 {
 #pragma unroll
-    for (int round = 0; round < 10; ++round) {
+    for (int round = 0; round < kRounds; ++round) {
         // one 32x32->64 product per multiplier (v_mad_u64_u32) instead of separate hi and lo multiplies
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
@@ -59,6 +60,22 @@ __device__ __forceinline__ Words philox4x32_10(uint32_t c0, uint32_t c1, uint32_
     Words r;
     r.w[0] = c0; r.w[1] = c1; r.w[2] = c2; r.w[3] = c3;
     return r;
+}
+
+// The count sampler (PRNB-3) draws from Philox4x32-7: the fewest rounds of Philox4x32 that pass BigCrush
+// (Salmon et al. 2011, section 5 and table 2: "Crush-resistant"; 10 rounds are the library default for
+// margin).  Every counter is used once, a sample's uniforms are never compared with a neighbour's, and
+// the statistical tests of tests/ run on this generator; the three rounds are 3 % of the whole kernel.
+// The device-mode lineage walk (PRLW-1, not a hot path) keeps the 10-round default.
+constexpr int kCountRounds = 7;
+template <int kXor3From = kCountRounds>
+__device__ __forceinline__ Words philox_count(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
+{
+    return philox4x32<kCountRounds, kXor3From>(c0, c1, c2, c3, k0, k1);
+}
+__device__ __forceinline__ Words philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
+{
+    return philox4x32<10, 10>(c0, c1, c2, c3, k0, k1);
 }
 
 // 1/x, x > 0 normal: integer seed (5 % error) + 3 Newton steps
@@ -236,12 +253,12 @@ __device__ __forceinline__ int32_t poisson_draw(float lam, uint32_t c0, uint32_t
 {
     if (!(lam > 0.0f)) return 0;
     if (lam < kPoisInv) {
-        const Words w = philox4x32_10(c0, c1, gene, 0x80000000u, k0, k1);
+        const Words w = philox_count(c0, c1, gene, 0x80000000u, k0, k1);
         return chop_down(w.w[0], det_exp(-lam), lam, 0.0f, inv_k);
     }
     const float slam = det_sqrt(lam);
     if (!(lam < kLamBig)) {
-        const Words w = philox4x32_10(c0, c1, gene, 0x80000000u, k0, k1);
+        const Words w = philox_count(c0, c1, gene, 0x80000000u, k0, k1);
         const float z = det_sqrt(-2.0f * det_log(unif(w.w[0]))) * det_cos2pi(w.w[1]);
         const float kf = __builtin_floorf(PRNB_FMA(slam, z, lam) + 0.5f);
         return (int32_t)__builtin_fminf(__builtin_fmaxf(kf, 0.0f), 2147483520.0f);
@@ -254,7 +271,7 @@ __device__ __forceinline__ int32_t poisson_draw(float lam, uint32_t c0, uint32_t
     float kf = __builtin_floorf(lam);
     Words w;
     for (int j = 0; j < 2 * kMaxTries; ++j) {
-        if ((j & 1) == 0) w = philox4x32_10(c0, c1, gene, 0x80000000u + (uint32_t)(j >> 1), k0, k1);
+        if ((j & 1) == 0) w = philox_count(c0, c1, gene, 0x80000000u + (uint32_t)(j >> 1), k0, k1);
         const uint32_t wu = (j & 1) ? w.w[2] : w.w[0];
         const uint32_t wv = (j & 1) ? w.w[3] : w.w[1];
         const float U = unif(wu) - 0.5f;
@@ -292,7 +309,7 @@ __device__ __forceinline__ float gamma_scaled(float r, float theta, uint32_t c0,
     Words w;
     for (int i = 0; i < kMaxTries; ++i) {
         const bool last = (i == kMaxTries - 1);
-        w = philox4x32_10(c0, c1, gene, 1u + (uint32_t)i, k0, k1);
+        w = philox_count(c0, c1, gene, 1u + (uint32_t)i, k0, k1);
         const float x = det_sqrt(-2.0f * det_log(unif(w.w[0]))) * det_cos2pi(w.w[1]);
         const float t = cc * x;
         const float v1 = 1.0f + t;

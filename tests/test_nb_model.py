@@ -1,6 +1,6 @@
 """
-CPU tests of oracle/nb_model.c, the scalar C model of the device count sampler (PRNB-2):
-known-answer vectors of Philox4x32-10, accuracy of the deterministic binary32 math, and the
+CPU tests of oracle/nb_model.c, the scalar C model of the device count sampler (PRNB-3):
+known-answer vectors of Philox4x32-10 and -7, accuracy of the deterministic binary32 math, and the
 LAW of the sampler against the reference's distribution (scipy.stats.nbinom tables of fixture
 g7 and the oracle's numpy path).  The HIP kernel is then held bit-exact to this model (-m gpu).
 """
@@ -21,6 +21,33 @@ def test_philox_known_answers():
             [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
     for ctr, key, want in kat:
         assert list(nm.philox(ctr, key)) == want
+        assert list(nm.philox_rounds(10, ctr, key)) == want
+
+
+def test_philox_seven_rounds_is_the_count_samplers_generator():
+    """The count sampler draws from Philox4x32-7 (Salmon et al. 2011: the fewest rounds that pass
+    BigCrush).  First vector: Random123's kat_vectors for philox4x32 7; the others: the same round
+    function, whose 10-round form reproduces all three 10-round vectors above.  Then plain sanity on
+    a million words of the 7-round stream (bit balance, byte chi-square, lag-1 serial correlation of
+    neighbouring counters) -- not a substitute for BigCrush, a guard against a broken build."""
+    assert nm.count_rounds() == 7
+    kat7 = [([0, 0, 0, 0], [0, 0], [0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48]),
+            ([0xffffffff] * 4, [0xffffffff] * 2, [0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662]),
+            ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+             [0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a])]
+    for ctr, key, want in kat7:
+        assert list(nm.philox_rounds(7, ctr, key)) == want
+    # the sampler's own use of it: counter (cell, 0, gene >> 2, 0), one word per gene
+    words = np.concatenate([nm.philox_rounds(7, [c, 0, g, 0], [12345, 678]) for c in range(500) for g in range(500)])
+    n = words.size
+    bits = np.unpackbits(words.view(np.uint8))
+    assert abs(bits.mean() - 0.5) < 4 * 0.5 / np.sqrt(bits.size)
+    counts = np.bincount(words.view(np.uint8), minlength=256)
+    chi = ((counts - n * 4 / 256) ** 2 / (n * 4 / 256)).sum()
+    assert chi < 255 + 5 * np.sqrt(2 * 255)
+    u = words.astype(np.float64) / 2 ** 32
+    assert abs(np.corrcoef(u[:-1], u[1:])[0, 1]) < 5 / np.sqrt(n)
+    assert abs(np.corrcoef(u[:-4:4], u[4::4])[0, 1]) < 5 / np.sqrt(n / 4)      # same word of neighbouring gene quads
 
 
 def test_deterministic_math_accuracy():
