@@ -78,13 +78,45 @@ constexpr float kTailBand = 9.765625e-4f;    // a group's last term within 2^-10
 constexpr float kT2Sure = 27.41120f * (1.0f - 1.53e-5f);   // 19 / ln 2, less 2^-16: surely t <= 19
 constexpr int kLateCap = 128;      // results that missed their row wait here for one burst of stores (< 64 left + 64)
 
-// What stage 1 needs to know about a cell, packed by cellinfo_kernel so that one scalar load
-// fetches it: byte offset of the cell's row in the mean tensor, library-size factor, global id.
+// What stage 1 needs to know about a cell, packed by the preparation kernel so that one scalar load
+// fetches it: byte offset of the cell's row in the mean tensor, library-size factor, (cell index
+// within its strip) << 8, and the cell's share of the Philox call -- the counter is (cell_lo, cell_hi,
+// gene quad, 0), so the halves of rounds 1 and 2 that do not depend on the gene are the same for a whole
+// row of the count matrix: ph[0] = cell_hi ^ k0, ph[1] = hi(M1 * (hi(M0 * cell_lo) ^ k1)) ^ (k0 + W0),
+// ph[2] = lo(M0 * cell_lo) ^ (k1 + W1), ph[3] = lo(M1 * (hi(M0 * cell_lo) ^ k1))  (philox_cell_part).
 // The array holds N + 4 entries (the last cell repeated) so that prefetches need no clamp.
-// (pos_base = (cell index within its strip) << 8 rides along so that the 16-byte scalar load has
-// no dead destination register for the allocator to reuse while the load is in flight.)
-struct CellInfo { uint64_t row_bytes; float s; uint32_t cell_lo, cell_hi, pos_base, pad1, pad2; };
+struct CellInfo { uint64_t row_bytes; float s; uint32_t pos_base; uint32_t ph[4]; };
 static_assert(sizeof(CellInfo) == 32, "one s_load_dwordx8");
+
+constexpr uint32_t kPhiloxM0 = 0xD2511F53u, kPhiloxM1 = 0xCD9E8D57u, kPhiloxW0 = 0x9E3779B9u, kPhiloxW1 = 0xBB67AE85u;
+
+// the cell-only part of Philox4x32 on counter (cell_lo, cell_hi, x, 0), key (k0, k1): see CellInfo
+__host__ __device__ inline void philox_cell_part(uint32_t cell_lo, uint32_t cell_hi, uint32_t k0, uint32_t k1, uint32_t ph[4])
+{
+    const uint64_t p0 = (uint64_t)kPhiloxM0 * cell_lo;                       // round 1, first product
+    const uint64_t p1 = (uint64_t)kPhiloxM1 * ((uint32_t)(p0 >> 32) ^ k1);   // round 2, second product: c2' = hi(p0) ^ c3 ^ k1, c3 = 0
+    ph[0] = cell_hi ^ k0;
+    ph[1] = (uint32_t)(p1 >> 32) ^ (k0 + kPhiloxW0);
+    ph[2] = (uint32_t)p0 ^ (k1 + kPhiloxW1);
+    ph[3] = (uint32_t)p1;
+}
+
+// Philox4x32-7 of stage 1: rounds 1 and 2 from the cell's part (scalar registers) and the gene quad's
+// part (hi1, lo1 = the halves of M1 * quad, constant per lane over a strip), rounds 3..7 as usual.
+// Same words as prnb::philox_count(cell_lo, cell_hi, quad, 0, k0, k1).
+__device__ __forceinline__ prnb::Words philox_count_row(const uint32_t ph[4], uint32_t hi1, uint32_t lo1, uint32_t k0, uint32_t k1)
+{
+    static_assert(prnb::kCountRounds >= 3, "two rounds are spelled out here");
+    // round 1: c0' = hi1 ^ cell_hi ^ k0, c1' = lo1, c2' = hi(M0*cell_lo) ^ k1 (scalar), c3' = lo(M0*cell_lo) (scalar)
+    const uint32_t c0a = hi1 ^ ph[0];
+    // round 2: p0 = M0 * c0', p1 = M1 * c2' (scalar, in ph)
+    const uint64_t p0 = (uint64_t)kPhiloxM0 * c0a;
+    const uint32_t c0b = lo1 ^ ph[1];                 // hi(p1) ^ c1' ^ (k0 + W0)
+    const uint32_t c1b = ph[3];                       // lo(p1)
+    const uint32_t c2b = (uint32_t)(p0 >> 32) ^ ph[2];  // hi(p0) ^ c3' ^ (k1 + W1)
+    const uint32_t c3b = (uint32_t)p0;
+    return prnb::philox4x32<prnb::kCountRounds - 2, 0>(c0b, c1b, c2b, c3b, k0 + 2u * kPhiloxW0, k1 + 2u * kPhiloxW1);
+}
 
 struct S1Entry { float m, theta, wf; uint32_t pos; };  // theta = a*m + b - 1, not yet clamped; wf = (float)(32-bit uniform)
 struct S2Entry { float ps, mp, q, rem; };             // pmf (x 2^32) at k = 3 and what is left of wf; the numerator of step k is mp + k*q
@@ -421,7 +453,10 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
     Seg cur = load_seg(cinfo[0].row_bytes), nxt = load_seg(cinfo[1].row_bytes);
     uint64_t row2 = cinfo[2].row_bytes;
     float s = cinfo[0].s;
-    uint32_t c_lo = cinfo[0].cell_lo, c_hi = cinfo[0].cell_hi, posbase = cinfo[0].pos_base;
+    uint32_t posbase = cinfo[0].pos_base;
+    uint32_t ph[4] = {cinfo[0].ph[0], cinfo[0].ph[1], cinfo[0].ph[2], cinfo[0].ph[3]};
+    const uint64_t quad_p1 = (uint64_t)kPhiloxM1 * ((uint32_t)g0 >> 2);     // the gene quad's part of round 1
+    const uint32_t quad_hi = (uint32_t)(quad_p1 >> 32), quad_lo = (uint32_t)quad_p1;
     // Nothing may be pending on the vector-memory counter when the loop is entered: the compiler's wait
     // for the first pass's mean segment would otherwise sit in the loop body, behind the row store.
     __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0)
@@ -444,20 +479,22 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
         const Seg nn = load_seg(row2);
         const uint64_t row3 = cinfo[3].row_bytes;
         const float s_next = cinfo[1].s;
-        const uint32_t c_lo_next = cinfo[1].cell_lo, c_hi_next = cinfo[1].cell_hi, posbase_next = cinfo[1].pos_base;
+        const uint32_t posbase_next = cinfo[1].pos_base;
+        const uint32_t ph_next[4] = {cinfo[1].ph[0], cinfo[1].ph[1], cinfo[1].ph[2], cinfo[1].ph[3]};
         ++cinfo;
         __builtin_amdgcn_sched_barrier(0);
-        const prnb::Words W = prnb::philox_count<2>(c_lo, c_hi, (uint32_t)g0 >> 2, 0u, k0, k1);
+        const prnb::Words W = philox_count_row(ph, quad_hi, quad_lo, k0, k1);
         uint32_t s1_at = s1_lds + ((uint32_t)s1_top << 4);     // LDS byte address of the stack's top (wave-uniform)
+        // P(X=0) = exp(-m*log1p(theta)/theta) >= exp(-x) >= 1 - x + x^2/2 - x^3/6, x = m * phi
+        // (prnb::zero_test_factor).  The polynomial is evaluated times 2^32 with 1e-5 taken off
+        // the constant term: far more than every rounding of the exact evaluation, so a sample
+        // settled here is one the exact path would also call 0 (and a sample with theta <= 0 is
+        // 0 by definition); it is negative from x = 1.6 on, which keeps every sample of the
+        // gamma-Poisson class out.
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float m = M[j] * s;
-            // P(X=0) = exp(-m*log1p(theta)/theta) >= exp(-x) >= 1 - x + x^2/2 - x^3/6, x = m * phi
-            // (prnb::zero_test_factor).  The polynomial is evaluated times 2^32 with 1e-5 taken off
-            // the constant term: far more than every rounding of the exact evaluation, so a sample
-            // settled here is one the exact path would also call 0 (and a sample with theta <= 0 is
-            // 0 by definition); it is negative from x = 1.6 on, which keeps every sample of the
-            // gamma-Poisson class out.
+            // (packed binary32 instructions for two bounds at a time were tried: fewer instructions, 2 % slower)
             const float x = m * phi[j];
             const float bound32 = PRNB_FMA(PRNB_FMA(PRNB_FMA(-715827882.7f, x, 2147483648.0f), x, -4294967296.0f),
                                            x, 4294924346.0f);
@@ -487,8 +524,7 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
         nxt = nn;
         row2 = row3;
         s = s_next;
-        c_lo = c_lo_next;
-        c_hi = c_hi_next;
+        ph[0] = ph_next[0]; ph[1] = ph_next[1]; ph[2] = ph_next[2]; ph[3] = ph_next[3];
         posbase = posbase_next;
     }
 

@@ -130,7 +130,7 @@ __global__ void prep_kernel(const double* __restrict__ scaling, int64_t N,
                             float* __restrict__ bm1_f, float* __restrict__ phi_f,
                             const int32_t* __restrict__ row_of_cell, int64_t rows, uint64_t cell_offset,
                             const int64_t* __restrict__ cell_index, int32_t strip_cells,
-                            k3::CellInfo* __restrict__ info, int64_t* __restrict__ flags)
+                            uint32_t k0, uint32_t k1, k3::CellInfo* __restrict__ info, int64_t* __restrict__ flags)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (flags && i < 4) flags[i] = 0;      // [0] domain flag, [1] row index outside the tensor, [2] full-test request, [3] list overflow
@@ -150,10 +150,8 @@ __global__ void prep_kernel(const double* __restrict__ scaling, int64_t N,
         const int64_t row = row_of_cell[n] < 0 ? 0 : (row_of_cell[n] >= rows ? rows - 1 : row_of_cell[n]);
         c.row_bytes = (uint64_t)row * (uint64_t)G * 4u;
         c.s = (float)scaling[n];
-        c.cell_lo = (uint32_t)cell;
-        c.cell_hi = (uint32_t)(cell >> 32);
         c.pos_base = (uint32_t)(n % strip_cells) << 8;
-        c.pad1 = c.pad2 = 0u;
+        k3::philox_cell_part((uint32_t)cell, (uint32_t)(cell >> 32), k0, k1, c.ph);
         info[i] = c;
     }
 }
@@ -503,7 +501,7 @@ static StreamGeometry stream_geometry(int64_t N, int32_t G, int64_t rows)
 static int sampler_setup(prosstt_amd_ctx* c, Staging& st, const float* means, int64_t rows, int32_t G,
                          const int32_t* row_of_cell, const double* scaling, const double* alpha,
                          const double* beta, int64_t N, uint32_t flags, SamplerArgs* A,
-                         const StreamGeometry* geo, uint64_t cell_offset, const int64_t* cell_index)
+                         const StreamGeometry* geo, uint64_t cell_offset, const int64_t* cell_index, uint64_t seed)
 {
     if (!c) return fail(PROSSTT_AMD_EINVAL, "ctx is NULL");
     if (N < 0 || G < 0 || rows < 0) return fail(PROSSTT_AMD_EINVAL, "negative size");
@@ -553,7 +551,7 @@ static int sampler_setup(prosstt_amd_ctx* c, Staging& st, const float* means, in
     const int64_t span = (N + 4 > G ? N + 4 : G);
     prep_kernel<<<dim3((unsigned)((span + 255) / 256)), dim3(256), 0, c->stream>>>(
         scaling, N, alpha, beta, G, A->scal, A->ga, A->gbm1, A->gphi, row_of_cell, rows, cell_offset, cell_index,
-        geo ? (int32_t)geo->strip_cells : 1, info, geo ? c->scratch : nullptr);
+        geo ? (int32_t)geo->strip_cells : 1, (uint32_t)seed, (uint32_t)(seed >> 32), info, geo ? c->scratch : nullptr);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -578,7 +576,7 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
     const StreamGeometry geo = stream_geometry(N, G, rows);
     if (geo.groups * geo.tiles_g > 0x1fffffffll) return fail(PROSSTT_AMD_EINVAL, "too many tiles; chunk the cells");
     int rc = sampler_setup(c, st, means, rows, G, row_of_cell, scaling, alpha, beta, N, flags, &A, &geo, cell_offset,
-                           cell_index);
+                           cell_index, seed);
     if (rc) return rc;
     if (N == 0 || G == 0) return 0;
     k3::HeavyList heavy;
@@ -696,7 +694,7 @@ PA_EXPORT int prosstt_amd_nb_params(prosstt_amd_ctx* c, const float* means, int6
 {
     Staging st;
     SamplerArgs A{};
-    int rc = sampler_setup(c, st, means, rows, G, row_of_cell, scaling, alpha, beta, N, flags, &A, nullptr, 0, nullptr);
+    int rc = sampler_setup(c, st, means, rows, G, row_of_cell, scaling, alpha, beta, N, flags, &A, nullptr, 0, nullptr, 0);
     if (rc) return rc;
     if (N == 0 || G == 0) return 0;
     const size_t bytes = (size_t)N * G * 4;
