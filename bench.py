@@ -260,7 +260,10 @@ def run_case(job, config, scaling, cells_per_gpu, steps, warmup, strict_steps, g
         per_gpu = cells_per_gpu or work.cfg["N"]
         n_total = per_gpu * world
     pt, br, sc, rows = work.plan(n_total)
-    mine, owner = parallel.shard_cells(br, rank, world)
+    if tree._branch_owner is not None:      # the lineage was built sharded: a cell is sampled where its branch's rows are
+        mine = parallel.cells_of_rank(br, tree._branch_owner, rank)
+    else:
+        mine, _ = parallel.shard_cells(br, rank, world)
 
     means = tree.device_means()
     d_rows = ctx.tensor(rows[mine], torch.int32)
@@ -285,7 +288,7 @@ def run_case(job, config, scaling, cells_per_gpu, steps, warmup, strict_steps, g
     kms = job.max_over_ranks(ctx.last_kernel_ms())      # mean over the K launches of the timed region
     res = dict(work=work, plan=(pt, br, sc), G=G, n_total=n_total, per_gpu=per_gpu, cells_on_rank=int(len(mine)),
                ms_per_step=elapsed / steps * 1e3, value=n_total * G / (elapsed / steps), kernel_ms=kms,
-               rows_total=work.info["rows"], ms_strict=None, gather_ms=None)
+               rows_total=work.info["resident_rows"], ms_strict=None, gather_ms=None)
 
     # the product API's default: with the domain check of the reference's scipy call
     if strict_steps > 0:

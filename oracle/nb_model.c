@@ -422,6 +422,65 @@ PRNB_EXPORT PRNB_CLONES void prnb_nb_params(const float* means, int64_t rows, in
 }
 
 /*
+ * For tests of the device's give-up protocol: how close the EXACT walk of
+ * selected samples comes to a decision that the hardware-math evaluation of the streaming kernel could get
+ * wrong.  Per sample i (cell n = cells[i] of the call's arrays, gene genes[i]):
+ *   out_path[i]   0 degenerate / 1 inversion / 2 gamma-Poisson          out_count[i]  the count
+ *   out_t2[i]     -log2 P(X = 0) in the exact arithmetic (inversion class; else 0)
+ *   out_close[i]  min over the evaluated terms of |remainder| / margin, with the device's margins
+ *                 margin0 + t2 * margin_per_t2 + margin_per_term * (2 for k = 0..2, 6 for k = 3..6, 10 for 7..10, ...)
+ *   out_tail[i]   min over the groups' last terms of |term - 1|  (the end-of-pmf test)
+ * (binary32 throughout, the walk exactly as chop_down does it).
+ */
+PRNB_EXPORT PRNB_CLONES void prnb_walk_detail(const float* means, int64_t rows, int32_t G, const int32_t* row_of_cell,
+                                              const double* scaling, const double* alpha, const double* beta,
+                                              uint64_t seed, uint64_t cell_offset, const int64_t* cell_index,
+                                              const int64_t* cells, const int32_t* genes, int64_t count,
+                                              float margin0, float margin_per_t2, float margin_per_term,
+                                              int32_t* out_path, int32_t* out_count, float* out_t2,
+                                              float* out_close, float* out_tail)
+{
+    (void)rows;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < count; ++i) {
+        const int64_t n = cells[i];
+        const int32_t g = genes[i];
+        const uint64_t cell = cell_index ? (uint64_t)cell_index[n] : cell_offset + (uint64_t)n;
+        prnb_detail d;
+        out_count[i] = prnb_one(means[(int64_t)row_of_cell[n] * G + g], (float)scaling[n], GENE_A(alpha, g), GENE_BM1(beta, g),
+                                k0, k1, cell, (uint32_t)g, &d);
+        out_path[i] = d.path;
+        out_t2[i] = 0.0f; out_close[i] = INFINITY; out_tail[i] = INFINITY;
+        if (d.path != 1) continue;
+        /* the exact walk once more, watching the remainders (prnb_one's arithmetic, chop_down's loop) */
+        float theta = fminf(fmaxf(d.theta, PRNB_THETA_MIN), PRNB_THETA_MAX);
+        float u1 = 1.0f + theta, dd = det_rcp(theta * u1);
+        float inv_th = dd * u1, inv_u1 = dd * theta, q = theta * inv_u1, mp = d.m * inv_u1;
+        float t = d.m * (det_log1p(theta) * inv_th);
+        float t2 = t * 1.44269504f;
+        uint32_t w[4];
+        philox_count((uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)g >> 2, 0u, k0, k1, w);
+        float ps = fminf(det_exp(-t), 0.99999994f) * 4294967296.0f, num = mp, rem = (float)w[g & 3];
+        float closest = INFINITY, tail = INFINITY;
+        for (int k = 0; ; ) {
+            const float margin = margin0 + t2 * margin_per_t2 + margin_per_term * (k < 3 ? 2.0f : (float)(4 * ((k - 3) / 4) + 6));
+            rem = rem - ps;
+            closest = fminf(closest, fabsf(rem) / margin);
+            if (rem < 0.0f) break;
+            if ((k & 3) == 2) {
+                tail = fminf(tail, fabsf(ps - 1.0f));
+                if (ps < 1.0f) break;
+            }
+            ps = (ps * num) * g_inv_k[k + 1];
+            ++k;
+            num = ((k & 3) == 3) ? FMA((float)k, q, mp) : num + q;
+        }
+        out_t2[i] = t2; out_close[i] = closest; out_tail[i] = tail;
+    }
+}
+
+/*
  * Device-mode expression programs ("PRLW-1"): the walk of simulation.diffusion
  * (/root/reference/prosstt/simulation.py:89-124) with counter-based variates instead of numpy's
  * stream.  Program k of walk stream `sid` draws from Philox4x32-10 with key

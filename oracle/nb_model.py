@@ -38,6 +38,11 @@ def lib():
                                          ctypes.c_void_p, _i32p, ctypes.c_int64]
         L.prnb_nb_params.argtypes = [_f32p, ctypes.c_int64, ctypes.c_int32, _i32p, _f64p, _f64p, _f64p,
                                      ctypes.c_int64, _f32p, _f32p, _f32p, _i32p]
+        _i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+        L.prnb_walk_detail.argtypes = [_f32p, ctypes.c_int64, ctypes.c_int32, _i32p, _f64p, _f64p, _f64p, ctypes.c_uint64,
+                                       ctypes.c_uint64, ctypes.c_void_p, _i64p, _i32p, ctypes.c_int64, ctypes.c_float,
+                                       ctypes.c_float, ctypes.c_float, _i32p, _i32p, _f32p, _f32p, _f32p]
+        L.prnb_walk_detail.restype = None
         L.prnb_sample_iid.argtypes = [ctypes.c_float, ctypes.c_double, ctypes.c_double, ctypes.c_uint64,
                                       ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int64, _i32p]
         L.prnb_lineage_walk.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, _f64p]
@@ -88,6 +93,27 @@ def sample_counts(means, row_of_cell, scaling, alpha, beta, seed, cell_offset=0,
                              np.ascontiguousarray(beta, np.float64), N, seed, cell_offset,
                              cell_index.ctypes.data if cell_index is not None else None, out, G)
     return out
+
+
+def walk_detail(means, row_of_cell, scaling, alpha, beta, seed, cells, genes, margins, cell_offset=0, cell_index=None):
+    """(path, count, t2, close, tail) of selected samples: how close the exact walk comes to a decision the
+    device's hardware-math evaluation could get wrong (see prnb_walk_detail).  margins = the device's
+    (margin0, margin per unit of t2, margin per term), in units of 2^-32."""
+    means = np.ascontiguousarray(means, np.float32)
+    rows, G = means.shape
+    cells = np.ascontiguousarray(cells, np.int64)
+    genes = np.ascontiguousarray(genes, np.int32)
+    n = cells.size
+    path, count = np.empty(n, np.int32), np.empty(n, np.int32)
+    t2, close, tail = np.empty(n, np.float32), np.empty(n, np.float32), np.empty(n, np.float32)
+    if cell_index is not None:
+        cell_index = np.ascontiguousarray(cell_index, np.int64)
+    lib().prnb_walk_detail(means, rows, G, np.ascontiguousarray(row_of_cell, np.int32),
+                           np.ascontiguousarray(scaling, np.float64), np.ascontiguousarray(alpha, np.float64),
+                           np.ascontiguousarray(beta, np.float64), seed, cell_offset,
+                           cell_index.ctypes.data if cell_index is not None else None, cells, genes, n,
+                           margins[0], margins[1], margins[2], path, count, t2, close, tail)
+    return path, count, t2, close, tail
 
 
 def nb_params(means, row_of_cell, scaling, alpha, beta):

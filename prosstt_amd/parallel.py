@@ -6,9 +6,11 @@ The reference is single-process (no collective anywhere),
 layer is new.  The path shards naturally (SURVEY section 8 e): given the mean tensor, cells
 are independent.  Every rank
 
-  1. holds the same tree (the lineage stage is deterministic under the same numpy seed;
-     its data -- programs, coefficients, 4*sum(T)*G bytes of means -- is small next to
-     288 GB of HBM, so it is replicated rather than exchanged),
+  1. builds the tree together with the others (``simulate_lineage_sharded``): the host draws are the
+     same on every rank (same numpy seed), a batch of candidate programs is evaluated on a SLICE OF
+     THE GENES per rank with one all-reduce of the few scalars that decide acceptance, and the
+     accepted branch is materialised only by the rank that owns it -- or, with the single-process
+     ``simulation.simulate_lineage``, holds a replica of the whole tree,
   2. receives the same sampling plan (rank 0's plan is broadcast),
   3. owns a disjoint set of branches (greedy balance of cells per branch) and samples only
      the cells on them, keyed by their position in the GLOBAL plan (``cell_index``), so the
@@ -67,6 +69,95 @@ def _comm_device(group=None):
     if _dist().get_backend(group) == "nccl":
         return torch.device("cuda", torch.cuda.current_device())
     return torch.device("cpu")
+
+
+def assign_branches_by_density(tree, world_size):
+    """owner[label] -> rank before any cell exists: longest-processing-time greedy on the density mass
+    of the branches (cells are drawn from it; ties by position in ``tree.branches``)."""
+    mass = [float(np.sum(tree.density[b])) for b in tree.branches]
+    order = sorted(range(len(tree.branches)), key=lambda i: (-mass[i], i))
+    load = [0.0] * world_size
+    owner = {}
+    for i in order:
+        r = min(range(world_size), key=lambda k: (load[k], k))
+        owner[tree.branches[i]] = r
+        load[r] += mass[i]
+    return owner
+
+
+def simulate_lineage_sharded(tree, rel_exp_cutoff=8, intra_branch_tol=0.5, inter_branch_tol=0, *, group=None,
+                             max_attempts=None, stats=None, batch=16, **kwargs):
+    """``simulation.simulate_lineage`` (simulation.py:215-286) by the ranks of ``group`` together.
+
+    Every rank makes the same host draws (seed numpy identically); a batch of attempts is evaluated on the
+    rank's slice of the genes (``lineage_attempt``: the maximum and the per-sibling counts of
+    anticorrelated genes are a max and sums over genes) and ONE small all-reduce per batch -- B maxima, B x
+    siblings counts -- makes every rank take the same decision; the accepted branch is committed only by
+    the rank that owns it (``assign_branches_by_density``), which is also the rank that will sample its
+    cells.  No rank ever holds the relative means or the mean tensor of the whole tree.
+
+    Returns ``(rel_means, programs, coefficients)`` like the reference; ``rel_means`` holds this rank's
+    branches only (``tree.resident_branches()``).  ``simulate_base_gene_exp`` and ``Tree.add_genes`` then
+    work on the resident rows (the per-gene maximum over the whole tree has been all-reduced), and
+    ``sample_density_sharded`` samples every cell on the rank that holds its branch."""
+    import torch
+    dist = _dist()
+    rank, size = world(group)
+    if size == 1:
+        return sim.simulate_lineage(tree, rel_exp_cutoff, intra_branch_tol, inter_branch_tol,
+                                    max_attempts=max_attempts, stats=stats, batch=batch, **kwargs)
+    if not len(tree.time) == tree.num_branches:
+        raise ValueError("the parameters are not enough for %i branches" % tree.num_branches)
+    ctx = _device.get_context()
+    dev = _comm_device(group)
+    coefficients = sim.simulate_coefficients(tree, **kwargs)              # same draws on every rank
+    G = tree.G
+    lo, hi = rank * G // size, (rank + 1) * G // size                      # this rank's genes
+    H = ctx.tensor(coefficients, torch.float64)                            # K x G: commits need every gene
+    H_slice = ctx.tensor(np.ascontiguousarray(coefficients[:, lo:hi]), torch.float64) if hi > lo else None
+    owner = assign_branches_by_density(tree, size)
+    tree._branch_owner = owner
+    tree._resident = [b for b in tree.branches if owner[b] == rank]
+    offsets, rows = tree.row_offsets()
+    rel = torch.empty((rows, G), dtype=torch.float64, device=ctx.torch_device)
+    gene_max = torch.full((G,), -np.inf, dtype=torch.float64, device=ctx.torch_device)
+
+    def evaluate(candidates, sibling_programs):
+        B, n_sib = len(candidates), len(sibling_programs)
+        if H_slice is not None:
+            tops, counts = ctx.lineage_attempt_batch(candidates, H_slice, sibling_programs)
+        else:                                                             # more ranks than genes
+            tops, counts = np.full(B, -np.inf), np.zeros((B, n_sib), np.int64)
+        t_top = torch.as_tensor(np.ascontiguousarray(tops, dtype=np.float64)).to(dev)
+        dist.all_reduce(t_top, op=dist.ReduceOp.MAX, group=group)
+        if n_sib:
+            t_cnt = torch.as_tensor(np.ascontiguousarray(counts, dtype=np.int64)).to(dev)
+            dist.all_reduce(t_cnt, op=dist.ReduceOp.SUM, group=group)
+            counts = t_cnt.cpu().numpy()
+        return t_top.cpu().numpy(), counts
+
+    def commit(key, accepted):
+        if owner[key] == rank:
+            at = offsets[key]
+            ctx.lineage_commit(accepted, H, rel[at:at + int(tree.time[key])], gene_max)
+
+    programs = sim._lineage_loop(tree, ctx, evaluate, commit, rel_exp_cutoff, intra_branch_tol, inter_branch_tol,
+                                 max_attempts, stats, "numpy", None, batch)
+    # the per-gene maximum over the WHOLE tree (simulate_base_gene_exp needs it; G doubles)
+    g_all = gene_max.to(dev)
+    dist.all_reduce(g_all, op=dist.ReduceOp.MAX, group=group)
+    gene_max = g_all.to(ctx.torch_device)
+    return sim._finish_lineage(tree, rel, gene_max, H, programs, offsets, coefficients)
+
+
+def cells_of_rank(branch_of_cell, owner, rank):
+    """Global indices (ascending) of the cells whose branch ``owner`` gives to ``rank``."""
+    labels = np.asarray(branch_of_cell)
+    mine = np.zeros(len(labels), dtype=bool)
+    for label, r in owner.items():
+        if r == rank:
+            mine |= labels == label
+    return np.nonzero(mine)[0].astype(np.int64)
 
 
 def broadcast_plan(plan, group=None, src=0):
@@ -163,11 +254,15 @@ def sample_density_sharded(tree, no_cells, alpha=0.3, beta=2, scale=True, scale_
         lo, hi = np.random.randint(0, 2 ** 32, size=2, dtype=np.uint64)
         seed = int(lo) | (int(hi) << 32)
     pt, br, sc, seed = broadcast_plan((pt, br, sc, seed), group)
-    mine, _ = shard_cells(br, rank, size)
     alpha = np.full(tree.G, alpha, np.float64) if np.ndim(alpha) == 0 else np.asarray(alpha, np.float64)
     beta = np.full(tree.G, beta, np.float64) if np.ndim(beta) == 0 else np.asarray(beta, np.float64)
-    if strict:
-        assert_replicas_agree(tree, alpha, beta, group)
+    if tree._branch_owner is not None and size > 1:
+        # the tree was built sharded: a cell is sampled where its branch's rows are
+        mine = cells_of_rank(br, tree._branch_owner, rank)
+    else:
+        mine, _ = shard_cells(br, rank, size)
+        if strict:
+            assert_replicas_agree(tree, alpha, beta, group)
     ctx = _device.get_context()
     rows = sim.cell_rows(tree, pt[mine], br[mine])
     counts = ctx.sample_counts(tree.device_means(), rows, sc[mine], alpha, beta, seed=seed, cell_index=mine,

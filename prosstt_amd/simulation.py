@@ -121,16 +121,17 @@ def _sim_coeff_gamma(tree, a=0.05):
 # ----------------------------------------------------------------------------------
 
 def _stack_rows(tree, per_branch):
-    return np.concatenate([np.asarray(per_branch[b], dtype=np.float64) for b in tree.branches], axis=0)
+    return np.concatenate([np.asarray(per_branch[b], dtype=np.float64) for b in tree.resident_branches()], axis=0)
 
 
 def _lineage_cache(tree, relative_means):
     """The device tensors simulate_lineage left behind, if ``relative_means`` are the very arrays it
     returned AND their contents are untouched (fingerprint); else None -- the caller uploads."""
     cache = tree._lineage
-    if cache is None or not all(relative_means[b] is cache["host"][b] for b in tree.branches):
+    held = tree.resident_branches()
+    if cache is None or not all(b in relative_means and relative_means[b] is cache["host"][b] for b in held):
         return None
-    if _device.host_fingerprint([cache["host"][b] for b in tree.branches]) != cache["print"]:
+    if _device.host_fingerprint([cache["host"][b] for b in held]) != cache["print"]:
         return None
     return cache
 
@@ -184,17 +185,43 @@ def simulate_lineage(tree, rel_exp_cutoff=8, intra_branch_tol=0.5, inter_branch_
     if not len(tree.time) == tree.num_branches:
         raise ValueError("the parameters are not enough for %i branches" % tree.num_branches)
     ctx = _device.get_context()
-    topology = np.array(tree.topology)
+    tree._resident = tree._branch_owner = None       # this process builds and keeps the whole tree
     coefficients = simulate_coefficients(tree, **kwargs)
     H = ctx.tensor(coefficients, torch.float64)
     offsets, rows = tree.row_offsets()
     rel = torch.empty((rows, tree.G), dtype=torch.float64, device=ctx.torch_device)
     gene_max = torch.full((tree.G,), -np.inf, dtype=torch.float64, device=ctx.torch_device)
+
+    def evaluate(candidates, sibling_programs):
+        return ctx.lineage_attempt_batch(candidates, H, sibling_programs)
+
+    def commit(key, accepted):
+        at = offsets[key]
+        ctx.lineage_commit(accepted, H, rel[at:at + int(tree.time[key])], gene_max)
+
+    programs = _lineage_loop(tree, ctx, evaluate, commit, rel_exp_cutoff, intra_branch_tol, inter_branch_tol,
+                             max_attempts, stats, rng, seed, batch)
+    return _finish_lineage(tree, rel, gene_max, H, programs, offsets, coefficients)
+
+
+def _lineage_loop(tree, ctx, evaluate, commit, rel_exp_cutoff, intra_branch_tol, inter_branch_tol,
+                  max_attempts, stats, rng, seed, batch):
+    """The accept/reject loop of simulate_lineage (simulation.py:264-282) over the branches in breadth-first
+    order.  ``evaluate(candidates (B, T, K), sibling programs) -> (max per attempt, anticorrelated-gene counts per
+    attempt and sibling)`` and ``commit(branch, programs)`` are the device side: one process evaluates whole
+    genes, ``parallel.simulate_lineage_sharded`` a gene slice per rank with an all-reduce of the few scalars."""
+    if batch < 1:
+        raise ValueError("batch must be at least 1")
+    if max_attempts is not None and max_attempts < 1:
+        raise ValueError("max_attempts must be at least 1")
     if rng not in ("numpy", "device"):
         raise ValueError("rng must be 'numpy' or 'device'")
     if rng == "device" and seed is None:
         lo, hi = random.randint(0, 2 ** 32, size=2, dtype=np.uint64)
         seed = int(lo) | (int(hi) << 32)
+    if rng == "device" and tree.modules < 2:
+        raise ValueError("at least 2 expression programs are needed")
+    topology = np.array(tree.topology)
     programs = {}
     for ordinal, branch in enumerate(sut.breadth_first_branches(tree)):
         steps, tries, accepted = int(tree.time[branch]), 0, None
@@ -204,24 +231,33 @@ def simulate_lineage(tree, rel_exp_cutoff=8, intra_branch_tol=0.5, inter_branch_
             # (one sim_expr_branch per attempt); all of them go through ONE lineage_attempt launch.  The
             # first acceptable one is taken and numpy's generator is put back to where the sequential
             # loop would have left it, just behind that attempt's draws -- same numbers, same stream
-            # position, one device round trip per batch instead of per attempt.
-            width = min(batch, 4 if tries == 0 else batch)           # most branches are accepted early
+            # position, one device round trip per batch instead of per attempt.  (Device-mode walks do not
+            # touch numpy's stream, and the first attempt is usually accepted: one walk first, batches after.)
+            first = 1 if rng == "device" else 4
+            width = min(batch, first if tries == 0 else batch)           # most branches are accepted early
             if max_attempts is not None:
                 width = min(width, max_attempts - tries)
             candidates, states = [], []
-            for i in range(width):
-                if rng == "device":
-                    if tree.modules < 2:
-                        raise ValueError("at least 2 expression programs are needed")
-                    programs[branch] = ctx.lineage_walk(seed, (ordinal << 32) | (tries + i), steps, int(tree.modules))
-                else:
-                    programs[branch] = sim_expr_branch(steps, tree.modules, cutoff=intra_branch_tol)
-                    states.append(random.get_state())
-                candidates.append(sut.adjust_to_parent(programs, branch, topology))
-            if siblings is None:
-                siblings = [b for b in sut.find_parallel(tree, programs, branch)
-                            if b is not None and b != branch]
-            tops, counts = ctx.lineage_attempt_batch(np.stack(candidates), H, [programs[s] for s in siblings])
+            entry_state = random.get_state() if rng == "numpy" else None
+            try:
+                for i in range(width):
+                    if rng == "device":
+                        programs[branch] = ctx.lineage_walk(seed, (ordinal << 32) | (tries + i), steps, int(tree.modules))
+                    else:
+                        programs[branch] = sim_expr_branch(steps, tree.modules, cutoff=intra_branch_tol)
+                        states.append(random.get_state())
+                    candidates.append(sut.adjust_to_parent(programs, branch, topology))
+                if siblings is None:
+                    siblings = [b for b in sut.find_parallel(tree, programs, branch)
+                                if b is not None and b != branch]
+                tops, counts = evaluate(np.stack(candidates), [programs[s] for s in siblings])
+            except BaseException:
+                # the stream goes back to where the batch found it: a failed call must not leave numpy
+                # advanced past the position of the sequential loop
+                if entry_state is not None:
+                    random.set_state(entry_state)
+                programs.pop(branch, None)
+                raise
             for i in range(width):
                 tries += 1
                 if stats is not None:
@@ -238,18 +274,24 @@ def simulate_lineage(tree, rel_exp_cutoff=8, intra_branch_tol=0.5, inter_branch_
                                    "(rel_exp_cutoff=%r, inter_branch_tol=%r)"
                                    % (branch, tries, rel_exp_cutoff, inter_branch_tol))
         programs[branch] = accepted
-        key = _plain_label(tree, branch)
-        at = offsets[key]
-        ctx.lineage_commit(programs[branch], H, rel[at:at + int(tree.time[key])], gene_max)
+        commit(_plain_label(tree, branch), accepted)
+    return programs
+
+
+def _finish_lineage(tree, rel, gene_max, H, programs, offsets, coefficients):
+    """Host copies of the resident branches' relative means, the device cache, the reference's return value."""
     host = rel.cpu().numpy()
     # the device keeps `rel` for simulate_base_gene_exp / add_genes, which recognise these arrays by
     # identity and fingerprint: writable like the reference's; edited arrays are uploaded afresh
-    rel_means = {b: host[offsets[b]:offsets[b] + int(tree.time[b])] for b in tree.branches}
+    held = tree.resident_branches()
+    rel_means = {b: host[offsets[b]:offsets[b] + int(tree.time[b])] for b in held}
     tree._lineage = dict(rel=rel, gene_max=gene_max, host=rel_means, H=H,
-                         print=_device.host_fingerprint([rel_means[b] for b in tree.branches]))
+                         print=_device.host_fingerprint([rel_means[b] for b in held]))
     ordered = {}
     for branch in programs:                      # keep the reference's insertion (BFS) order
-        ordered[branch] = rel_means[_plain_label(tree, branch)]
+        key = _plain_label(tree, branch)
+        if key in rel_means:
+            ordered[branch] = rel_means[key]
     return pd.Series(ordered), pd.Series(programs), coefficients
 
 
@@ -359,6 +401,9 @@ def cell_rows(tree, pseudotime, branches):
     length = np.empty(len(uniques), dtype=np.int64)
     for i, label in enumerate(uniques):
         key = _plain_label(tree, label)
+        if key not in offsets:
+            raise ValueError("branch %r is not resident on this process (the tree is sharded: "
+                             "sample the cells of a branch on the rank that owns it)" % (key,))
         start[i], base[i], length[i] = bt[key][0], offsets[key], int(tree.time[key])
     inside = np.asarray(pseudotime, dtype=np.int64) - start[codes]
     if len(inside) and (inside.min() < 0 or np.any(inside >= length[codes])):

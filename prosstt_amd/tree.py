@@ -39,6 +39,8 @@ class Tree(object):
         self._dev_means = None         # torch float32 (sum T_b, G), or None
         self._dev_print = None         # fingerprint of _host_means when _dev_means was made from / mirrored to it
         self._lineage = None           # device cache left by simulate_lineage
+        self._resident = None          # branches whose rows this process holds (None: all; see parallel.simulate_lineage_sharded)
+        self._branch_owner = None      # branch -> rank when the tree is sharded over processes
         if modules is None:
             # consumes one draw of the global stream, as tree.py:67-68 does
             self.modules = 5 * branch_points + np.random.randint(1, 20)
@@ -134,10 +136,16 @@ class Tree(object):
         self.density = tu._density_from_velocity(velocity)
 
     # ---- the mean tensor -----------------------------------------------------------
+    def resident_branches(self):
+        """Branches whose rows of the mean tensor this process holds, in ``tree.branches`` order: all of
+        them, unless the lineage was built sharded over the ranks of a process group
+        (``parallel.simulate_lineage_sharded``: every rank keeps the branches it owns)."""
+        return list(self.branches) if self._resident is None else list(self._resident)
+
     def row_offsets(self):
-        """Row of the first time step of every branch inside the device tensor."""
+        """Row of the first time step of every resident branch inside the device tensor."""
         offsets, at = {}, 0
-        for b in self.branches:
+        for b in self.resident_branches():
             offsets[b] = at
             at += int(self.time[b])
         return offsets, at
@@ -152,7 +160,7 @@ class Tree(object):
         if self._host_means is None and self._dev_means is not None:
             host = self._dev_means.cpu().numpy().astype(np.float64)
             offsets, _ = self.row_offsets()
-            self._host_means = {b: host[offsets[b]:offsets[b] + int(self.time[b])] for b in self.branches}
+            self._host_means = {b: host[offsets[b]:offsets[b] + int(self.time[b])] for b in self.resident_branches()}
             self._dev_print = self._means_fingerprint()
         return self._host_means
 
@@ -161,10 +169,12 @@ class Tree(object):
         self._host_means = value
         self._dev_means = None
         self._dev_print = None
+        self._resident = None          # a dict of means covers the whole tree
+        self._branch_owner = None
 
     def _means_fingerprint(self):
         return _device.host_fingerprint([self._host_means.get(b) if hasattr(self._host_means, "get")
-                                         else self._host_means[b] for b in self.branches])
+                                         else self._host_means[b] for b in self.resident_branches()])
 
     def device_means(self):
         """(sum T_b, G) float32 device tensor.  When the host dict exists (the caller assigned it,
@@ -177,7 +187,7 @@ class Tree(object):
                 ctx = _device.get_context()
                 import torch
                 stacked = np.concatenate([np.asarray(self._host_means[b], dtype=np.float64)
-                                          for b in self.branches], axis=0)
+                                          for b in self.resident_branches()], axis=0)
                 as32 = stacked.astype(np.float32)
                 tiny = np.float32(1.17549435e-38)      # positive means stay positive in binary32 (see means_from_rel)
                 as32[(stacked > 0) & (as32 < tiny)] = tiny
@@ -199,10 +209,10 @@ class Tree(object):
         import torch
         from . import simulation as sim
         ctx = _device.get_context()
-        if len(relative_means) != self.num_branches:
+        if len(relative_means) != len(self.resident_branches()):
             raise ValueError("The number of arrays in average_expression must be equal to the "
                              "number of branches in the topology")
-        for b in self.branches:
+        for b in self.resident_branches():
             shape = np.shape(relative_means[b])
             if shape != (self.time[b], self.G):
                 raise ValueError("Branch %s was expected to have a shape %s and instead is %s"

@@ -57,7 +57,8 @@ class Workload:
         self.name, self.cfg, self.tree, self.alpha, self.beta, self.info = name, cfg, tree, alpha, beta, info
 
     def plan(self, n_cells=None):
-        """(pseudotime, branch labels, scalings, rows) of ``n_cells`` cells (default: the config's N)."""
+        """(pseudotime, branch labels, scalings, rows) of ``n_cells`` cells (default: the config's N).
+        On a tree that is sharded over processes, ``rows`` is -1 for cells of branches held elsewhere."""
         n_cells = self.cfg["N"] if n_cells is None else n_cells
         np.random.seed(self.cfg["seed"] + 1)
         if self.name == "C1":
@@ -66,11 +67,19 @@ class Workload:
         else:
             pt, br = sim._density_plan(self.tree, n_cells)
         sc = sut.calc_scalings(len(pt))
-        return pt, br, sc, sim.cell_rows(self.tree, pt, br)
+        if self.tree._branch_owner is None:
+            return pt, br, sc, sim.cell_rows(self.tree, pt, br)
+        held = np.isin(br, np.asarray(self.tree.resident_branches()))
+        rows = np.full(len(pt), -1, dtype=np.int32)
+        rows[held] = sim.cell_rows(self.tree, pt[held], br[held])
+        return pt, br, sc, rows
 
 
-def build(name, *, a=0.05, rel_exp_cutoff=8, max_attempts=20000, G=None, verbose=False):
-    """Tree with lineage, base expression and mean tensor on the device, plus (alpha, beta)."""
+def build(name, *, a=0.05, rel_exp_cutoff=8, max_attempts=20000, G=None, verbose=False, group=None, sharded=None):
+    """Tree with lineage, base expression and mean tensor on the device, plus (alpha, beta).
+    Under an initialised process group of more than one rank the lineage is built sharded
+    (``parallel.simulate_lineage_sharded``: gene slices for the attempts, every rank keeps the branches it
+    owns) unless ``sharded=False``."""
     cfg = dict(CONFIGS[name])
     if G is not None:
         cfg["G"] = G
@@ -80,8 +89,15 @@ def build(name, *, a=0.05, rel_exp_cutoff=8, max_attempts=20000, G=None, verbose
                 branch_points=len({p for p, _ in topology}), modules=cfg["K"], G=cfg["G"])
     stats = []
     t0 = _time.perf_counter()
-    rel, _, _ = sim.simulate_lineage(tree, a=a, intra_branch_tol=0, inter_branch_tol=0,
-                                     rel_exp_cutoff=rel_exp_cutoff, max_attempts=max_attempts, stats=stats)
+    from . import parallel
+    if sharded is None:
+        sharded = parallel.world(group)[1] > 1
+    if sharded:
+        rel, _, _ = parallel.simulate_lineage_sharded(tree, rel_exp_cutoff, 0, 0, group=group, a=a,
+                                                      max_attempts=max_attempts, stats=stats)
+    else:
+        rel, _, _ = sim.simulate_lineage(tree, a=a, intra_branch_tol=0, inter_branch_tol=0,
+                                         rel_exp_cutoff=rel_exp_cutoff, max_attempts=max_attempts, stats=stats)
     t1 = _time.perf_counter()
     base = sut.simulate_base_gene_exp(tree, rel)
     tree.add_genes(rel, base)
@@ -90,7 +106,8 @@ def build(name, *, a=0.05, rel_exp_cutoff=8, max_attempts=20000, G=None, verbose
     alpha = np.exp(np.random.normal(np.log(0.2), np.log(1.5), cfg["G"]))      # generate_simN.py:94-95
     beta = np.exp(np.random.normal(np.log(1), np.log(1.5), cfg["G"])) + 1
     info = dict(branches=len(labels), rows=int(sum(tree.time.values)), attempts=len(stats),
-                lineage_s=t1 - t0, base_and_means_s=t2 - t1)
+                lineage_s=t1 - t0, base_and_means_s=t2 - t1, sharded=bool(sharded),
+                resident_rows=int(tree.row_offsets()[1]))
     if verbose:
         print("[workload %s] %s" % (name, info))
     return Workload(name, cfg, tree, alpha, beta, info)

@@ -1,8 +1,9 @@
 """
 -m gpu: the N > 1 path with the REAL kernel.  Two fresh child processes (gloo backend, both on
 cuda:0 -- the test box has one GPU; the children are started before anything in them touches the GPU)
-build the same tree, run parallel.sample_density_sharded and parallel.gather_rows; rank 0 compares the
-gathered matrix with the single-process result of the same plan and seed.  The plan travels by tensor
+build the tree together (parallel.simulate_lineage_sharded: attempts on gene slices, one all-reduce per batch,
+every rank keeps the branches it owns), run parallel.sample_density_sharded and parallel.gather_rows; rank 0
+compares the gathered matrix with the single-process result (whole tree, same plan and seed).  The plan travels by tensor
 broadcasts (the ranks are seeded differently on purpose: rank 0's plan must win).
 """
 import os
@@ -28,8 +29,11 @@ torch.cuda.set_device(0)
 from prosstt_amd import device, parallel, simulation as sim, sim_utils as sut, workloads
 from prosstt_amd.tree import Tree
 
-work = workloads.build("C2", G=1536)            # same numpy seed on both ranks: identical trees (lineage on the device)
+work = workloads.build("C2", G=1536)            # under the process group: the lineage is built sharded (gene slices, owned branches)
 tree = work.tree
+assert work.info["sharded"] and tree._branch_owner is not None
+held = tree.resident_branches()
+assert 0 < len(held) < len(tree.branches) and tree.device_means().shape[0] == sum(int(tree.time[b]) for b in held)
 N = 2500
 np.random.seed(1000 + rank)                      # the ranks' own streams differ: the plan must be rank 0's
 counts, mine, pt, br, sc = parallel.sample_density_sharded(tree, N, alpha=work.alpha, beta=work.beta, seed=11)
@@ -44,7 +48,14 @@ if rank == 0:
     sc0 = sut.calc_scalings(N)
     assert np.array_equal(pt, pt0) and np.array_equal(br, br0) and np.array_equal(sc, sc0)
     ctx = device.get_context()
-    want = ctx.sample_counts(tree.device_means(), sim.cell_rows(tree, pt, br), sc, work.alpha, work.beta, seed=11)
+    whole = workloads.build("C2", G=1536, sharded=False).tree     # the single-process tree: every branch, same draws
+    assert whole.resident_branches() == list(whole.branches)
+    at, _ = whole.row_offsets()
+    mine_at, _ = tree.row_offsets()
+    for b in held:                                                 # the owned rows are the single-process rows
+        assert torch.equal(tree.device_means()[mine_at[b]:mine_at[b] + int(tree.time[b])],
+                           whole.device_means()[at[b]:at[b] + int(whole.time[b])])
+    want = ctx.sample_counts(whole.device_means(), sim.cell_rows(whole, pt, br), sc, work.alpha, work.beta, seed=11)
     assert torch.equal(full, want), "gathered shards differ from the single-process matrix"
     assert int(want.sum()) > 0
     print("TWO_RANKS_OK", sizes, int(want.sum()), flush=True)

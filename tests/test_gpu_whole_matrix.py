@@ -89,3 +89,60 @@ def test_c5_full_size_eight_shards_on_one_gpu():
     assert seen == N
     print("[C5] %d x %d: 8 shards == chunked pass; lineage attempts %d in %.2f s; sum(X)/sum(mu) = %.5f"
           % (N, G, work.info["attempts"], work.info["lineage_s"], total / mu_sum))
+
+
+def test_the_give_up_path_is_live_and_every_listed_sample_has_a_reason():
+    """Stages 2 and 3 of the streaming kernel evaluate P(X = 0) with the hardware's log/rcp/exp and leave a
+    sample to the second kernel when the exact arithmetic could decide otherwise.
+    On C3: the list of the last launch is read back (prosstt_amd_last_list) and every entry must have a
+    reason in the EXACT arithmetic of the model: the gamma-Poisson class, a class the approximate t cannot
+    decide, a count above 255, a remainder within (a generous multiple of) the margin of zero, or an
+    end-of-pmf term near 1.  The margins themselves must be doing work (near-threshold walks > 0), the list
+    must stay far below its capacity, and -- the other direction -- samples that are NOT listed and come
+    close to a threshold in the exact arithmetic must be rare and still drawn right (the whole-matrix
+    tests above compare every count)."""
+    import torch
+    from prosstt_amd import device, workloads
+    from oracle import nb_model
+    ctx = device.get_context()
+    work = workloads.build("C3")
+    N = 50000
+    pt, br, sc, rows = work.plan(N)
+    means = work.tree.device_means()
+    X = ctx.sample_counts(means, rows, sc, work.alpha, work.beta, seed=424242)
+    cells, genes, total, overflowed = ctx.last_list()
+    assert not overflowed and total == len(cells)
+    assert 2e5 < total < 0.01 * N * work.tree.G            # ~1.5e6 of 1e9 samples
+    margins = (4096.0, 8192.0, 2048.0)                    # k3_stream.h: kMargin0, kMarginPerT2, kMarginPerTerm
+    path, count, t2, close, tail = nb_model.walk_detail(means.cpu().numpy(), rows, sc, work.alpha, work.beta, 424242,
+                                                        cells, genes, margins)
+    # what the second kernel wrote for them is the model's count
+    got = X[torch.as_tensor(cells, device=X.device), torch.as_tensor(genes.astype(np.int64), device=X.device)].cpu().numpy()
+    np.testing.assert_array_equal(got, count)
+    heavy = path == 2
+    big = (path == 1) & (count > 255)
+    t2_sure = 27.41120 * (1.0 - 1.53e-5)
+    undecided = (path == 1) & (t2 >= t2_sure * (1 - 3e-6))            # the approximate t2 may differ by 1e-6 relative
+    near = (path == 1) & (close < 1.5)                                # device remainder within its margin => exact one within 1.5 margins
+    tailband = (path == 1) & (tail < 2 * 9.765625e-4)
+    explained = heavy | big | undecided | near | tailband
+    assert path.min() >= 1                                            # degenerate samples are never listed
+    assert explained.all(), "%d listed samples without a reason" % int((~explained).sum())
+    assert heavy.sum() > 1e5 and near.sum() > 1e4                     # both classes of entries occur
+    print("[list] %d entries: gamma-Poisson %d, near a threshold %d, undecidable class %d, above 255: %d, tail band %d"
+          % (total, heavy.sum(), (near & ~heavy).sum(), undecided.sum(), big.sum(), tailband.sum()))
+    # the other direction, on a block of cells: exact walks that come within a THIRD of the margin of a threshold
+    # (where the two evaluations may really disagree) must all have been listed
+    blk = np.arange(2000, 2300)
+    bc = np.repeat(blk, work.tree.G).astype(np.int64)
+    bg = np.tile(np.arange(work.tree.G, dtype=np.int32), len(blk))
+    bpath, bcount, bt2, bclose, btail = nb_model.walk_detail(means.cpu().numpy(), rows, sc, work.alpha, work.beta, 424242,
+                                                             bc, bg, margins)
+    risky = (bpath == 1) & (bclose < 1.0 / 3.0) & (bt2 < t2_sure)
+    listed = set(zip(cells[(cells >= 2000) & (cells < 2300)].tolist(), genes[(cells >= 2000) & (cells < 2300)].tolist()))
+    # a walk ends at its first negative remainder: only thresholds up to there count, which is what `close` tracks
+    missing = [(int(c), int(g)) for c, g in zip(bc[risky], bg[risky]) if (int(c), int(g)) not in listed]
+    stage1_zero = [cg for cg in missing if bcount[(bc == cg[0]) & (bg == cg[1])][0] == 0]
+    # (a sample settled as 0 by stage 1's bound never reaches the margin test: its uniform is below the bound,
+    # hence more than 1e-5 * 2^32 below the first threshold -- it cannot be `risky`)
+    assert not missing, "%d risky samples were not listed (%d of them zeros)" % (len(missing), len(stage1_zero))

@@ -223,3 +223,115 @@ def test_plan_broadcast_and_gather_inside_a_subgroup(tmp_path):
     port = _free_port()
     mp.spawn(_worker_subgroup, args=(3, port, str(tmp_path)), nprocs=3, join=True)
     assert all(os.path.exists(tmp_path / ("ok%d" % r)) for r in range(3))
+
+
+class _FakeLineageContext(_FakeContext):
+    """numpy stand-ins for the lineage kernels (K2a attempt: max of programs@H and per-sibling counts of
+    genes with negative Pearson r over the common steps; K2b commit; gene_max; means_from_rel), on whatever
+    gene range H covers -- which is all the sharded lineage needs from the device."""
+
+    def lineage_attempt_batch(self, programs, H, sib_programs=()):
+        Hn = H.numpy()
+        tops = np.array([np.max(p @ Hn) for p in programs])
+        counts = np.zeros((len(programs), len(sib_programs)), np.int64)
+        for b, p in enumerate(programs):
+            for j, s in enumerate(sib_programs):
+                c = min(len(p), len(s))
+                x, y = p[:c] @ Hn, np.asarray(s)[:c] @ Hn
+                cov = ((x - x.mean(axis=0)) * (y - y.mean(axis=0))).sum(axis=0)
+                counts[b, j] = int((cov < 0).sum())
+        return tops, counts
+
+    def lineage_commit(self, programs, H, rel_out=None, gene_max=None):
+        import torch
+        rel = torch.as_tensor(np.asarray(programs) @ H.numpy())
+        rel_out.copy_(rel)
+        torch.maximum(gene_max, rel.max(dim=0).values, out=gene_max)
+
+    def gene_max(self, rel, gmax):
+        import torch
+        return torch.maximum(gmax, rel.max(dim=0).values, out=gmax) if rel.shape[0] else gmax
+
+    def means_from_rel(self, rel, base, out=None):
+        import torch
+        return (torch.exp(rel) * base[None, :]).to(torch.float32)
+
+
+def _lineage_case():
+    from prosstt_amd.tree import Tree
+    return Tree(topology=[["A", "B"], ["A", "C"], ["C", "D"], ["C", "E"], ["B", "F"]],
+                time={"A": 12, "B": 9, "C": 14, "D": 7, "E": 10, "F": 8}, num_branches=6, branch_points=2, modules=4, G=37)
+
+
+def _worker_lineage(rank, world_size, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    from prosstt_amd import device, parallel, simulation as sim, sim_utils as sut
+    fake = _FakeLineageContext()
+    device.get_context = lambda *a, **k: fake
+    try:
+        # the single-process lineage (every rank computes it for itself as the yardstick)
+        np.random.seed(31)
+        ref_tree = _lineage_case()
+        ref_stats = []
+        ref_rel, ref_prog, ref_H = sim.simulate_lineage(ref_tree, a=0.3, intra_branch_tol=0, inter_branch_tol=0.25,
+                                                        rel_exp_cutoff=6, stats=ref_stats)
+        ref_after = np.random.random()
+        ref_base = None
+        np.random.seed(32)
+        ref_base = sut.simulate_base_gene_exp(ref_tree, ref_rel)
+        ref_tree.add_genes(ref_rel, ref_base)
+        # the same by all ranks together
+        np.random.seed(31)
+        t = _lineage_case()
+        stats = []
+        rel, prog, H = parallel.simulate_lineage_sharded(t, 6, 0, 0.25, a=0.3, stats=stats)
+        assert np.random.random() == ref_after                        # numpy's stream: same position as the single process
+        assert np.array_equal(H, ref_H) and list(prog.keys()) == list(ref_prog.keys())
+        assert all(np.array_equal(prog[b], ref_prog[b]) for b in prog.keys())
+        assert len(stats) == len(ref_stats) > len(t.branches)         # some attempts were rejected, the same ones
+        for (b0, top0, c0), (b1, top1, c1) in zip(stats, ref_stats):
+            assert b0 == b1 and c0 == c1 and abs(top0 - top1) <= 1e-12 * max(1.0, abs(top1))
+        owner = parallel.assign_branches_by_density(t, world_size)
+        held = [b for b in t.branches if owner[b] == rank]
+        assert t.resident_branches() == held and sorted(rel.keys()) == sorted(held)
+        assert t._lineage["rel"].shape[0] == sum(t.time[b] for b in held)           # nobody holds the whole tree
+        for b in held:
+            np.testing.assert_allclose(rel[b], ref_rel[b], rtol=1e-13, atol=1e-13)
+        np.random.seed(32)
+        base = sut.simulate_base_gene_exp(t, rel)                     # the all-reduced per-gene maximum
+        np.testing.assert_array_equal(base, ref_base)
+        t.add_genes(rel, base)
+        assert sorted(t.means.keys()) == sorted(held)
+        for b in held:
+            np.testing.assert_allclose(t.means[b], ref_tree.means[b], rtol=1e-6)
+        # sampling on the sharded tree: every cell on the rank that holds its branch, gathered in plan order
+        np.random.seed(33)
+        counts, mine, pt, br, sc = parallel.sample_density_sharded(t, 150, seed=9)
+        assert all(owner[str(b)] == rank for b in br[mine])
+        full = parallel.gather_rows(counts, mine, 150)
+        if rank == 0:
+            want = (torch.arange(150)[:, None] * 1000 + torch.arange(t.G)[None, :] + 9 % 7).to(torch.int32)
+            assert torch.equal(full, want)
+        sizes = [None] * world_size
+        dist.all_gather_object(sizes, (len(held), len(mine)))
+        assert sum(s[0] for s in sizes) == len(t.branches) and sum(s[1] for s in sizes) == 150
+        dist.barrier()
+        open(os.path.join(tmpdir, "ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world_size", [2, 3])
+def test_lineage_sharded_by_genes_equals_the_single_process_lineage(tmp_path, world_size):
+    """parallel.simulate_lineage_sharded on 2 and 3 gloo ranks: programs, attempt records (maxima, anticorrelated
+    counts), numpy stream position, base expression and the owned rows equal the single-process run; no rank
+    holds more than its own branches."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker_lineage, args=(world_size, port, str(tmp_path)), nprocs=world_size, join=True)
+    assert all(os.path.exists(tmp_path / ("ok%d" % r)) for r in range(world_size))
