@@ -18,10 +18,13 @@ namespace k3 {
 constexpr int kHeavyBlock = 256;
 constexpr int kHCap = 128;     // < 64 left over + 64 pushed (new entries, or re-pushed ones after 64 were popped)
 
-struct HGEntry { int32_t n, g, attempt, row; };   // row = row_of_cell[n], looked up once per ticket
+// Stack entries carry the scaled mean m = M[row, g] * s of their sample (looked up once, when the list
+// entry is read), so that a pass depends on one level of loads (the per-gene parameters), not on a chain
+// row -> mean.
+struct HGEntry { int32_t n, g, attempt; float m; };
 struct HPEntry { int32_t n, g; float lam; int32_t attempt; };
 
-struct HLEntry { int32_t n, g, row; };             // an inversion walk to redo
+struct HLEntry { int32_t n, g; float m; };         // an inversion walk to redo
 
 struct HeavyLds {
     HGEntry hg[kHCap];
@@ -125,12 +128,11 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
         const int cnt = hg_top < 64 ? hg_top : 64;
         bool again = false, accepted = false;
         HGEntry e;
-        e.n = 0; e.g = 0; e.attempt = 0; e.row = 0;
+        e.n = 0; e.g = 0; e.attempt = 0; e.m = 0.0f;
         float lam = 0.0f;
         if (lane < cnt) {
             e = L.hg[hg_top - 1 - lane];
-            const prnb::Params P = prnb::make_params(means[(int64_t)e.row * G + e.g], scal[e.n],
-                                                     ga[e.g], gbm1[e.g]);
+            const prnb::Params P = prnb::make_params_m(e.m, ga[e.g], gbm1[e.g]);
             const float r = P.m * P.inv_th;
             // (a flagged sample is valid: m > 0, theta > 0); r under 2^-40 is a count of 0 (P(X > 0) < 2^-32)
             if (P.valid && r >= prnb::kRMin) {
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
         const int cnt = hl_top < 64 ? hl_top : 64;
         if (lane < cnt) {
             const HLEntry e = L.hl[hl_top - 1 - lane];
-            const prnb::Params P = prnb::make_params(means[(int64_t)e.row * G + e.g], scal[e.n], ga[e.g], gbm1[e.g]);
+            const prnb::Params P = prnb::make_params_m(e.m, ga[e.g], gbm1[e.g]);
             const uint64_t cell = cell_id(e.n);
             const prnb::Words w = prnb::philox_count((uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)e.g >> 2, 0u, k0, k1);
             const int32_t x = prnb::light_draw(P, w.w[e.g & 3], inv_k);
@@ -209,25 +211,26 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
     // ---- 64 list entries per wave and step, sorted onto the gamma stack and the redo stack ---------
     auto feed = [&](bool has, int32_t n, int32_t g) {
         bool heavy = false, light = false;
-        int32_t row = 0;
+        float m = 0.0f;
         if (has) {
-            row = row_of_cell[n];
-            row = row < 0 ? 0 : (row >= rows ? (int32_t)(rows - 1) : row);     // as cellinfo_kernel: never a wild read
+            int32_t row = row_of_cell[n];
+            row = row < 0 ? 0 : (row >= rows ? (int32_t)(rows - 1) : row);     // as the preparation kernel: never a wild read
             const prnb::Params P = prnb::make_params(means[(int64_t)row * G + g], scal[n], ga[g], gbm1[g]);
+            m = P.m;
             light = P.valid && P.light;
             heavy = P.valid && !P.light;
         }
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(heavy);
+        const unsigned long long mh = __builtin_amdgcn_ballot_w64(heavy);
         if (heavy) {
             HGEntry e;
-            e.n = n; e.g = g; e.attempt = 0; e.row = row;
-            L.hg[hg_top + lane_rank(m)] = e;
+            e.n = n; e.g = g; e.attempt = 0; e.m = m;
+            L.hg[hg_top + lane_rank(mh)] = e;
         }
-        hg_top += __popcll(m);
+        hg_top += __popcll(mh);
         const unsigned long long ml = __builtin_amdgcn_ballot_w64(light);
         if (light) {
             HLEntry e;
-            e.n = n; e.g = g; e.row = row;
+            e.n = n; e.g = g; e.m = m;
             L.hl[hl_top + lane_rank(ml)] = e;
         }
         hl_top += __popcll(ml);
@@ -244,13 +247,16 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
         const int sub = lane >> 4, sl = lane & 15;
         for (int64_t r0 = wave_id * 4; r0 < (int64_t)regions; r0 += waves * 4) {
             const int64_t r = r0 + sub;
-            const uint32_t cnt = r < (int64_t)regions ? heavy.count[r] : 0u;
+            const bool in = r < (int64_t)regions;
+            // the first 16 entries are read beside the count, not behind it (a region's words exist whatever it holds)
+            const uint32_t cnt = in ? heavy.count[r] : 0u;
+            uint32_t p = in ? heavy.list[(uint64_t)r * heavy.cap + (uint32_t)sl] : 0u;
             const int32_t blk = (int32_t)(r >> 2);
             const int32_t tile_g = blk / groups;
             const int64_t n0 = (int64_t)((blk - tile_g * groups) * 4 + (int32_t)(r & 3)) * strip_cells;
             for (uint32_t i0 = 0u; __builtin_amdgcn_ballot_w64(i0 < cnt) != 0ull; i0 += 16u) {
                 const bool has = i0 + (uint32_t)sl < cnt;
-                const uint32_t p = has ? heavy.list[(uint64_t)r * heavy.cap + i0 + (uint32_t)sl] : 0u;
+                if (i0 != 0u) p = has ? heavy.list[(uint64_t)r * heavy.cap + i0 + (uint32_t)sl] : 0u;
                 feed(has, (int32_t)(n0 + (p >> 8)), tile_g * kTileG + (int32_t)(p & 255u));
             }
         }

@@ -124,6 +124,7 @@ struct S2Entry { float ps, mp, q, rem; };             // pmf (x 2^32) at k = 3 a
 // -- it is a bound, and the model knows nothing of it) with pos in the 16 bits that frees
 
 struct WaveLds {
+    S1Entry s1_null;               // m = 0: what a lane of stage 2 reads when the stack holds fewer than 64 entries
     S1Entry s1[kS1Cap];
     S2Entry s2[kS2Cap];
     uint32_t s2m[kS2Cap];
@@ -134,6 +135,8 @@ struct WaveLds {
 // The list of samples left to K3h: wave w of block b owns region r = 4*b + w, entries
 // list[r * cap .. + count[r]) = pos (cell-in-strip << 8 | gene-in-tile); overflow[0] != 0 once a
 // region was too small (more than one sample in 16 listed) -- K3h then redoes every sample itself.
+static_assert(offsetof(WaveLds, s1) == offsetof(WaveLds, s1_null) + sizeof(S1Entry), "s1[-1] must be the null entry");
+
 struct HeavyList { uint32_t* count; uint32_t* list; uint32_t* overflow; uint32_t cap; };
 
 __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
@@ -207,6 +210,7 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
     // pos of the last sample whose row has already left the ring (wave-uniform; -1: none)
     int32_t flushed_pos = -1;
     for (int i = lane; i < kRing * 64; i += 64) reinterpret_cast<uint32_t*>(L.ring)[i] = 0u;
+    if (lane < 4) reinterpret_cast<uint32_t*>(&L.s1_null)[lane] = 0u;
 
     // store row `cl` of the strip from ring slot cl % kRing and clear the slot
     auto flush_row = [&](int cl, int32_t* row_ptr) {
@@ -249,23 +253,6 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
 #define K3_MASK(x) __builtin_amdgcn_ballot_w64(x)
     const uint32_t ring_lds = (uint32_t)(uintptr_t)&L.ring[0];
     const uint32_t late_lds = (uint32_t)(uintptr_t)&L.late[0];
-    // Every lane of the wave calls this; the lanes of `ok_m` deliver count `res` (1..255) of sample `p`:
-    // into the row ring while the row is still there, else (rare) onto the late list.
-    auto deliver = [&](unsigned long long ok_m, uint32_t p, uint32_t res) {
-        const unsigned long long late_m = K3_MASK((int32_t)p <= flushed_pos);
-        // slot = cell % kRing, gene-in-tile
-        asm volatile("s_mov_b64 exec, %0\n\tds_write_b8 %1, %2\n\ts_mov_b64 exec, -1"
-                     :: "s"(ok_m & ~late_m), "v"(ring_lds + (p & (uint32_t)(kRing * 256 - 1))), "v"(res) : "memory");
-        const unsigned long long ml = ok_m & late_m;
-        if (ml != 0ull) {
-            const int cnt = __popcll(ml);
-            if (late_top + cnt > kLateCap) flush_late();
-            asm volatile("s_mov_b64 exec, %0\n\tds_write_b32 %1, %2\n\ts_mov_b64 exec, -1"
-                         :: "s"(ml), "v"(late_lds + (uint32_t)((late_top + lane_rank(ml)) << 2)), "v"((p << 16) | res) : "memory");
-            late_top += cnt;
-        }
-    };
-
     // write the samples the lanes hold for K3h to this wave's region of the list (about ten entries
     // each time on the headline workload: the first lane to meet its second sample triggers it)
     uint32_t* const my_list = heavy.list + (uint64_t)region * heavy.cap;
@@ -279,11 +266,28 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
         h_cnt += (uint32_t)__popcll(mp_);
         hpend = kNoHeavy;
     };
-    // every lane of the wave calls this; the lanes of `mine_m` leave sample `p` to K3h
-    auto list_sample = [&](unsigned long long mine_m, uint32_t p) {
-        if (mine_m != 0ull) {
-            if ((mine_m & K3_MASK(hpend != kNoHeavy)) != 0ull) flush_heavy();
-            asm volatile("s_mov_b64 exec, %1\n\tv_mov_b32 %0, %2\n\ts_mov_b64 exec, -1" : "+v"(hpend) : "s"(mine_m), "v"(p));
+    // Every lane of the wave calls this at the end of a stage-2 or stage-3 pass.  The lanes of `ok_m`
+    // deliver count `res` (1..255) of sample `p`: into the row ring while the row is still there, else
+    // (rare) onto the late list; the lanes of `give_m` (rare as well) leave sample `p` to K3h.  One test
+    // covers both rare paths.
+    auto deliver = [&](unsigned long long ok_m, unsigned long long give_m, uint32_t p, uint32_t res) {
+        const unsigned long long late_m = K3_MASK((int32_t)p <= flushed_pos);
+        // slot = cell % kRing, gene-in-tile
+        asm volatile("s_mov_b64 exec, %0\n\tds_write_b8 %1, %2\n\ts_mov_b64 exec, -1"
+                     :: "s"(ok_m & ~late_m), "v"(ring_lds + (p & (uint32_t)(kRing * 256 - 1))), "v"(res) : "memory");
+        const unsigned long long ml = ok_m & late_m;
+        if ((ml | give_m) != 0ull) {
+            if (ml != 0ull) {
+                const int cnt = __popcll(ml);
+                if (late_top + cnt > kLateCap) flush_late();
+                asm volatile("s_mov_b64 exec, %0\n\tds_write_b32 %1, %2\n\ts_mov_b64 exec, -1"
+                             :: "s"(ml), "v"(late_lds + (uint32_t)((late_top + lane_rank(ml)) << 2)), "v"((p << 16) | res) : "memory");
+                late_top += cnt;
+            }
+            if (give_m != 0ull) {
+                if ((give_m & K3_MASK(hpend != kNoHeavy)) != 0ull) flush_heavy();
+                asm volatile("s_mov_b64 exec, %1\n\tv_mov_b32 %0, %2\n\ts_mov_b64 exec, -1" : "+v"(hpend) : "s"(give_m), "v"(p));
+            }
         }
     };
     // ---- stage 3: four pmf steps for every busy lane; idle lanes pull from S2 ------------------
@@ -341,8 +345,7 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
         const unsigned long long big_m = K3_MASK(res_k > 255);         // does not fit the ring's 8 bits (1 in 10^4): K3h's as well
         const unsigned long long done_m = hit_m | tail_m | close_m;    // (idle lanes: their ps3 = 0 is under 1)
         const unsigned long long give_m = (close_m | (big_m & (hit_m | tail_m))) & busy_m;
-        deliver(done_m & busy_m & ~close_m & ~big_m, pos, (uint32_t)res_k);
-        list_sample(give_m, pos);
+        deliver(done_m & busy_m & ~close_m & ~big_m, give_m, pos, (uint32_t)res_k);
         rem = r4;
         const float ps4 = (ps3 * num3) * inv.w;
         kf = kf + 4.0f;
@@ -362,15 +365,14 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
     const uint32_t s2_lds = (uint32_t)(uintptr_t)&L.s2[0];
     const uint32_t s2m_lds = (uint32_t)(uintptr_t)&L.s2m[0];
     auto stage2_pass = [&]() {
-        // Straight-line for every lane (a lane beyond the entries reads the stack's bottom entry and is
-        // masked out): every wave-level test below is a lane mask formed outside divergent control flow.
+        // Straight-line for every lane (a lane beyond the entries reads a null entry, which is invalid):
+        // every wave-level test below is a lane mask formed outside divergent control flow.
         const int cnt = s1_top < 64 ? s1_top : 64;
         const int at = s1_top - 1 - lane;
-        const S1Entry e = L.s1[at > 0 ? at : 0];
+        const S1Entry e = (&L.s1[0])[at >= 0 ? at : -1];      // s1[-1] is s1_null: invalid, so no mask of the lanes that hold an entry
         const uint32_t p2 = e.pos;
-        const unsigned long long in_m = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);     // the lanes that hold an entry
         // (m <= 0 or theta <= 0: the count is 0 by definition; stage 1 does not test that)
-        const unsigned long long valid_m = in_m & K3_MASK(e.m > 0.0f) & K3_MASK(e.theta > 0.0f);
+        const unsigned long long valid_m = K3_MASK(e.m > 0.0f) & K3_MASK(e.theta > 0.0f);
         float theta, thetaq;                          // (plain v_max_f32: the builtin puts a canonicalising copy in front)
         asm("v_max_f32 %0, 0x21800000, %1" : "=v"(theta) : "v"(e.theta));      // prnb::kThetaMin = 2^-60
         asm("v_max_f32 %0, 0x34000000, %1" : "=v"(thetaq) : "v"(e.theta));     // 2^-23
@@ -404,8 +406,7 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
         const uint32_t res = 3u - (nneg > 1u ? nneg : 1u);
         const unsigned long long walk_m = valid_m & light_m & ~close_m;       // decided by this kernel
         const unsigned long long nz_m = K3_MASK(res != 0u);
-        deliver(walk_m & (hit_m | tail_m) & nz_m, p2, res);
-        list_sample(valid_m & ~walk_m, p2);
+        deliver(walk_m & (hit_m | tail_m) & nz_m, valid_m & ~walk_m, p2, res);
         s1_top -= cnt;
         const unsigned long long push_m = walk_m & ~(hit_m | tail_m);
         {

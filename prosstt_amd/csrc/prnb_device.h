@@ -356,10 +356,17 @@ __device__ __forceinline__ float zero_test_factor(float a, float bm1)
     return phi;
 }
 
+__device__ __forceinline__ Params make_params_m(float m, float a, float bm1);
 __device__ __forceinline__ Params make_params(float M, float s, float a, float bm1)
 {
+    return make_params_m(M * s, a, bm1);
+}
+
+// the same from the scaled mean m = M * s
+__device__ __forceinline__ Params make_params_m(float m, float a, float bm1)
+{
     Params P;
-    P.m = M * s;
+    P.m = m;
     float theta = PRNB_FMA(a, P.m, bm1);
     P.valid = (P.m > 0.0f) && (theta > 0.0f);
     theta = __builtin_fminf(__builtin_fmaxf(theta, kThetaMin), kThetaMax);

@@ -54,6 +54,9 @@ VARIANTS = {
     # K3h without the redo walks / without the gamma-Poisson samples
     "k3h_noredo": [("            light = P.valid && P.light;\n", "            light = false;\n")],
     "k3h_noheavy": [("            heavy = P.valid && !P.light;\n", "            heavy = false;\n")],
+    "k3h_grid1024": [("k3::sample_counts_heavy_kernel<<<dim3(2048),", "k3::sample_counts_heavy_kernel<<<dim3(1024),")],
+    "k3h_grid1536": [("k3::sample_counts_heavy_kernel<<<dim3(2048),", "k3::sample_counts_heavy_kernel<<<dim3(1536),")],
+    "k3h_grid3072": [("k3::sample_counts_heavy_kernel<<<dim3(2048),", "k3::sample_counts_heavy_kernel<<<dim3(3072),")],
     "k3h_none": [("            light = P.valid && P.light;\n", "            light = false;\n"), ("            heavy = P.valid && !P.light;\n", "            heavy = false;\n")],
     # the library default of 10 Philox rounds instead of 7 (timing only: the model is not changed along)
     "philox10": [("constexpr int kCountRounds = 7;", "constexpr int kCountRounds = 10;")],

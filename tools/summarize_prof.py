@@ -19,6 +19,7 @@ for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recur
 for f in glob.glob(os.path.join(root, "*.json")):
     print("== %s ==" % os.path.basename(f))
     print(open(f).read().strip()[:2000])
+allc = {}
 for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
     if not os.path.isdir(d):
         continue
@@ -32,3 +33,24 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
                 continue
             for c, xs in sorted(v.items()):
                 print("  %-40s %-26s %.6g  (n=%d)" % (k, c, sum(xs) / len(xs), len(xs)))
+                if "stream_kernel" in k:
+                    allc[c] = sum(xs) / len(xs)
+
+# ---- derived, stream kernel: the SQ's wave-cycle budget and the issue rate ----
+need = ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_SALU",
+        "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_BRANCH", "GRBM_GUI_ACTIVE")
+if all(c in allc for c in need):
+    w = allc["SQ_WAVE_CYCLES"]
+    parts = allc["SQ_WAIT_ANY"] + allc["SQ_WAIT_INST_ANY"] + allc["SQ_ACTIVE_INST_ANY"]
+    print("== derived: k3::sample_counts_stream_kernel (per launch) ==")
+    print("  wave cycles (quads) %.4g = waiting at s_waitcnt %.1f %% + waiting for issue %.1f %% + executing %.1f %% (sum %.1f %%)"
+          % (w, 100 * allc["SQ_WAIT_ANY"] / w, 100 * allc["SQ_WAIT_INST_ANY"] / w, 100 * allc["SQ_ACTIVE_INST_ANY"] / w, 100 * parts / w))
+    instr = sum(allc[c] for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD",
+                                  "SQ_INSTS_VMEM_WR", "SQ_INSTS_BRANCH"))
+    cycles = allc["GRBM_GUI_ACTIVE"] / 8.0          # the counter sums the 8 XCDs
+    simds = 1024.0
+    print("  wave-level instructions %.4g (vector %.4g, scalar %.4g, LDS %.4g, branch %.4g, memory %.4g): %.1f per sample-quad, "
+          "%.3g per SIMD in %.4g cycles = %.2f cycles per instruction per SIMD"
+          % (instr, allc["SQ_INSTS_VALU"], allc["SQ_INSTS_SALU"], allc["SQ_INSTS_LDS"], allc["SQ_INSTS_BRANCH"],
+             allc["SQ_INSTS_SMEM"] + allc["SQ_INSTS_VMEM_RD"] + allc["SQ_INSTS_VMEM_WR"],
+             instr * 64 / 1e9 / 4 * 4, instr / simds, cycles, cycles / (instr / simds)))
