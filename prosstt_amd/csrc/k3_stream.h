@@ -76,6 +76,7 @@ constexpr float kMarginPerT2 = 8192.0f;      // 2^-19 per unit of t2 = t / ln 2 
 constexpr float kMarginPerTerm = 2048.0f;    // 2^-21 per term                   (worst case 1.2e-7 = 515 units, + 256)
 constexpr float kTailBand = 9.765625e-4f;    // a group's last term within 2^-10 of 1: the end-of-pmf test is K3h's
 constexpr float kT2Sure = 27.41120f * (1.0f - 1.53e-5f);   // 19 / ln 2, less 2^-16: surely t <= 19
+constexpr int kBail = 6;           // walks left to K3h when a strip has nothing else to do (see the drain)
 constexpr int kLateCap = 128;      // results that missed their row wait here for one burst of stores (< 64 left + 64)
 
 // What stage 1 needs to know about a cell, packed by the preparation kernel so that one scalar load
@@ -534,7 +535,21 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
         stage2_pass();
         while (s2_top >= kS2Run) stage3_pass();
     }
-    while (s2_top > 0 || __builtin_amdgcn_ballot_w64(k != kIdle) != 0ull) stage3_pass();
+    // The last walks of a strip would run with a handful of busy lanes (13 % of the lanes over a quarter of a
+    // pass per cell on the headline workload): once nothing waits on S2 and at most kBail lanes still walk,
+    // their samples go on K3h's list instead, which redoes them from the start.
+    for (;;) {
+        const unsigned long long busy_m = __builtin_amdgcn_ballot_w64(k != kIdle);
+        if (s2_top == 0) {
+            if (busy_m == 0ull) break;
+            if (__popcll(busy_m) <= kBail) {
+                if ((busy_m & __builtin_amdgcn_ballot_w64(hpend != kNoHeavy)) != 0ull) flush_heavy();
+                if (k != kIdle) hpend = pos;
+                break;
+            }
+        }
+        stage3_pass();
+    }
     for (int cl = (cells > kRing ? cells - kRing : 0); cl < cells; ++cl) flush_row(cl, strip_out + (int64_t)cl * ld);
     flush_late();
     if (__builtin_amdgcn_ballot_w64(hpend != kNoHeavy) != 0ull) flush_heavy();

@@ -96,8 +96,8 @@ def test_the_give_up_path_is_live_and_every_listed_sample_has_a_reason():
     sample to the second kernel when the exact arithmetic could decide otherwise.
     On C3: the list of the last launch is read back (prosstt_amd_last_list) and every entry must have a
     reason in the EXACT arithmetic of the model: the gamma-Poisson class, a class the approximate t cannot
-    decide, a count above 255, a remainder within (a generous multiple of) the margin of zero, or an
-    end-of-pmf term near 1.  The margins themselves must be doing work (near-threshold walks > 0), the list
+    decide, a count above 255, a remainder within (a generous multiple of) the margin of zero, an
+    end-of-pmf term near 1, or a walk still running when its strip was otherwise done (a few per wave).  The margins themselves must be doing work (near-threshold walks > 0), the list
     must stay far below its capacity, and -- the other direction -- samples that are NOT listed and come
     close to a threshold in the exact arithmetic must be rare and still drawn right (the whole-matrix
     tests above compare every count)."""
@@ -127,10 +127,16 @@ def test_the_give_up_path_is_live_and_every_listed_sample_has_a_reason():
     tailband = (path == 1) & (tail < 2 * 9.765625e-4)
     explained = heavy | big | undecided | near | tailband
     assert path.min() >= 1                                            # degenerate samples are never listed
-    assert explained.all(), "%d listed samples without a reason" % int((~explained).sum())
+    # what is left: walks that were still running when their strip had nothing else to do (at most k3::kBail = 6
+    # per wave; they entered stage 3, so the count is at least 3)
+    leftover = ~explained
+    waves = -(-N // 64) * -(-work.tree.G // 256)
+    assert leftover.sum() <= 6 * waves and (count[leftover] >= 3).all(), \
+        "%d listed samples without a reason" % int((leftover & (count < 3)).sum())
     assert heavy.sum() > 1e5 and near.sum() > 1e4                     # both classes of entries occur
-    print("[list] %d entries: gamma-Poisson %d, near a threshold %d, undecidable class %d, above 255: %d, tail band %d"
-          % (total, heavy.sum(), (near & ~heavy).sum(), undecided.sum(), big.sum(), tailband.sum()))
+    print("[list] %d entries: gamma-Poisson %d, near a threshold %d, undecidable class %d, above 255: %d, tail band %d, "
+          "unfinished at the end of their strip %d"
+          % (total, heavy.sum(), (near & ~heavy).sum(), undecided.sum(), big.sum(), tailband.sum(), leftover.sum()))
     # the other direction, on a block of cells: exact walks that come within a THIRD of the margin of a threshold
     # (where the two evaluations may really disagree) must all have been listed
     blk = np.arange(2000, 2300)
