@@ -25,8 +25,8 @@ RUN_23 = """        while (s1_top >= 64) {
         }
         cur = nxt;"""
 
-PHILOX_OFF = ("        const prnb::Words W = prnb::philox4x32_10<2>(c_lo, c_hi, (uint32_t)g0 >> 2, 0u, k0, k1);",
-              "        prnb::Words W; W.w[0] = (c_lo * 2654435761u) ^ ((uint32_t)g0 * 40503u); W.w[1] = W.w[0] * 3u + k0;\n"
+PHILOX_OFF = ("        const prnb::Words W = philox_count_row(ph, quad_hi, quad_lo, k0, k1);",
+              "        prnb::Words W; W.w[0] = (ph[0] * 2654435761u) ^ ((uint32_t)g0 * 40503u); W.w[1] = W.w[0] * 3u + k0;\n"
               "        W.w[2] = W.w[1] ^ 0x9E3779B9u; W.w[3] = W.w[2] + W.w[0];")
 STORE_OFF = ("        if (g0 < G) {\n            if (VEC) {", "        if (g0 < G && v[0] == 12345) {\n            if (VEC) {")
 
@@ -62,6 +62,8 @@ VARIANTS = {
     "philox10": [("constexpr int kCountRounds = 7;", "constexpr int kCountRounds = 10;")],
     # real variants (correct results): tuning constants
     "run16": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 16;")],
+    # the strip-end drain runs to the last walk (nothing is left to K3h there)
+    "nobail": [("constexpr int kBail = 6;", "constexpr int kBail = 0;")],
     "strip128": [("    g.strip_cells = k3::kStripCells / 2;", "    g.strip_cells = k3::kStripCells;")],
     "strip32": [("    g.strip_cells = k3::kStripCells / 2;", "    g.strip_cells = k3::kStripCells / 4;")],
     # plain instead of non-temporal row stores

@@ -16,6 +16,24 @@ for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recur
         name = row["Name"].split("(")[0][-60:]
         print("%-60s calls %4s  avg %10.1f us  total %6.2f %%" %
               (name, row["Calls"], float(row["AverageNs"]) / 1e3, float(row["Percentage"])))
+# the K timed dispatches of the stream kernel under the tracer (ramp and warmup passes in front of them, strict ones behind)
+import json
+import re
+try:
+    line = json.loads([l for l in open(os.path.join(root, "bench_trace.json")) if l.startswith("{")][-1])
+    ramp = int(re.match(r"(\d+) untimed", line["config"].get("clock_ramp", "0 untimed")).group(1))
+    first, count = ramp + line["warmup"], line["steps"]
+    for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
+        rows = [r for r in csv.DictReader(open(f)) if "sample_counts_stream_kernel" in r["Kernel_Name"]]
+        rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+        dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
+        timed = dur[first:first + count]
+        print("== stream kernel under the tracer: %d dispatches, mean %.1f us; the %d of bench.py's timed region (dispatches %d..%d): "
+              "mean %.1f us, min %.1f, max %.1f  (bench_trace.json: roofline.kernel_ms %.4f)"
+              % (len(dur), sum(dur) / len(dur), len(timed), first, first + len(timed) - 1, sum(timed) / max(1, len(timed)),
+                 min(timed), max(timed), line["roofline"]["kernel_ms"]))
+except Exception as exc:                                      # older sets have no ramp information
+    print("== (no per-dispatch summary: %r)" % (exc,))
 for f in glob.glob(os.path.join(root, "*.json")):
     print("== %s ==" % os.path.basename(f))
     print(open(f).read().strip()[:2000])
