@@ -76,6 +76,10 @@ int prosstt_amd_last_kernel_ms(prosstt_amd_ctx* ctx, float* ms);
  *   cell_index   [N] global id of every cell, or NULL (a shard of a larger plan passes
  *                the positions of its cells in that plan: results do not depend on sharding)
  *   out          [N][ld_out] int32 counts (the reference returns int64)
+ * Limits, refused with PROSSTT_AMD_EINVAL before anything is allocated: N < 2^31, ld_out >= G,
+ * ld_out * 128 < 2^32, ceil(N/64)/4 * ceil(G/256) < 2^29 (chunk the cells beyond that), rows > 0.
+ * Workspace: the ctx grows its device workspace to about N*G/4 + 36*N + 12*G bytes for the call (one
+ * region of the list of samples drawn by the second kernel per 64 x 256 block of the matrix).
  */
 int prosstt_amd_sample_counts(prosstt_amd_ctx* ctx, const float* means, int64_t rows, int32_t G,
                               const int32_t* row_of_cell, const double* scaling,

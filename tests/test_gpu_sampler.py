@@ -127,7 +127,7 @@ def test_inversion_class_limit_and_invalid_inputs_bit_exact(ctx, monkeypatch):
 
 
 def test_many_gamma_poisson_samples_overflow_the_list(ctx):
-    """More gamma-Poisson samples than the streaming kernel's list holds (1/64 of the matrix):
+    """More gamma-Poisson samples than the streaming kernel's list holds (a region takes 1/16 of its wave's samples):
     K3h then classifies every sample itself; a list that just fits takes the normal way.  Both
     bit-exact against the model."""
     from oracle import nb_model
@@ -256,3 +256,15 @@ def test_row_index_outside_the_tensor_is_reported(ctx):
             ctx.sample_counts(means, roc, sc, np.full(16, 0.2), np.full(16, 2.0), seed=1)
         out = ctx.sample_counts(means, roc, sc, np.full(16, 0.2), np.full(16, 2.0), seed=1, check_domain=False)
         assert tuple(out.shape) == (4, 16)
+        # a gene with beta < 1 makes the checked mode run its full per-sample domain pass: that pass, nb_params and the
+        # second kernel must not follow the bad index either
+        beta = np.full(16, 2.0)
+        beta[5] = 0.5
+        with pytest.raises((_native.NativeError, ValueError)):
+            ctx.sample_counts(means, roc, sc, np.full(16, 0.2), beta, seed=1)
+        mu, p, r, path = ctx.nb_params(means, roc, sc, np.full(16, 0.2), beta)
+        assert tuple(mu.shape) == (4, 16)
+    # a mean tensor without rows cannot serve any cell
+    with pytest.raises(_native.NativeError):
+        ctx.sample_counts(np.ones((0, 16), np.float32), np.zeros(2, np.int32), np.ones(2), np.full(16, 0.2), np.full(16, 2.0),
+                          seed=1, check_domain=False)

@@ -63,12 +63,16 @@ if all(c in allc for c in need):
     print("== derived: k3::sample_counts_stream_kernel (per launch) ==")
     print("  wave cycles (quads) %.4g = waiting at s_waitcnt %.1f %% + waiting for issue %.1f %% + executing %.1f %% (sum %.1f %%)"
           % (w, 100 * allc["SQ_WAIT_ANY"] / w, 100 * allc["SQ_WAIT_INST_ANY"] / w, 100 * allc["SQ_ACTIVE_INST_ANY"] / w, 100 * parts / w))
+    try:
+        samples = float(line["config"]["cells_on_rank_0"]) * float(re.search(r"(\d+) genes", line["config"]["workload"]).group(1))
+    except Exception:
+        samples = 1e9
     instr = sum(allc[c] for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD",
                                   "SQ_INSTS_VMEM_WR", "SQ_INSTS_BRANCH"))
     cycles = allc["GRBM_GUI_ACTIVE"] / 8.0          # the counter sums the 8 XCDs
     simds = 1024.0
-    print("  wave-level instructions %.4g (vector %.4g, scalar %.4g, LDS %.4g, branch %.4g, memory %.4g): %.1f per sample-quad, "
+    print("  wave-level instructions %.4g (vector %.4g, scalar %.4g, LDS %.4g, branch %.4g, memory %.4g): %.1f lane-instructions per sample, "
           "%.3g per SIMD in %.4g cycles = %.2f cycles per instruction per SIMD"
           % (instr, allc["SQ_INSTS_VALU"], allc["SQ_INSTS_SALU"], allc["SQ_INSTS_LDS"], allc["SQ_INSTS_BRANCH"],
              allc["SQ_INSTS_SMEM"] + allc["SQ_INSTS_VMEM_RD"] + allc["SQ_INSTS_VMEM_WR"],
-             instr * 64 / 1e9 / 4 * 4, instr / simds, cycles, cycles / (instr / simds)))
+             instr * 64 / samples, instr / simds, cycles, cycles / (instr / simds)))
