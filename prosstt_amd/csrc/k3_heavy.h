@@ -58,20 +58,19 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
     // ---- one PTRS attempt (or the whole of the rare small/huge-lambda branches) ---------------
     auto poisson_pass = [&]() {
         const int cnt = hp_top < 64 ? hp_top : 64;
-        bool again = false;
+        bool again = false, small = false;
         HPEntry e;
         e.n = 0; e.g = 0; e.lam = 0.0f; e.attempt = 0;
+        int32_t x = 0;
         if (lane < cnt) {
             e = L.hp[hp_top - 1 - lane];
             const uint64_t cell = cell_id(e.n);
             const uint32_t c0 = (uint32_t)cell, c1 = (uint32_t)(cell >> 32);
             const float lam = e.lam;
-            int32_t x = 0;
             if (!(lam > 0.0f)) {
                 x = 0;
             } else if (lam < prnb::kPoisInv) {
-                const prnb::Words w = prnb::philox_count(c0, c1, (uint32_t)e.g, 0x80000000u, k0, k1);
-                x = prnb::chop_down(w.w[0], prnb::det_exp(-lam), lam, 0.0f, inv_k);
+                small = true;                      // walked below, all such lanes side by side
             } else if (!(lam < prnb::kLamBig)) {
                 const prnb::Words w = prnb::philox_count(c0, c1, (uint32_t)e.g, 0x80000000u, k0, k1);
                 const float z = prnb::det_sqrt(-2.0f * prnb::det_log(prnb::unif(w.w[0]))) * prnb::det_cos2pi(w.w[1]);
@@ -112,8 +111,16 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
                 }
                 x = (int32_t)__builtin_fminf(__builtin_fmaxf(kf, 0.0f), 2147483520.0f);
             }
-            if (!again && x != 0) out[(int64_t)e.n * ld + e.g] = x;
         }
+        if (__builtin_amdgcn_ballot_w64(small) != 0ull) {
+            // lambda under 10: inversion (prnb::chop_down with q = 0)
+            const uint64_t cell = cell_id(e.n);
+            const prnb::Words w = prnb::philox_count((uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)e.g, 0x80000000u, k0, k1);
+            const float lam = small ? e.lam : 1.0f;
+            const int32_t xs = prnb::chop_down_wave(small, w.w[0], prnb::det_exp(-lam), lam, 0.0f, inv_k);
+            if (small) x = xs;
+        }
+        if (lane < cnt && !again && x != 0) out[(int64_t)e.n * ld + e.g] = x;
         hp_top -= cnt;
         const unsigned long long m = __builtin_amdgcn_ballot_w64(again);
         if (again) {
@@ -197,14 +204,18 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
     // arithmetic, 64 at a time, each lane walking its own pmf
     auto light_pass = [&]() {
         const int cnt = hl_top < 64 ? hl_top : 64;
-        if (lane < cnt) {
-            const HLEntry e = L.hl[hl_top - 1 - lane];
-            const prnb::Params P = prnb::make_params_m(e.m, ga[e.g], gbm1[e.g]);
-            const uint64_t cell = cell_id(e.n);
-            const prnb::Words w = prnb::philox_count((uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)e.g >> 2, 0u, k0, k1);
-            const int32_t x = prnb::light_draw(P, w.w[e.g & 3], inv_k);
-            if (x != 0) out[(int64_t)e.n * ld + e.g] = x;
-        }
+        const bool has = lane < cnt;
+        HLEntry e;
+        e.n = 0; e.g = 0; e.m = 1.0f;
+        if (has) e = L.hl[hl_top - 1 - lane];
+        const prnb::Params P = prnb::make_params_m(e.m, ga[e.g], gbm1[e.g]);
+        const uint64_t cell = cell_id(e.n);
+        const prnb::Words w = prnb::philox_count((uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)e.g >> 2, 0u, k0, k1);
+        const uint32_t sel = (uint32_t)e.g & 3u;
+        const uint32_t wj = sel == 0u ? w.w[0] : (sel == 1u ? w.w[1] : (sel == 2u ? w.w[2] : w.w[3]));
+        // prnb::light_draw for the 64 walks side by side
+        const int32_t x = prnb::chop_down_wave(has, wj, prnb::det_exp(-P.t), P.m * P.inv_u1, P.theta * P.inv_u1, inv_k);
+        if (has && x != 0) out[(int64_t)e.n * ld + e.g] = x;
         hl_top -= cnt;
     };
 
@@ -245,8 +256,10 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
         // every step is a chain of dependent loads (count -> entry -> row -> mean)
         const int32_t groups = (strips + 3) / 4;
         const int sub = lane >> 4, sl = lane & 15;
-        for (int64_t r0 = wave_id * 4; r0 < (int64_t)regions; r0 += waves * 4) {
-            const int64_t r = r0 + sub;
+        // a wave's regions lie `waves` apart: the listed samples cluster in a few gene tiles (regions are laid out
+        // tile by tile), and neighbouring regions for one wave would leave most waves waiting for a few
+        for (int64_t r0 = wave_id; r0 < (int64_t)regions; r0 += waves * 4) {
+            const int64_t r = r0 + (int64_t)sub * waves;
             const bool in = r < (int64_t)regions;
             // the first 16 entries are read beside the count, not behind it (a region's words exist whatever it holds)
             const uint32_t cnt = in ? heavy.count[r] : 0u;

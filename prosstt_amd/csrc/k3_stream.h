@@ -238,8 +238,11 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
 
     // a finished count (> 0) goes into the row ring while its row is still there, else (rare) on
     // the late list; a burst of 4-B stores empties the list when it is full and when the strip ends,
-    // always after the rows' own stores (a wave's stores to one address stay in order).  Every lane
-    // of the wave calls this (res = 0: nothing to deliver).
+    // always after the rows' own stores.  That a late 4-B store lands on top of its row's 16-B store rests
+    // on the gfx9 rule that a wave's global_* operations are performed in issue order (it is what makes
+    // vmcnt a counter: MI355X_MICROARCH.md, "s_waitcnt vmcnt"; flat_* would not be) -- tests/test_kernel_isa.py
+    // checks that this kernel has no flat_ instruction, the whole-matrix tests that no late count is lost.
+    // Every lane of the wave calls this (res = 0: nothing to deliver).
     int late_top = 0;                                // wave-uniform
     auto flush_late = [&]() {
         for (int i = lane; i < late_top; i += 64) {

@@ -232,6 +232,60 @@ __device__ __forceinline__ int32_t chop_down_grouped(uint32_t w, float p0, float
     }
 }
 
+// chop_down for a whole wave at once (K3h): every lane carries its own walk, all lanes are at the same k.
+// The same operations in the same order per lane as chop_down_grouped, but a group of four terms is
+// evaluated without a branch per term (terms behind a lane's draw are computed and ignored), and the
+// reciprocals of two groups come from one wave-uniform LDS round trip.  Must be called by all
+// lanes of the wave (`active` = this lane has a walk); returns when no lane is walking any more.
+__device__ __forceinline__ int32_t chop_down_wave(bool active, uint32_t w, float p0, float mp, float q,
+                                                  const float* inv_k)
+{
+    float ps = __builtin_fminf(p0, 0.99999994f) * 4294967296.0f;
+    float rem = (float)w;
+    // k = 0, 1, 2
+    const float r0 = rem - ps;
+    const float p1 = (ps * mp) * inv_k[1];
+    const float n1 = mp + q;
+    const float r1 = r0 - p1;
+    const float p2 = (p1 * n1) * inv_k[2];
+    const float n2 = n1 + q;
+    const float r2 = r1 - p2;
+    int32_t res = (r0 < 0.0f) ? 0 : ((r1 < 0.0f) ? 1 : 2);
+    bool busy = active && !((r0 < 0.0f) || (r1 < 0.0f) || (r2 < 0.0f) || (p2 < 1.0f));
+    ps = (p2 * n2) * inv_k[3];
+    float num = PRNB_FMA(3.0f, q, mp);
+    rem = r2;
+    const float4* tab = reinterpret_cast<const float4*>(__builtin_assume_aligned(inv_k + 4, 16));
+    int k = 3;
+    auto group = [&](const float4 inv) {
+        const float a1 = rem - ps;
+        const float q2 = (ps * num) * inv.x;
+        const float m2 = num + q;
+        const float a2 = a1 - q2;
+        const float q3 = (q2 * m2) * inv.y;
+        const float m3 = m2 + q;
+        const float a3 = a2 - q3;
+        const float q4 = (q3 * m3) * inv.z;
+        const float m4 = m3 + q;
+        const float a4 = a3 - q4;
+        const bool end = (a1 < 0.0f) || (a2 < 0.0f) || (a3 < 0.0f) || (a4 < 0.0f) || (q4 < 1.0f);
+        const int32_t at = (a1 < 0.0f) ? k : ((a2 < 0.0f) ? k + 1 : ((a3 < 0.0f) ? k + 2 : k + 3));
+        if (busy && end) { res = at; busy = false; }
+        ps = (q4 * m4) * inv.w;
+        k += 4;
+        num = PRNB_FMA((float)k, q, mp);
+        rem = a4;
+    };
+    // two groups per LDS round trip (the table ends in zeros: a walk stops at the sentinel at the latest,
+    // which is the last group this loop can reach)
+    while (__builtin_amdgcn_ballot_w64(busy) != 0ull) {
+        const float4 ia = tab[(k - 3) >> 2], ib = tab[((k - 3) >> 2) + 1];
+        group(ia);
+        group(ib);
+    }
+    return res;
+}
+
 __device__ __forceinline__ float logfact_small(int k)
 {
     // log(k!) for k < 10, binary32-rounded

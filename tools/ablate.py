@@ -30,6 +30,11 @@ PHILOX_OFF = ("        const prnb::Words W = philox_count_row(ph, quad_hi, quad_
               "        W.w[2] = W.w[1] ^ 0x9E3779B9u; W.w[3] = W.w[2] + W.w[0];")
 STORE_OFF = ("        if (g0 < G) {\n            if (VEC) {", "        if (g0 < G && v[0] == 12345) {\n            if (VEC) {")
 
+K3H_LAUNCH = """    k3::sample_counts_heavy_kernel<<<dim3(2048), dim3(k3::kHeavyBlock), 0, c->stream>>>(
+        heavy, (uint32_t)geo.regions, (int32_t)geo.strips, (int32_t)geo.strip_cells, A.means, rows, G, A.row_of_cell,
+        A.scal, A.ga, A.gbm1, N, k0, k1, cell_offset, d_cell_index, d_out, ld_out);
+"""
+
 VARIANTS = {
     "base": [],
     # stage 1 only: survivors are pushed, then dropped
@@ -58,6 +63,40 @@ VARIANTS = {
     "k3h_grid1536": [("k3::sample_counts_heavy_kernel<<<dim3(2048),", "k3::sample_counts_heavy_kernel<<<dim3(1536),")],
     "k3h_grid3072": [("k3::sample_counts_heavy_kernel<<<dim3(2048),", "k3::sample_counts_heavy_kernel<<<dim3(3072),")],
     "k3h_none": [("            light = P.valid && P.light;\n", "            light = false;\n"), ("            heavy = P.valid && !P.light;\n", "            heavy = false;\n")],
+    # K3h diagnosis (timing only): redo walks cut at 35 / 131 terms; every gamma / Poisson attempt accepted
+    "k3h_walk35": [("    for (int k = 3;; k += 4) {\n        const float4 inv", "    for (int k = 3;; k += 4) {\n        if (k >= 35) return k;\n        const float4 inv")],
+    "k3h_walk131": [("    for (int k = 3;; k += 4) {\n        const float4 inv", "    for (int k = 3;; k += 4) {\n        if (k >= 131) return k;\n        const float4 inv")],
+    "k3h_gamma1": [("                    ok = last;\n                    if (!ok) {", "                    ok = true;\n                    if (!ok) {")],
+    "k3h_pois1": [("                    again = j + 1 < 2 * prnb::kMaxTries;", "                    again = false;")],
+    # K3h launched twice / three times (idempotent): what a launch costs when its code and data are warm
+    "k3h_twice": [(K3H_LAUNCH, K3H_LAUNCH * 2)],
+    "k3h_thrice": [(K3H_LAUNCH, K3H_LAUNCH * 3)],
+    # K3h without its scattered 4-byte stores
+    "k3h_noout": [("            if (x != 0) out[(int64_t)e.n * ld + e.g] = x;", "            if (x == 0x7fffffff) out[(int64_t)e.n * ld + e.g] = x;"),
+                  ("            if (!again && x != 0) out[(int64_t)e.n * ld + e.g] = x;", "            if (!again && x == 0x7fffffff) out[(int64_t)e.n * ld + e.g] = x;")],
+    # K3h: the list is read and sorted onto the stacks, no pass runs
+    "k3h_feedonly": [("        while (hg_top >= 64) gamma_pass();\n        while (hl_top >= 64) light_pass();",
+                      "        if (hg_top >= 64) { asm volatile(\"\" :: \"v\"(L.hg[lane].m)); hg_top = 0; }\n"
+                      "        if (hl_top >= 64) { asm volatile(\"\" :: \"v\"(L.hl[lane].m)); hl_top = 0; }"),
+                     ("    while (hl_top > 0) light_pass();\n    while (hg_top > 0) gamma_pass();\n    while (hp_top > 0) poisson_pass();",
+                      "    asm volatile(\"\" :: \"v\"(L.hl[lane].m), \"v\"(L.hg[lane].m));")],
+    # K3h: redo walks replaced by one compare (parameters, Philox call and store stay)
+    "k3h_nowalk": [("            const int32_t x = prnb::light_draw(P, w.w[e.g & 3], inv_k);", "            const int32_t x = (float)w.w[e.g & 3] < P.t * P.inv_u1;")],
+    # K3h: gamma-Poisson entries dropped after the gamma pass
+    "k3h_nopois": [("        while (hp_top >= 64) poisson_pass();", "        hp_top = 0;")],
+    # K3h with a device printf of per-phase cycle counts of a few waves (diagnosis; printf costs registers and time)
+    "k3h_trace": [("    int hg_top = 0, hp_top = 0, hl_top = 0;      // wave-uniform",
+                   "    int hg_top = 0, hp_top = 0, hl_top = 0;      // wave-uniform\n    int np_l = 0, np_g = 0, np_p = 0; long long T0 = clock64(), TW = 0, TL = 0, TG = 0, TP = 0;"),
+                  ("    auto poisson_pass = [&]() {\n", "    auto poisson_pass = [&]() {\n        ++np_p; const long long tp0 = clock64();\n"),
+                  ("        hp_top += __popcll(m);\n    };", "        hp_top += __popcll(m);\n        TP += clock64() - tp0;\n    };"),
+                  ("    auto gamma_pass = [&]() {\n", "    auto gamma_pass = [&]() {\n        ++np_g; const long long tg0 = clock64();\n"),
+                  ("        hp_top += __popcll(mp);\n        while (hp_top >= 64) poisson_pass();", "        hp_top += __popcll(mp);\n        TG += clock64() - tg0;\n        while (hp_top >= 64) poisson_pass();"),
+                  ("    auto light_pass = [&]() {\n", "    auto light_pass = [&]() {\n        ++np_l; const long long tl0 = clock64();\n"),
+                  ("        hl_top -= cnt;\n    };", "        hl_top -= cnt;\n        TL += clock64() - tl0;\n    };"),
+                  ("    while (hl_top > 0) light_pass();\n    while (hg_top > 0) gamma_pass();\n    while (hp_top > 0) poisson_pass();",
+                   "    const long long T1 = clock64();\n    while (hl_top > 0) light_pass();\n    while (hg_top > 0) gamma_pass();\n    while (hp_top > 0) poisson_pass();\n"
+                   "    const long long T2 = clock64();\n"
+                   "    if (lane == 0 && (wave_id % 1021) == 5) printf(\"K3HTRACE wave %lld total %lld feedloop %lld drain %lld | light %d passes %lld | gamma %d passes %lld | poisson %d passes %lld\\n\", (long long)wave_id, T2 - T0, T1 - T0, T2 - T1, np_l, TL, np_g, TG, np_p, TP);")],
     # the library default of 10 Philox rounds instead of 7 (timing only: the model is not changed along)
     "philox10": [("constexpr int kCountRounds = 7;", "constexpr int kCountRounds = 10;")],
     # real variants (correct results): tuning constants
