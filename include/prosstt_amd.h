@@ -92,8 +92,9 @@ int prosstt_amd_sample_counts(prosstt_amd_ctx* ctx, const float* means, int64_t 
  * to its second kernel (K3h): the gamma-Poisson class, inversion walks whose hardware-math
  * evaluation came within its margin of a threshold, counts above 255.  Decoded to (cell, gene)
  * pairs, cells[i] indexing that call's arrays; at most `cap` pairs are written, *total receives the
- * number listed, *overflowed whether a wave's region of the list was too small (K3h then ignores the
- * list and redoes the whole matrix).  For tests and diagnostics: it synchronises and copies.
+ * number listed, *overflowed whether a wave's region of the list was too small (more than one in 16 of
+ * its 64 x 256 samples listed; K3h then redoes that region sample by sample, and the list holds the
+ * entries that fitted).  For tests and diagnostics: it synchronises and copies.
  * Valid until the next call on the ctx.
  */
 int prosstt_amd_last_list(prosstt_amd_ctx* ctx, int64_t* cells, int32_t* genes, int64_t cap,

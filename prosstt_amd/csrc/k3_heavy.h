@@ -250,9 +250,8 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
     };
     const int64_t wave_id = (int64_t)blockIdx.x * (kHeavyBlock / 64) + wv;
     const int64_t waves = (int64_t)gridDim.x * (kHeavyBlock / 64);
-    const int64_t wave0 = wave_id * 64, stride = waves * 64;
-    if (heavy.overflow[0] == 0u) {
-        // four regions per step, 16 lanes each: a region holds ~20 entries on the headline workload, and
+    {
+        // four regions per step, 16 lanes each: a region holds ~30 entries on the headline workload, and
         // every step is a chain of dependent loads (count -> entry -> row -> mean)
         const int32_t groups = (strips + 3) / 4;
         const int sub = lane >> 4, sl = lane & 15;
@@ -262,24 +261,34 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
             const int64_t r = r0 + (int64_t)sub * waves;
             const bool in = r < (int64_t)regions;
             // the first 16 entries are read beside the count, not behind it (a region's words exist whatever it holds)
-            const uint32_t cnt = in ? heavy.count[r] : 0u;
+            const uint32_t cnt_all = in ? heavy.count[r] : 0u;
             uint32_t p = in ? heavy.list[(uint64_t)r * heavy.cap + (uint32_t)sl] : 0u;
             const int32_t blk = (int32_t)(r >> 2);
             const int32_t tile_g = blk / groups;
             const int64_t n0 = (int64_t)((blk - tile_g * groups) * 4 + (int32_t)(r & 3)) * strip_cells;
+            const bool over = cnt_all > heavy.cap;       // the region was too small: redone as a whole below
+            const uint32_t cnt = over ? 0u : cnt_all;
             for (uint32_t i0 = 0u; __builtin_amdgcn_ballot_w64(i0 < cnt) != 0ull; i0 += 16u) {
                 const bool has = i0 + (uint32_t)sl < cnt;
                 if (i0 != 0u) p = has ? heavy.list[(uint64_t)r * heavy.cap + i0 + (uint32_t)sl] : 0u;
                 feed(has, (int32_t)(n0 + (p >> 8)), tile_g * kTileG + (int32_t)(p & 255u));
             }
-        }
-    } else {
-        // the list overflowed: every sample of the matrix is redone here
-        const int64_t total = N * (int64_t)G;
-        for (int64_t i0 = wave0; i0 < total; i0 += stride) {
-            const int64_t i = i0 + lane;
-            const int32_t n = i < total ? (int32_t)(i / G) : 0;
-            feed(i < total, n, (int32_t)(i - (int64_t)n * G));
+            // every sample of an overflowed region (strip_cells x 256 of the matrix) goes through the classification
+            // here, 64 at a time: slow (the streaming kernel's own results are recomputed), but any parameter set
+            // stays correct and only the regions that overflowed pay
+            unsigned long long over_m = __builtin_amdgcn_ballot_w64(over && sl == 0);
+            while (over_m != 0ull) {
+                const int src = (int)__builtin_ctzll(over_m);
+                over_m &= over_m - 1ull;
+                const int32_t tg = __builtin_amdgcn_readlane(tile_g, src);
+                const int64_t nb = ((int64_t)__builtin_amdgcn_readlane((int32_t)(n0 >> 32), src) << 32) |
+                                   (uint32_t)__builtin_amdgcn_readlane((int32_t)n0, src);
+                for (int32_t c = 0; c < strip_cells && nb + c < N; ++c)
+                    for (int j = 0; j < 4; ++j) {
+                        const int32_t g = tg * kTileG + j * 64 + lane;
+                        feed(g < G, (int32_t)(nb + c), g);
+                    }
+            }
         }
     }
     while (hl_top > 0) light_pass();

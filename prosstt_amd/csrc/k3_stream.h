@@ -134,8 +134,9 @@ struct WaveLds {
 };
 
 // The list of samples left to K3h: wave w of block b owns region r = 4*b + w, entries
-// list[r * cap .. + count[r]) = pos (cell-in-strip << 8 | gene-in-tile); overflow[0] != 0 once a
-// region was too small (more than one sample in 16 listed) -- K3h then redoes every sample itself.
+// list[r * cap .. + min(count[r], cap)) = pos (cell-in-strip << 8 | gene-in-tile); a region that was too
+// small (count[r] > cap: more than one sample in 16 listed) is redone by K3h sample by sample, and
+// overflow[0] != 0 says that there was one.
 static_assert(offsetof(WaveLds, s1) == offsetof(WaveLds, s1_null) + sizeof(S1Entry), "s1[-1] must be the null entry");
 
 struct HeavyList { uint32_t* count; uint32_t* list; uint32_t* overflow; uint32_t cap; };
@@ -557,8 +558,8 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
     flush_late();
     if (__builtin_amdgcn_ballot_w64(hpend != kNoHeavy) != 0ull) flush_heavy();
     if (lane == 0) {
-        heavy.count[region] = h_cnt < heavy.cap ? h_cnt : heavy.cap;
-        if (h_cnt > heavy.cap) heavy.overflow[0] = 1u;
+        heavy.count[region] = h_cnt;                 // above cap: K3h redoes the whole region
+        if (h_cnt > heavy.cap) heavy.overflow[0] = 1u;   // (for prosstt_amd_last_list)
     }
 }
 

@@ -475,7 +475,7 @@ struct SamplerArgs {
 struct StreamGeometry {
     int64_t tiles_g, strip_cells, strips, groups;
     uint64_t regions;       // one region of the K3h list per wave
-    uint32_t region_cap;    // room for one in 16 of a wave's samples (beyond that K3h redoes the matrix itself)
+    uint32_t region_cap;    // room for one in 16 of a wave's samples (beyond that K3h redoes the region itself)
     size_t list_bytes, count_bytes, rows_bytes, info_bytes;
     size_t total() const { return list_bytes + count_bytes + rows_bytes + info_bytes + 256; }
 };
@@ -653,8 +653,8 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
 // The samples the streaming kernel of the LAST sample_counts call on this ctx left to K3h (the gamma-Poisson
 // class, walks too close to a threshold, counts above 255), decoded to (cell, gene) pairs: `cells[i]` is the
 // cell's index in that call's arrays.  At most `cap` pairs are written; `*total` receives the number listed
-// (the regions' counts are clamped to their capacity, as K3h sees them) and `*overflowed` whether a region
-// was too small, in which case K3h ignored the list.  Valid until the next call on the ctx grows its workspace.
+// (of a region that was too small: the entries that fitted) and `*overflowed` whether there was such a region
+// (K3h redoes those regions sample by sample).  Valid until the next call on the ctx grows its workspace.
 PA_EXPORT int prosstt_amd_last_list(prosstt_amd_ctx* c, int64_t* cells, int32_t* genes, int64_t cap,
                                     int64_t* total, int32_t* overflowed)
 {

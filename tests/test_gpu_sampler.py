@@ -138,6 +138,14 @@ def test_many_gamma_poisson_samples_overflow_the_list(ctx):
         assert (share > 0.3) if frac > 0.5 else (0.002 < share < 1 / 64)
         got = ctx.sample_counts(means, roc, sc, al, be, seed=seed).cpu().numpy()
         np.testing.assert_array_equal(got, nb_model.sample_counts(means, roc, sc, al, be, seed))
+        assert ctx.last_list()[3] == (frac > 0.5)
+    # only the second of four gene tiles is that dense: its regions are redone whole, the others take their lists
+    means, roc, sc, al, be = synthetic(33, 50, 1024, 900, heavy_frac=0.012)
+    means[:, 256:512][:, np.random.default_rng(1).random(256) < 0.5] *= 200.0
+    got = ctx.sample_counts(means, roc, sc, al, be, seed=33).cpu().numpy()
+    np.testing.assert_array_equal(got, nb_model.sample_counts(means, roc, sc, al, be, 33))
+    cells, genes, total, overflowed = ctx.last_list()
+    assert overflowed and ((genes < 256) | (genes >= 512)).sum() > 100
 
 
 def test_long_inversion_walks_bit_exact(ctx):
