@@ -311,33 +311,42 @@ def run_case(job, config, scaling, cells_per_gpu, steps, warmup, strict_steps, g
         job.fence()
         res["ms_strict"] = job.max_over_ranks(time.perf_counter() - t0) / strict_steps * 1e3
 
-    # the one exchange of the path: count rows to rank 0 (point-to-point over xGMI), timed on its own.
-    # Bounded so that root's copy of the whole matrix plus its own shard stays far inside 288 GB.
-    if gather and world > 1 and 4 * n_total * G <= 64e9:
-        small = min(64, len(mine))
-        parallel.gather_rows(out[:small], mine[:small], n_total)        # connections come up outside the timed region
-        job.fence()
-        if job.backend == "nccl":
-            t0 = time.perf_counter()
-            full = parallel.gather_rows(out, mine, n_total)
-            job.fence()
-            res["gather_ms"] = job.max_over_ranks(time.perf_counter() - t0) * 1e3
-            del full
-        else:
-            # functional run on another backend (gloo stages device tensors through the host at ~25 MB/s):
-            # the exchange is exercised on 2048 rows per rank and not timed
-            part = min(2048, len(mine))
-            full = parallel.gather_rows(out[:part], mine[:part], n_total)
-            job.fence()
-            res["gather_rows_functional"] = int(job.max_over_ranks(part))
-            del full
-
     # sanity inside the bench: first moment of this rank's shard (catches a silently dead kernel)
     mu_sum = float((means.double().sum(dim=1)[d_rows.long()] * d_sc).sum())
     x_sum = sum(int(out[lo:lo + 16384].sum(dtype=torch.int64)) for lo in range(0, len(mine), 16384))   # bounded temporaries
     res["ratio"] = x_sum / mu_sum if mu_sum > 0 else float("nan")
     res["tree"] = tree
+    if gather and world > 1:
+        time_gather(job, res, out, mine)
+    else:
+        res["shard"] = (out, mine)          # for a later time_gather (the main case: after the line is assembled)
     return res
+
+
+def time_gather(job, res, out, mine):
+    """The one exchange of the path: count rows to rank 0 (point-to-point over xGMI), timed on its own.
+    Bounded so that root's copy of the whole matrix plus its own shard stays far inside 288 GB."""
+    from prosstt_amd import parallel
+    n_total, G = res["n_total"], res["G"]
+    if job.world == 1 or 4 * n_total * G > 64e9:
+        return
+    small = min(64, len(mine))
+    parallel.gather_rows(out[:small], mine[:small], n_total)        # connections come up outside the timed region
+    job.fence()
+    if job.backend == "nccl":
+        t0 = time.perf_counter()
+        full = parallel.gather_rows(out, mine, n_total)
+        job.fence()
+        res["gather_ms"] = job.max_over_ranks(time.perf_counter() - t0) * 1e3
+        del full
+    else:
+        # functional run on another backend (gloo stages device tensors through the host at ~25 MB/s):
+        # the exchange is exercised on 2048 rows per rank and not timed
+        part = min(2048, len(mine))
+        full = parallel.gather_rows(out[:part], mine[:part], n_total)
+        job.fence()
+        res["gather_rows_functional"] = int(job.max_over_ranks(part))
+        del full
 
 
 def main():
@@ -373,83 +382,158 @@ def main():
     job = Job(args)
     world, rank = job.world, job.rank
     main_case = run_case(job, args.config, args.scaling, args.cells_per_gpu, args.steps, args.warmup,
-                         args.strict_steps, gather=not args.no_gather, ramp_ms=args.ramp_ms)
+                         args.strict_steps, gather=False, ramp_ms=args.ramp_ms)
     work, G, n_total = main_case["work"], main_case["G"], main_case["n_total"]
     pt, br, sc = main_case["plan"]
 
     end_to_end = None
+    if world == 1:
+        main_case.pop("shard", None)
     if world == 1 and not args.no_end_to_end and rank == 0:
         end_to_end = end_to_end_ms(main_case["tree"], work, n_total)
 
-    strong = []
-    if world > 1:
-        from prosstt_amd import workloads
-        sharing = world if os.environ.get("PROSSTT_BENCH_ONE_GPU") == "1" else 1    # ranks on one device (functional test)
-        for cfg in [c for c in args.strong_configs.split(",") if c]:
-            spec = workloads.CONFIGS[cfg]
-            per_device = 4.0 * spec["N"] * spec["G"] / world * sharing
-            if per_device > 0.35 * job.torch.cuda.get_device_properties(job.ctx.device).total_memory:
-                strong.append({"config": cfg, "skipped": "%.0f GB of counts per device" % (per_device / 1e9)})
-                continue
-            case = run_case(job, cfg, "strong", None, max(3, args.steps // 2), 2, 0, gather=not args.no_gather,
-                            ramp_ms=args.ramp_ms / 2)
-            strong.append({"config": cfg, "cells_total": case["n_total"], "genes": case["G"],
-                           "cells_on_rank_0": case["cells_on_rank"], "value": case["value"], "unit": "cells*genes/s",
-                           "ms_per_step": case["ms_per_step"], "kernel_ms_max_over_ranks": case["kernel_ms"],
-                           "gather_ms": case["gather_ms"], "lineage_s": round(case["work"].info["lineage_s"], 3),
-                           "lineage_attempts": case["work"].info["attempts"],
-                           "sum_counts_over_sum_means": round(case["ratio"], 5)})
-            del case
+    # With N > 1 the measurements beyond the contract's line (the row gather, the strong-scaling configurations)
+    # run under a watchdog: if one of them raises or stalls, rank 0 still prints the line -- with what was
+    # measured and the reason under "extras_error" -- and every rank leaves with exit code 0.
+    strong, extras_error = [], None
 
-    if rank == 0:
-        kms = main_case["kernel_ms"]
-        abytes = algorithmic_bytes(main_case["cells_on_rank"], G, main_case["rows_total"])
-        achieved = abytes / (kms * 1e-3)
-        ms_per_step = main_case["ms_per_step"]
-        default_shape = args.config == "C3" and args.cells_per_gpu is None and args.scaling == "weak" and world == 1
-        traffic, traffic_src = profiled_traffic() if default_shape else (None, "profiles are of the default 1-GPU C3 run")
-        line = {
-            "metric": "simulated cells*genes per second (count sampling: sample_density -> draw_counts)",
-            "value": main_case["value"], "unit": "cells*genes/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "ms_per_step_strict": main_case["ms_strict"],
-            "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %d-branch tree (T=50, K=25), %d genes, %d cells per GPU "
-                                   "(%d total), density sampling; lineage via the product pipeline"
-                                   % (args.config, work.info["branches"], G, main_case["per_gpu"], n_total),
-                       "cells_on_rank_0": main_case["cells_on_rank"],
-                       "parallelism": "cells sharded by branch, %d rank(s), no data-path collective" % world,
-                       "lineage_attempts": work.info["attempts"], "lineage_s": round(work.info["lineage_s"], 3),
-                       "lineage_sharded_by_genes": bool(work.info["sharded"]),
-                       "clock_ramp": "%d untimed passes (%.0f ms) before the %d warmup steps" % (main_case["ramp_calls"], args.ramp_ms, args.warmup),
-                       "sum_counts_over_sum_means": round(main_case["ratio"], 5)},
-            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k3::sample_counts_stream_kernel<true>", "kernel_ms": kms,
-                         "frac_whole_step": abytes / (ms_per_step * 1e-3) / HBM_PEAK,
-                         "algorithmic_bytes_per_launch": abytes, "kernel_source_sha": kernel_source_sha(),
-                         "note": "frac = algorithmic bytes / the dominant kernel's mean duration (HIP events, max over "
-                                 "ranks); frac_whole_step prices them against ms_per_step (K3h, prep kernels, gaps). "
-                                 "VALU-issue-bound sampler: DESIGN.md section 6 and profiles/"},
-        }
-        if main_case["gather_ms"] is not None:
-            line["gather_ms"] = main_case["gather_ms"]
-        if "gather_rows_functional" in main_case:
-            line["gather_ms"] = None
-            line["gather_note"] = "backend %s: gather exercised on %d rows per rank, not timed" % (job.backend, main_case["gather_rows_functional"])
-        if strong:
-            line["strong_scaling"] = strong
-        if end_to_end is not None:
-            line["end_to_end_ms"] = end_to_end
-        if world == 1 and args.cpu_cells > 0:
-            line["cpu_baseline"] = cpu_baseline(work, pt, br, sc, min(args.cpu_cells, n_total))
-            line["speedup_vs_cpu_1core"] = main_case["value"] / line["cpu_baseline"]["value"]
-        procs = physical_cores() if args.cpu_procs < 0 else args.cpu_procs
-        if world == 1 and args.cpu_cells > 0 and procs > 1:
-            line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(
-                work, pt, br, sc, min(max(args.cpu_cells, 250 * procs), n_total), procs)
+    def emit(why=None):
+        """Print the line (rank 0).  ``why``: the watchdog's reason when it is the caller."""
+        if rank != 0:
+            return
+        line = assemble_line(args, job, main_case, strong, end_to_end, why or extras_error)
         print(json.dumps(line), flush=True)
+
+    guard = ExtrasGuard(rank, float(os.environ.get("PROSSTT_BENCH_EXTRAS_TIMEOUT_S", "600")))
+    if world > 1:
+        guard.arm(lambda why: emit(why))
+        try:
+            if not args.no_gather:
+                time_gather(job, main_case, *main_case["shard"])
+            main_case.pop("shard", None)
+            from prosstt_amd import workloads
+            sharing = world if os.environ.get("PROSSTT_BENCH_ONE_GPU") == "1" else 1    # ranks on one device (functional test)
+            for cfg in [c for c in args.strong_configs.split(",") if c]:
+                spec = workloads.CONFIGS[cfg]
+                per_device = 4.0 * spec["N"] * spec["G"] / world * sharing
+                if per_device > 0.35 * job.torch.cuda.get_device_properties(job.ctx.device).total_memory:
+                    strong.append({"config": cfg, "skipped": "%.0f GB of counts per device" % (per_device / 1e9)})
+                    continue
+                case = run_case(job, cfg, "strong", None, max(3, args.steps // 2), 2, 0, gather=not args.no_gather,
+                                ramp_ms=args.ramp_ms / 2)
+                strong.append({"config": cfg, "cells_total": case["n_total"], "genes": case["G"],
+                               "cells_on_rank_0": case["cells_on_rank"], "value": case["value"], "unit": "cells*genes/s",
+                               "ms_per_step": case["ms_per_step"], "kernel_ms_max_over_ranks": case["kernel_ms"],
+                               "gather_ms": case["gather_ms"], "lineage_s": round(case["work"].info["lineage_s"], 3),
+                               "lineage_attempts": case["work"].info["attempts"],
+                               "sum_counts_over_sum_means": round(case["ratio"], 5)})
+                del case
+        except Exception as exc:          # noqa: BLE001 -- whatever it is, the line must still go out
+            extras_error = "%s: %s" % (type(exc).__name__, str(exc)[:300])
+    main_case.pop("shard", None)
+
+    if not guard.disarm():
+        import threading
+        threading.Event().wait()    # the watchdog is printing and will end the process
+    emit()
+    if extras_error is not None:
+        # the other ranks may be waiting in a collective this rank left: no orderly shutdown is possible
+        sys.stdout.flush()
+        os._exit(0)
     job.close()
+
+
+class ExtrasGuard:
+    """Deadline for the measurements that are not part of the contract's line (N > 1)."""
+
+    def __init__(self, rank, seconds):
+        import threading
+        self.rank, self.seconds, self.lock, self.state, self.timer = rank, seconds, threading.Lock(), "idle", None
+
+    def arm(self, emit):
+        import threading
+
+        def fire():
+            with self.lock:
+                if self.state != "armed":
+                    return
+                self.state = "fired"
+            try:
+                emit("extras timed out after %.0f s (PROSSTT_BENCH_EXTRAS_TIMEOUT_S); what was measured until then is reported" % self.seconds)
+            finally:
+                sys.stdout.flush()
+                os._exit(0)
+
+        self.state = "armed"
+        self.timer = threading.Timer(self.seconds, fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def disarm(self):
+        """False if the deadline has already fired (the caller must not print)."""
+        with self.lock:
+            if self.state == "fired":
+                return False
+            self.state = "done"
+        if self.timer is not None:
+            self.timer.cancel()
+        return True
+
+
+def assemble_line(args, job, main_case, strong, end_to_end, extras_error):
+    """The one JSON line of the contract, from what has been measured (rank 0)."""
+    world = job.world
+    work, G, n_total = main_case["work"], main_case["G"], main_case["n_total"]
+    pt, br, sc = main_case["plan"]
+    kms = main_case["kernel_ms"]
+    abytes = algorithmic_bytes(main_case["cells_on_rank"], G, main_case["rows_total"])
+    achieved = abytes / (kms * 1e-3)
+    ms_per_step = main_case["ms_per_step"]
+    default_shape = args.config == "C3" and args.cells_per_gpu is None and args.scaling == "weak" and world == 1
+    traffic, traffic_src = profiled_traffic() if default_shape else (None, "profiles are of the default 1-GPU C3 run")
+    line = {
+        "metric": "simulated cells*genes per second (count sampling: sample_density -> draw_counts)",
+        "value": main_case["value"], "unit": "cells*genes/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "ms_per_step_strict": main_case["ms_strict"],
+        "higher_is_better": True,
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: %d-branch tree (T=50, K=25), %d genes, %d cells per GPU "
+                               "(%d total), density sampling; lineage via the product pipeline"
+                               % (args.config, work.info["branches"], G, main_case["per_gpu"], n_total),
+                   "cells_on_rank_0": main_case["cells_on_rank"],
+                   "parallelism": "cells sharded by branch, %d rank(s), no data-path collective" % world,
+                   "lineage_attempts": work.info["attempts"], "lineage_s": round(work.info["lineage_s"], 3),
+                   "lineage_sharded_by_genes": bool(work.info["sharded"]),
+                   "clock_ramp": "%d untimed passes (%.0f ms) before the %d warmup steps" % (main_case["ramp_calls"], args.ramp_ms, args.warmup),
+                   "sum_counts_over_sum_means": round(main_case["ratio"], 5)},
+        "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": "k3::sample_counts_stream_kernel<true>", "kernel_ms": kms,
+                     "frac_whole_step": abytes / (ms_per_step * 1e-3) / HBM_PEAK,
+                     "algorithmic_bytes_per_launch": abytes, "kernel_source_sha": kernel_source_sha(),
+                     "note": "frac = algorithmic bytes / the dominant kernel's mean duration (HIP events, max over "
+                             "ranks); frac_whole_step prices them against ms_per_step (K3h, prep kernels, gaps). "
+                             "VALU-issue-bound sampler: DESIGN.md section 6 and profiles/"},
+    }
+    if main_case["gather_ms"] is not None:
+        line["gather_ms"] = main_case["gather_ms"]
+    if "gather_rows_functional" in main_case:
+        line["gather_ms"] = None
+        line["gather_note"] = "backend %s: gather exercised on %d rows per rank, not timed" % (job.backend, main_case["gather_rows_functional"])
+    if strong:
+        line["strong_scaling"] = strong
+    if end_to_end is not None:
+        line["end_to_end_ms"] = end_to_end
+    if world == 1 and args.cpu_cells > 0:
+        line["cpu_baseline"] = cpu_baseline(work, pt, br, sc, min(args.cpu_cells, n_total))
+        line["speedup_vs_cpu_1core"] = main_case["value"] / line["cpu_baseline"]["value"]
+    procs = physical_cores() if args.cpu_procs < 0 else args.cpu_procs
+    if world == 1 and args.cpu_cells > 0 and procs > 1:
+        line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(
+            work, pt, br, sc, min(max(args.cpu_cells, 250 * procs), n_total), procs)
+    if extras_error:
+        line["extras_error"] = extras_error
+    return line
 
 
 def end_to_end_ms(tree, work, n_cells):

@@ -78,3 +78,26 @@ def test_gpus_flag_without_launcher_goes_through_launch_ranks(monkeypatch):
         raise AssertionError("a world size that contradicts --gpus must be refused")
     except SystemExit as e:
         assert "--gpus 4" in str(e.code)
+
+
+_GUARDED = """
+import sys, threading
+sys.path.insert(0, %r)
+import bench
+guard = bench.ExtrasGuard(0, %s)
+guard.arm(lambda why: print("LINE " + why, flush=True))
+if %s:
+    threading.Event().wait()          # an extra that never returns (a collective whose peers are gone)
+assert guard.disarm()
+print("LINE in time", flush=True)
+"""
+
+
+def test_a_stalled_extra_still_yields_the_line_and_exit_code_zero():
+    """With N > 1 the gather and the strong-scaling configurations run under a deadline: when one stalls, the line
+    goes out with the reason and the process ends with exit code 0; in time, the deadline is never heard of."""
+    stalled = subprocess.run([sys.executable, "-c", _GUARDED % (ROOT, "0.5", "True")], capture_output=True, text=True, timeout=120)
+    assert stalled.returncode == 0, stalled.stderr[-2000:]
+    assert stalled.stdout.count("LINE") == 1 and "timed out after" in stalled.stdout
+    fine = subprocess.run([sys.executable, "-c", _GUARDED % (ROOT, "30", "False")], capture_output=True, text=True, timeout=120)
+    assert fine.returncode == 0 and fine.stdout.strip() == "LINE in time"
