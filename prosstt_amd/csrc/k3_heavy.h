@@ -200,23 +200,108 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
         while (hp_top >= 64) poisson_pass();
     };
 
-    // ---- inversion walks the streaming kernel's approximate arithmetic gave up on: PRNB-2's exact
-    // arithmetic, 64 at a time, each lane walking its own pmf
-    auto light_pass = [&]() {
-        const int cnt = hl_top < 64 ? hl_top : 64;
-        const bool has = lane < cnt;
+    // ---- inversion walks the streaming kernel left (too close to a threshold, unfinished, above 255): the
+    // definition's arithmetic (prnb::light_draw), every lane walking its own pmf eight terms per pass.  Walks
+    // differ in length by two orders of magnitude (the unfinished ones are the longest of their strip), so a
+    // lane's walk lives in registers across passes and an idle lane takes the next entry of the redo stack:
+    // a pass runs with more than half of the lanes walking, and new walks start at least 32 at a time.
+    int32_t wk = -1;                                  // next term of this lane's walk; -1: idle
+    float wps = 0.0f, wnum = 0.0f, wrem = 0.0f, wmp = 0.0f, wq = 0.0f;
+    int32_t wn = 0, wg = 0;
+    auto light_start = [&]() {
+        // idle lanes take entries: parameters, P(X = 0) and the terms k = 0, 1, 2 (prnb::chop_down_grouped's first
+        // group); a walk that does not end there goes on in light_walk
+        const unsigned long long idle_m = __builtin_amdgcn_ballot_w64(wk < 0);
+        const int rank = lane_rank(idle_m);
+        const bool take = wk < 0 && rank < hl_top;
         HLEntry e;
         e.n = 0; e.g = 0; e.m = 1.0f;
-        if (has) e = L.hl[hl_top - 1 - lane];
+        if (take) e = L.hl[hl_top - 1 - rank];
+        const int idle = __popcll(idle_m);
+        hl_top -= idle < hl_top ? idle : hl_top;
         const prnb::Params P = prnb::make_params_m(e.m, ga[e.g], gbm1[e.g]);
         const uint64_t cell = cell_id(e.n);
         const prnb::Words w = prnb::philox_count((uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)e.g >> 2, 0u, k0, k1);
         const uint32_t sel = (uint32_t)e.g & 3u;
         const uint32_t wj = sel == 0u ? w.w[0] : (sel == 1u ? w.w[1] : (sel == 2u ? w.w[2] : w.w[3]));
-        // prnb::light_draw for the 64 walks side by side
-        const int32_t x = prnb::chop_down_wave(has, wj, prnb::det_exp(-P.t), P.m * P.inv_u1, P.theta * P.inv_u1, inv_k);
-        if (has && x != 0) out[(int64_t)e.n * ld + e.g] = x;
-        hl_top -= cnt;
+        const float mp = P.m * P.inv_u1, q = P.theta * P.inv_u1;
+        const float ps = __builtin_fminf(prnb::det_exp(-P.t), 0.99999994f) * 4294967296.0f;
+        const float r0 = (float)wj - ps;
+        const float p1 = (ps * mp) * inv_k[1];
+        const float n1 = mp + q;
+        const float r1 = r0 - p1;
+        const float p2 = (p1 * n1) * inv_k[2];
+        const float n2 = n1 + q;
+        const float r2 = r1 - p2;
+        const bool done = (r0 < 0.0f) || (r1 < 0.0f) || (r2 < 0.0f) || (p2 < 1.0f);
+        const int32_t x = (r0 < 0.0f) ? 0 : ((r1 < 0.0f) ? 1 : 2);
+        if (take) {
+            if (done) {
+                if (x != 0) out[(int64_t)e.n * ld + e.g] = x;
+            } else {
+                wk = 3;
+                wps = (p2 * n2) * inv_k[3];
+                wnum = PRNB_FMA(3.0f, q, mp);
+                wrem = r2;
+                wmp = mp; wq = q; wn = e.n; wg = e.g;
+            }
+        }
+    };
+    auto light_walk = [&]() {
+        // two groups of four terms for every walking lane (an idle lane computes on zeros).  Most passes of a
+        // strip's longest walks end nowhere: one wave-level test then skips everything but the arithmetic.
+        const bool busy = wk >= 0;
+        const float* tab = &inv_k[busy ? wk + 1 : 0];
+        const float4 ia = *reinterpret_cast<const float4*>(__builtin_assume_aligned(tab, 16));
+        const float4 ib = *reinterpret_cast<const float4*>(__builtin_assume_aligned(tab + 4, 16));
+        const float a1 = wrem - wps;
+        const float q2 = (wps * wnum) * ia.x;
+        const float m2 = wnum + wq;
+        const float a2 = a1 - q2;
+        const float q3 = (q2 * m2) * ia.y;
+        const float m3 = m2 + wq;
+        const float a3 = a2 - q3;
+        const float q4 = (q3 * m3) * ia.z;
+        const float m4 = m3 + wq;
+        const float a4 = a3 - q4;
+        const float q5 = (q4 * m4) * ia.w;
+        const float m5 = PRNB_FMA((float)(wk + 4), wq, wmp);
+        const float b1 = a4 - q5;
+        const float q6 = (q5 * m5) * ib.x;
+        const float m6 = m5 + wq;
+        const float b2 = b1 - q6;
+        const float q7 = (q6 * m6) * ib.y;
+        const float m7 = m6 + wq;
+        const float b3 = b2 - q7;
+        const float q8 = (q7 * m7) * ib.z;
+        const float m8 = m7 + wq;
+        const float b4 = b3 - q8;
+        // the remainders only fall: one of a group's four is negative iff its last one is
+        const bool end_a = (a4 < 0.0f) || (q4 < 1.0f);
+        const bool end_b = (b4 < 0.0f) || (q8 < 1.0f);
+        if (__builtin_amdgcn_ballot_w64(busy && (end_a || end_b)) != 0ull) {
+            const int32_t at_a = (a1 < 0.0f) ? wk : ((a2 < 0.0f) ? wk + 1 : ((a3 < 0.0f) ? wk + 2 : wk + 3));
+            const int32_t at_b = (b1 < 0.0f) ? wk + 4 : ((b2 < 0.0f) ? wk + 5 : ((b3 < 0.0f) ? wk + 6 : wk + 7));
+            if (busy && (end_a || end_b)) {
+                out[(int64_t)wn * ld + wg] = end_a ? at_a : at_b;         // (>= 3)
+                wk = -1;
+                wps = 0.0f;
+            }
+        }
+        if (wk >= 0) {
+            wps = (q8 * m8) * ib.w;
+            wk += 8;
+            wnum = PRNB_FMA((float)wk, wq, wmp);
+            wrem = b4;
+        }
+    };
+    auto light_service = [&](bool drain) {
+        for (;;) {
+            const int busy = __popcll(__builtin_amdgcn_ballot_w64(wk >= 0));
+            if (busy <= 32 && (drain ? hl_top > 0 : hl_top >= 32)) light_start();
+            else if (drain ? busy > 0 : busy > 32) light_walk();
+            else break;
+        }
     };
 
     // ---- 64 list entries per wave and step, sorted onto the gamma stack and the redo stack ---------
@@ -246,7 +331,7 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
         }
         hl_top += __popcll(ml);
         while (hg_top >= 64) gamma_pass();
-        while (hl_top >= 64) light_pass();
+        if (hl_top >= 64) light_service(false);
     };
     const int64_t wave_id = (int64_t)blockIdx.x * (kHeavyBlock / 64) + wv;
     const int64_t waves = (int64_t)gridDim.x * (kHeavyBlock / 64);
@@ -291,7 +376,7 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
             }
         }
     }
-    while (hl_top > 0) light_pass();
+    light_service(true);
     while (hg_top > 0) gamma_pass();
     while (hp_top > 0) poisson_pass();
 }

@@ -64,6 +64,7 @@ struct prosstt_amd_ctx {
     uint64_t list_regions = 0;
     uint32_t list_cap = 0;
     int64_t list_groups = 0, list_strip_cells = 0;
+    int heavy_grid = 1536;       // blocks of K3h that are resident at once on this device (one round: measured best)
 };
 
 // next (start, stop) event pair of the ctx's pool
@@ -419,6 +420,10 @@ PA_EXPORT int prosstt_amd_ctx_create(int device, void* stream, prosstt_amd_ctx**
         prosstt_amd_ctx_destroy(c);
         return fail(PROSSTT_AMD_EHIP, "ctx allocation failed");
     }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k3::sample_counts_heavy_kernel, k3::kHeavyBlock, 0) == hipSuccess &&
+        per_cu > 0 && prop.multiProcessorCount > 0)
+        c->heavy_grid = per_cu * prop.multiProcessorCount;
     *out = c;
     return 0;
 }
@@ -613,8 +618,9 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
             (int32_t)geo.strip_cells, heavy);
     HIP_TRY(hipGetLastError());
     if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, c->stream));
-    // every wave takes whole regions of the list
-    k3::sample_counts_heavy_kernel<<<dim3(2048), dim3(k3::kHeavyBlock), 0, c->stream>>>(
+    // every wave takes whole regions of the list; as many blocks as the device holds at once (6 per CU: 1536 --
+    // 1024, 2048 and 3072 blocks are 7-18 us slower at C3)
+    k3::sample_counts_heavy_kernel<<<dim3((unsigned)c->heavy_grid), dim3(k3::kHeavyBlock), 0, c->stream>>>(
         heavy, (uint32_t)geo.regions, (int32_t)geo.strips, (int32_t)geo.strip_cells, A.means, rows, G, A.row_of_cell,
         A.scal, A.ga, A.gbm1, N, k0, k1, cell_offset, d_cell_index, d_out, ld_out);
     HIP_TRY(hipGetLastError());

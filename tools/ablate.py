@@ -30,7 +30,7 @@ PHILOX_OFF = ("        const prnb::Words W = philox_count_row(ph, quad_hi, quad_
               "        W.w[2] = W.w[1] ^ 0x9E3779B9u; W.w[3] = W.w[2] + W.w[0];")
 STORE_OFF = ("        if (g0 < G) {\n            if (VEC) {", "        if (g0 < G && v[0] == 12345) {\n            if (VEC) {")
 
-K3H_LAUNCH = """    k3::sample_counts_heavy_kernel<<<dim3(2048), dim3(k3::kHeavyBlock), 0, c->stream>>>(
+K3H_LAUNCH = """    k3::sample_counts_heavy_kernel<<<dim3((unsigned)c->heavy_grid), dim3(k3::kHeavyBlock), 0, c->stream>>>(
         heavy, (uint32_t)geo.regions, (int32_t)geo.strips, (int32_t)geo.strip_cells, A.means, rows, G, A.row_of_cell,
         A.scal, A.ga, A.gbm1, N, k0, k1, cell_offset, d_cell_index, d_out, ld_out);
 """
@@ -59,9 +59,9 @@ VARIANTS = {
     # K3h without the redo walks / without the gamma-Poisson samples
     "k3h_noredo": [("            light = P.valid && P.light;\n", "            light = false;\n")],
     "k3h_noheavy": [("            heavy = P.valid && !P.light;\n", "            heavy = false;\n")],
-    "k3h_grid1024": [("k3::sample_counts_heavy_kernel<<<dim3(2048),", "k3::sample_counts_heavy_kernel<<<dim3(1024),")],
-    "k3h_grid1536": [("k3::sample_counts_heavy_kernel<<<dim3(2048),", "k3::sample_counts_heavy_kernel<<<dim3(1536),")],
-    "k3h_grid3072": [("k3::sample_counts_heavy_kernel<<<dim3(2048),", "k3::sample_counts_heavy_kernel<<<dim3(3072),")],
+    "k3h_grid1024": [("k3::sample_counts_heavy_kernel<<<dim3((unsigned)c->heavy_grid),", "k3::sample_counts_heavy_kernel<<<dim3(1024),")],
+    "k3h_grid2048": [("k3::sample_counts_heavy_kernel<<<dim3((unsigned)c->heavy_grid),", "k3::sample_counts_heavy_kernel<<<dim3(2048),")],
+    "k3h_grid3072": [("k3::sample_counts_heavy_kernel<<<dim3((unsigned)c->heavy_grid),", "k3::sample_counts_heavy_kernel<<<dim3(3072),")],
     "k3h_none": [("            light = P.valid && P.light;\n", "            light = false;\n"), ("            heavy = P.valid && !P.light;\n", "            heavy = false;\n")],
     # K3h diagnosis (timing only): redo walks cut at 35 / 131 terms; every gamma / Poisson attempt accepted
     "k3h_walk35": [("    for (int k = 3;; k += 4) {\n        const float4 inv", "    for (int k = 3;; k += 4) {\n        if (k >= 35) return k;\n        const float4 inv")],
@@ -78,7 +78,7 @@ VARIANTS = {
     "k3h_feedonly": [("        while (hg_top >= 64) gamma_pass();\n        while (hl_top >= 64) light_pass();",
                       "        if (hg_top >= 64) { asm volatile(\"\" :: \"v\"(L.hg[lane].m)); hg_top = 0; }\n"
                       "        if (hl_top >= 64) { asm volatile(\"\" :: \"v\"(L.hl[lane].m)); hl_top = 0; }"),
-                     ("    while (hl_top > 0) light_pass();\n    while (hg_top > 0) gamma_pass();\n    while (hp_top > 0) poisson_pass();",
+                     ("    light_service(true);\n    while (hg_top > 0) gamma_pass();\n    while (hp_top > 0) poisson_pass();",
                       "    asm volatile(\"\" :: \"v\"(L.hl[lane].m), \"v\"(L.hg[lane].m));")],
     # K3h: redo walks replaced by one compare (parameters, Philox call and store stay)
     "k3h_nowalk": [("            const int32_t x = prnb::light_draw(P, w.w[e.g & 3], inv_k);", "            const int32_t x = (float)w.w[e.g & 3] < P.t * P.inv_u1;")],
@@ -86,17 +86,18 @@ VARIANTS = {
     "k3h_nopois": [("        while (hp_top >= 64) poisson_pass();", "        hp_top = 0;")],
     # K3h with a device printf of per-phase cycle counts of a few waves (diagnosis; printf costs registers and time)
     "k3h_trace": [("    int hg_top = 0, hp_top = 0, hl_top = 0;      // wave-uniform",
-                   "    int hg_top = 0, hp_top = 0, hl_top = 0;      // wave-uniform\n    int np_l = 0, np_g = 0, np_p = 0; long long T0 = clock64(), TW = 0, TL = 0, TG = 0, TP = 0;"),
+                   "    int hg_top = 0, hp_top = 0, hl_top = 0;      // wave-uniform\n    int np_l = 0, np_w = 0, np_g = 0, np_p = 0; long long T0 = clock64(), TW = 0, TL = 0, TG = 0, TP = 0;"),
                   ("    auto poisson_pass = [&]() {\n", "    auto poisson_pass = [&]() {\n        ++np_p; const long long tp0 = clock64();\n"),
                   ("        hp_top += __popcll(m);\n    };", "        hp_top += __popcll(m);\n        TP += clock64() - tp0;\n    };"),
                   ("    auto gamma_pass = [&]() {\n", "    auto gamma_pass = [&]() {\n        ++np_g; const long long tg0 = clock64();\n"),
                   ("        hp_top += __popcll(mp);\n        while (hp_top >= 64) poisson_pass();", "        hp_top += __popcll(mp);\n        TG += clock64() - tg0;\n        while (hp_top >= 64) poisson_pass();"),
-                  ("    auto light_pass = [&]() {\n", "    auto light_pass = [&]() {\n        ++np_l; const long long tl0 = clock64();\n"),
-                  ("        hl_top -= cnt;\n    };", "        hl_top -= cnt;\n        TL += clock64() - tl0;\n    };"),
-                  ("    while (hl_top > 0) light_pass();\n    while (hg_top > 0) gamma_pass();\n    while (hp_top > 0) poisson_pass();",
-                   "    const long long T1 = clock64();\n    while (hl_top > 0) light_pass();\n    while (hg_top > 0) gamma_pass();\n    while (hp_top > 0) poisson_pass();\n"
+                  ("    auto light_service = [&](bool drain) {\n        for (;;) {", "    auto light_service = [&](bool drain) {\n        const long long tl0 = clock64();\n        for (;;) {"),
+                  ("            if (busy <= 32 && (drain ? hl_top > 0 : hl_top >= 32)) light_start();\n            else if (drain ? busy > 0 : busy > 32) light_walk();\n            else break;\n        }",
+                   "            if (busy <= 32 && (drain ? hl_top > 0 : hl_top >= 32)) { light_start(); ++np_l; }\n            else if (drain ? busy > 0 : busy > 32) { light_walk(); ++np_w; }\n            else break;\n        }\n        TL += clock64() - tl0;"),
+                  ("    light_service(true);\n    while (hg_top > 0) gamma_pass();\n    while (hp_top > 0) poisson_pass();",
+                   "    const long long T1 = clock64();\n    light_service(true);\n    while (hg_top > 0) gamma_pass();\n    while (hp_top > 0) poisson_pass();\n"
                    "    const long long T2 = clock64();\n"
-                   "    if (lane == 0 && (wave_id % 1021) == 5) printf(\"K3HTRACE wave %lld total %lld feedloop %lld drain %lld | light %d passes %lld | gamma %d passes %lld | poisson %d passes %lld\\n\", (long long)wave_id, T2 - T0, T1 - T0, T2 - T1, np_l, TL, np_g, TG, np_p, TP);")],
+                   "    if (lane == 0 && (wave_id % 1021) == 5) printf(\"K3HTRACE wave %lld total %lld feedloop %lld drain %lld | light %d starts %d walk passes %lld | gamma %d passes %lld | poisson %d passes %lld\\n\", (long long)wave_id, T2 - T0, T1 - T0, T2 - T1, np_l, np_w, TL, np_g, TG, np_p, TP);")],
     # the library default of 10 Philox rounds instead of 7 (timing only: the model is not changed along)
     "philox10": [("constexpr int kCountRounds = 7;", "constexpr int kCountRounds = 10;")],
     # real variants (correct results): tuning constants
