@@ -1,6 +1,6 @@
 """
 -m gpu: whole matrices, not samples of them.
-  * C3 (50 000 x 20 000 = 1e9 counts, the headline workload) and C2 (5 000 x 5 000) compared with the
+  * C3 (50 000 x 20 000 = 1e9 counts, the headline workload), C4 (200 000 x 20 000) and C2 (5 000 x 5 000) compared with the
     scalar C model count for count: every class of sample, every threshold margin of the hardware-math
     evaluation, every late result and list entry of the full launch (the model runs on all host cores,
     block by block, so the host never holds more than one block of expected counts);
@@ -41,6 +41,11 @@ def test_c3_entire_matrix_equals_the_model():
 
 def test_c2_entire_matrix_equals_the_model():
     _whole_matrix_vs_model("C2", 5000, 5000)
+
+
+def test_c4_entire_matrix_equals_the_model():
+    """200 000 x 20 000 = 4e9 counts of a 32-branch tree (twice C3's share of gamma-Poisson samples)."""
+    _whole_matrix_vs_model("C4", 200000, 10000)
 
 
 def _row_checksums(X):

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Composition of the list the streaming kernel leaves to K3h on a benchmark config (GPU box).
+usage: tools/list_stats.py [C3|C4|C5] [cells]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    from prosstt_amd import device, workloads
+    from oracle import nb_model
+    cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
+    ctx = device.get_context()
+    work = workloads.build(cfg)
+    N = int(sys.argv[2]) if len(sys.argv) > 2 else work.cfg["N"]
+    pt, br, sc, rows = work.plan(N)
+    means = work.tree.device_means()
+    X = ctx.sample_counts(means, rows, sc, work.alpha, work.beta, seed=424242)
+    cells, genes, total, over = ctx.last_list(cap=1 << 25)
+    margins = (4096.0, 8192.0, 2048.0)
+    path, count, t2, close, tail = nb_model.walk_detail(means.cpu().numpy(), rows, sc, work.alpha, work.beta, 424242,
+                                                        cells, genes, margins)
+    heavy = path == 2
+    near = (path == 1) & (close < 1.5)
+    rest = (path == 1) & ~near
+    samples = N * work.tree.G
+    print("%s %d x %d: %d listed (%.3f %% of the samples, overflowed %s): gamma-Poisson %d, near a threshold %d "
+          "(mean count %.1f), other (unfinished, > 255, tail band) %d (mean count %.1f, max %d); mean count of the matrix %.2f"
+          % (cfg, N, work.tree.G, total, 100.0 * total / samples, over, heavy.sum(), near.sum(),
+             count[near].mean() if near.any() else 0, rest.sum(), count[rest].mean() if rest.any() else 0,
+             count[rest].max() if rest.any() else 0, float(X[:4096].double().mean())))
+    q = np.percentile(count[rest], [50, 90, 99]) if rest.any() else [0, 0, 0]
+    print("   unfinished walks: count percentiles 50/90/99 = %d/%d/%d" % tuple(q))
+
+
+if __name__ == "__main__":
+    main()
