@@ -1,14 +1,16 @@
 // K3h: the samples the streaming kernel (k3_stream.h) listed instead of drawing them: the
-// gamma-Poisson class of PRNB-2 (prnb_device.h; theta above 16 or -log P(X = 0) above 19, about
-// one in a thousand of a typical workload) and the few inversion walks whose hardware-math
-// evaluation came too close to a threshold (drawn here with the exact arithmetic).
+// gamma-Poisson class of PRNB-3 (prnb_device.h; theta above 16 or -log P(X = 0) above 19, one or
+// two in a thousand of a typical workload), the inversion walks whose hardware-math evaluation came
+// too close to a threshold, and the walks that were still running when their strip was done
+// (all redone here from k = 0 with the definition's arithmetic).
 // Both halves of the gamma-Poisson path are rejection samplers; run lane-per-sample
 // they would make every wave repeat each half until its unluckiest lane is accepted.  Here
 // every ATTEMPT is a stack entry: a gamma pass runs one Marsaglia-Tsang attempt for 64
 // entries of HG (accepted -> the Poisson stack HP, rejected -> back on HG with the next
 // attempt number), a Poisson pass one PTRS attempt for 64 entries of HP.  Attempts are pure
 // functions of (parameters, seed, cell, gene, attempt), so the order of evaluation cannot
-// change a result, and every pass runs with all lanes doing the same thing.
+// change a result, and every pass runs with all lanes doing the same thing.  The redo walks
+// keep their state in registers across passes, and idle lanes take the next entries (below).
 #pragma once
 #include "prnb_device.h"
 #include "k3_stream.h"
@@ -33,8 +35,8 @@ struct HeavyLds {
 };
 
 // heavy: what the streaming kernel's waves listed (k3::HeavyList; `regions` of them, laid out by
-// its block -> (gene tile, strip group) map).  If a region was too small, the list is ignored
-// and every sample of the matrix is redone here instead: slow, but any parameter set stays correct.
+// its block -> (gene tile, strip group) map).  A region that was too small (count above cap) is redone
+// here sample by sample instead: slow, but any parameter set stays correct.
 __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
     HeavyList heavy, uint32_t regions, int32_t strips, int32_t strip_cells,
     const float* __restrict__ means, int64_t rows,
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
             }
         }
         if (__builtin_amdgcn_ballot_w64(small) != 0ull) {
-            // lambda under 10: inversion (prnb::chop_down with q = 0)
+            // lambda under 10: inversion (the chop-down of prnb_device.h with q = 0)
             const uint64_t cell = cell_id(e.n);
             const prnb::Words w = prnb::philox_count((uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)e.g, 0x80000000u, k0, k1);
             const float lam = small ? e.lam : 1.0f;
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
     };
 
     // ---- inversion walks the streaming kernel left (too close to a threshold, unfinished, above 255): the
-    // definition's arithmetic (prnb::light_draw), every lane walking its own pmf eight terms per pass.  Walks
+    // definition's arithmetic, every lane walking its own pmf eight terms per pass.  Walks
     // differ in length by two orders of magnitude (the unfinished ones are the longest of their strip), so a
     // lane's walk lives in registers across passes and an idle lane takes the next entry of the redo stack:
     // a pass runs with more than half of the lanes walking, and new walks start at least 32 at a time.
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
     float wps = 0.0f, wnum = 0.0f, wrem = 0.0f, wmp = 0.0f, wq = 0.0f;
     int32_t wn = 0, wg = 0;
     auto light_start = [&]() {
-        // idle lanes take entries: parameters, P(X = 0) and the terms k = 0, 1, 2 (prnb::chop_down_grouped's first
+        // idle lanes take entries: parameters, P(X = 0) and the terms k = 0, 1, 2 (the chop-down's first
         // group); a walk that does not end there goes on in light_walk
         const unsigned long long idle_m = __builtin_amdgcn_ballot_w64(wk < 0);
         const int rank = lane_rank(idle_m);

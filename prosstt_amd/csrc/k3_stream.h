@@ -298,7 +298,7 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
     // ---- stage 3: four pmf steps for every busy lane; idle lanes pull from S2 ------------------
     // A lane is idle iff k == kIdle, and an idle lane keeps ps = 0: its "count" k + 3 is negative,
     // which keeps it out of every mask below, so the arithmetic never asks which lanes are busy.
-    // PRNB-3's walk (prnb::chop_down): the terms are subtracted from a binary32 remainder, the count
+    // PRNB-3's walk (the chop-down of prnb_device.h): the terms are subtracted from a binary32 remainder, the count
     // is the first k whose subtraction leaves it negative; when a group of four ends without that
     // and its last term is under 1 (the pmf has fallen under 2^-32) the count is the group's last k.
     // A walk enters at k = 3 and advances by 4: the four reciprocals 1/(k+1)..1/(k+4) are one aligned

@@ -1,5 +1,7 @@
-// PRNB-3 count sampler, device side (gfx950).  DESIGN.md section 4 defines it; this is
-// the product implementation.  Replaces, per (cell, gene):
+// PRNB-3 count sampler, device side (gfx950).  DESIGN.md section 4 defines it; this header holds
+// its building blocks -- the counter generator, the binary32 functions of the definition, the
+// parameters of a sample, the inversion walk -- that the kernels (k3_stream.h, k3_heavy.h,
+// nb_params_kernel) are made of.  Replaces, per (cell, gene):
 //   count_model.get_pr_umi                 /root/reference/prosstt/count_model.py:131-161
 //   scipy.stats.nbinom(n=r,p=1-p).rvs()    /root/reference/prosstt/simulation.py:647-648
 //
@@ -175,66 +177,18 @@ __device__ __forceinline__ float unif(uint32_t w) { return ((float)w + 0.5f) * 2
 
 __device__ __forceinline__ float det_sqrt(float x) { return __builtin_sqrtf(x); }  // IEEE (see Makefile)
 
-// Inversion by chop-down on a binary32 remainder; inv_k = LDS table of 1/k (0 sentinel at the end).
+// Inversion by chop-down on a binary32 remainder; inv_k = LDS table of 1/k
+// (16-byte aligned, 0 from the sentinel k = KTAB-1 on, 8 more zeros behind it).
 // P(k+1) = P(k) * num_k / (k+1), num_k = mp + k*q, carried scaled by 2^32.  The remainder starts as
 // (float)w and every term is subtracted from it; the draw is the first k whose subtraction leaves it
 // negative.  Terms come in groups (k = 0..2, then four at a time: the streaming kernel's passes); when
 // a group ends without a negative remainder and its last term is below 1 (the pmf has fallen under
-// 2^-32 before w is used up: mass lost to rounding, < 1e-6) the draw is that group's last k.
-__device__ __forceinline__ int32_t chop_down(uint32_t w, float p0, float mp, float q,
-                                             const float* inv_k)
-{
-    float ps = __builtin_fminf(p0, 0.99999994f) * 4294967296.0f;
-    float num = mp;
-    float rem = (float)w;
-    int k = 0;
-    for (;;) {
-        rem = rem - ps;
-        if (rem < 0.0f) return k;
-        if ((k & 3) == 2 && ps < 1.0f) return k;
-        ps = (ps * num) * inv_k[k + 1];
-        ++k;
-        // numerator mp + k*q: one fma where a group of four terms starts (k = 3, 7, ...), by
-        // addition inside a group (the rounding errors of a running sum would pile up over a long walk)
-        num = ((k & 3) == 3) ? PRNB_FMA((float)k, q, mp) : num + q;
-    }
-}
-
-// chop_down with the groups of four terms unrolled: the same operations in the same order (so the
-// same result), but one aligned 16-byte read of four reciprocals per group instead of a dependent
-// 4-byte read per term.  inv_k must be 16-byte aligned with at least 4 zero entries behind the
-// sentinel (K3h's redo walks run hundreds of terms, each waiting for its read).
-__device__ __forceinline__ int32_t chop_down_grouped(uint32_t w, float p0, float mp, float q,
-                                                     const float* inv_k)
-{
-    float ps = __builtin_fminf(p0, 0.99999994f) * 4294967296.0f;
-    float num = mp;
-    float rem = (float)w;
-    // k = 0, 1, 2 as chop_down does them
-    for (int k = 0; k < 3; ++k) {
-        rem = rem - ps;
-        if (rem < 0.0f) return k;
-        if (k == 2 && ps < 1.0f) return 2;
-        ps = (ps * num) * inv_k[k + 1];
-        num = (k == 2) ? PRNB_FMA(3.0f, q, mp) : num + q;
-    }
-    for (int k = 3;; k += 4) {
-        const float4 inv = *reinterpret_cast<const float4*>(__builtin_assume_aligned(inv_k + k + 1, 16));
-        const float iv[4] = {inv.x, inv.y, inv.z, inv.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            rem = rem - ps;
-            if (rem < 0.0f) return k + j;
-            if (j == 3 && ps < 1.0f) return k + 3;
-            ps = (ps * num) * iv[j];
-            num = (j == 3) ? PRNB_FMA((float)(k + 4), q, mp) : num + q;
-        }
-    }
-}
-
-// chop_down for a whole wave at once (K3h): every lane carries its own walk, all lanes are at the same k.
-// The same operations in the same order per lane as chop_down_grouped, but a group of four terms is
-// evaluated without a branch per term (terms behind a lane's draw are computed and ignored), and the
+// 2^-32 before w is used up: mass lost to rounding, < 1e-6) the draw is that group's last k.  The numerator
+// mp + k*q is ONE fma where a group of four terms starts (k = 3, 7, ...) and grows by addition inside a
+// group (the rounding errors of a running sum would pile up over a long walk).
+//
+// For a whole wave at once (K3h): every lane carries its own walk, all lanes are at the same k.  A group
+// of four terms is evaluated without a branch per term (terms behind a lane's draw are computed and ignored), and the
 // reciprocals of two groups come from one wave-uniform LDS round trip.  Must be called by all
 // lanes of the wave (`active` = this lane has a walk); returns when no lane is walking any more.
 __device__ __forceinline__ int32_t chop_down_wave(bool active, uint32_t w, float p0, float mp, float q,
@@ -302,91 +256,6 @@ __device__ __forceinline__ float logfact_small(int k)
     }
 }
 
-__device__ __forceinline__ int32_t poisson_draw(float lam, uint32_t c0, uint32_t c1, uint32_t gene,
-                                             uint32_t k0, uint32_t k1, const float* inv_k)
-{
-    if (!(lam > 0.0f)) return 0;
-    if (lam < kPoisInv) {
-        const Words w = philox_count(c0, c1, gene, 0x80000000u, k0, k1);
-        return chop_down(w.w[0], det_exp(-lam), lam, 0.0f, inv_k);
-    }
-    const float slam = det_sqrt(lam);
-    if (!(lam < kLamBig)) {
-        const Words w = philox_count(c0, c1, gene, 0x80000000u, k0, k1);
-        const float z = det_sqrt(-2.0f * det_log(unif(w.w[0]))) * det_cos2pi(w.w[1]);
-        const float kf = __builtin_floorf(PRNB_FMA(slam, z, lam) + 0.5f);
-        return (int32_t)__builtin_fminf(__builtin_fmaxf(kf, 0.0f), 2147483520.0f);
-    }
-    // PTRS (Hoermann 1993)
-    const float bb = PRNB_FMA(2.53f, slam, 0.931f);
-    const float aa = PRNB_FMA(0.02483f, bb, -0.059f);
-    const float invalpha = PRNB_FMA(1.1328f, det_rcp(bb - 3.4f), 1.1239f);
-    const float vr = PRNB_FMA(-3.6224f, det_rcp(bb - 2.0f), 0.9277f);
-    float kf = __builtin_floorf(lam);
-    Words w;
-    for (int j = 0; j < 2 * kMaxTries; ++j) {
-        if ((j & 1) == 0) w = philox_count(c0, c1, gene, 0x80000000u + (uint32_t)(j >> 1), k0, k1);
-        const uint32_t wu = (j & 1) ? w.w[2] : w.w[0];
-        const uint32_t wv = (j & 1) ? w.w[3] : w.w[1];
-        const float U = unif(wu) - 0.5f;
-        const float V = unif(wv);
-        const float us = __builtin_fmaxf(0.5f - __builtin_fabsf(U), 5.8207661e-11f);
-        const float rus = det_rcp(us);
-        kf = __builtin_floorf(PRNB_FMA(PRNB_FMA(2.0f * aa, rus, bb), U, lam + 0.43f));
-        if (us >= 0.07f && V <= vr) break;
-        if (kf < 0.0f || (us < 0.013f && V > us)) { kf = __builtin_floorf(lam); continue; }
-        const float lhs = det_log((V * invalpha) * det_rcp(PRNB_FMA(aa * rus, rus, bb)));
-        float rhs;
-        if (kf < 10.0f) {
-            rhs = PRNB_FMA(kf, det_log(lam), -lam) - logfact_small((int)kf);
-        } else {
-            const float rk = det_rcp(kf);
-            const float d = (lam - kf) * rk;
-            const float lp = det_log1pmx(d, lam * rk);
-            const float st = rk * PRNB_FMA(-0.0027777778f, rk * rk, 0.083333336f);
-            rhs = PRNB_FMA(kf, lp, PRNB_FMA(-0.5f, det_log(6.2831855f * kf), -st));
-        }
-        if (lhs <= rhs) break;
-        kf = __builtin_floorf(lam);
-    }
-    return (int32_t)__builtin_fminf(__builtin_fmaxf(kf, 0.0f), 2147483520.0f);
-}
-
-__device__ __forceinline__ float gamma_scaled(float r, float theta, uint32_t c0, uint32_t c1,
-                                           uint32_t gene, uint32_t k0, uint32_t k1)
-{
-    const bool boost = r < 1.0f;
-    const float rr = boost ? r + 1.0f : r;
-    const float dd = rr - 0.33333334f;
-    const float cc = det_rcp(3.0f * det_sqrt(dd));
-    float v = 1.0f;
-    Words w;
-    for (int i = 0; i < kMaxTries; ++i) {
-        const bool last = (i == kMaxTries - 1);
-        w = philox_count(c0, c1, gene, 1u + (uint32_t)i, k0, k1);
-        const float x = det_sqrt(-2.0f * det_log(unif(w.w[0]))) * det_cos2pi(w.w[1]);
-        const float t = cc * x;
-        const float v1 = 1.0f + t;
-        if (!(v1 > 0.0f)) {
-            v = 1.0f;
-            if (last) break;
-            continue;
-        }
-        v = (v1 * v1) * v1;
-        if (last) break;
-        const float u = unif(w.w[2]);
-        const float x2 = x * x;
-        if (u < PRNB_FMA(-0.0331f, x2 * x2, 1.0f)) break;
-        const float t2 = t * t;
-        const float h = PRNB_FMA(3.0f, det_log1pmx(t, v1), PRNB_FMA(-t2, t, -3.0f * t2));
-        if (det_log(u) < PRNB_FMA(dd, h, 0.5f * x2)) break;
-    }
-    float g = dd * v;
-    if (boost) g = g * det_exp(det_log(unif(w.w[3])) * det_rcp(r));
-    return theta * g;
-}
-
-// Per-sample parameters shared by the light and heavy paths.
 struct Params {
     float m, theta, inv_th, inv_u1;
     float t;      // -log P(X = 0) = m * log1p(theta) / theta
@@ -432,24 +301,6 @@ __device__ __forceinline__ Params make_params_m(float m, float a, float bm1)
     P.t = P.m * (det_log1p(theta) * P.inv_th);
     P.light = (theta <= kLightTheta) && (P.t <= kLightT);
     return P;
-}
-
-// Light path: NB inversion with one 32-bit uniform.
-__device__ __forceinline__ int32_t light_draw(const Params& P, uint32_t w, const float* inv_k)
-{
-    const float q = P.theta * P.inv_u1;
-    return chop_down_grouped(w, det_exp(-P.t), P.m * P.inv_u1, q, inv_k);
-}
-
-// Heavy path: Poisson(theta * Gamma(r)).
-__device__ __forceinline__ int32_t heavy_draw(const Params& P, uint32_t c0, uint32_t c1,
-                                              uint32_t gene, uint32_t k0, uint32_t k1,
-                                              const float* inv_k)
-{
-    const float r = P.m * P.inv_th;
-    if (!(r >= kRMin)) return 0;
-    const float lam = gamma_scaled(r, P.theta, c0, c1, gene, k0, k1);
-    return poisson_draw(lam, c0, c1, gene, k0, k1, inv_k);
 }
 
 }  // namespace prnb
