@@ -194,9 +194,10 @@ static Entry entries[] = { LIST(ENT) };
 int main(int argc, char** argv)
 {
     const int tpb = argc > 1 ? atoi(argv[1]) : 1024;
-    const char* only = argc > 2 ? argv[2] : nullptr;
-    const int blocks = 256, iters = 2000, waves = blocks * tpb / 64;
-    printf("# %d threads per block, one block per CU: %d waves per SIMD; %d groups of 8 statements per wave\n", tpb, tpb / 256, iters);
+    const char* only = (argc > 2 && argv[2][0]) ? argv[2] : nullptr;
+    const int per_cu = argc > 3 ? atoi(argv[3]) : 1;          // blocks per CU (2 x 1024 threads: 8 waves per SIMD)
+    const int blocks = 256 * per_cu, iters = 2000, waves = blocks * tpb / 64;
+    printf("# %d threads per block, %d block(s) per CU: %d waves per SIMD; %d groups of 8 statements per wave\n", tpb, per_cu, per_cu * tpb / 256, iters);
     printf("# cycles per instruction per SIMD = wave loop cycles / instructions per wave / waves per SIMD\n");
     printf("# %-58s %8s | %7s %7s %7s | %7s | %6s %6s\n", "kind", "kern ms", "fastest", "median", "slowest", "kernel", "MHz", "spread");
     uint32_t* out; Stamp* st;
@@ -222,7 +223,7 @@ int main(int argc, char** argv)
         }
         mhz /= waves;
         std::sort(cyc.begin(), cyc.end());
-        const double instr = 8.0 * iters * e.per_group, wps = tpb / 256.0;
+        const double instr = 8.0 * iters * e.per_group, wps = per_cu * tpb / 256.0;
         // whole kernel: first loop start to last loop end, in shader cycles at the measured clock
         const double kern_cyc = (double)(tmax - tmin) / 100.0 * mhz;
         printf("  %-58s %8.3f | %7.2f %7.2f %7.2f | %7.2f | %6.0f %6.2f\n", e.desc, ms,
