@@ -104,6 +104,9 @@ VARIANTS = {
     "run16": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 16;")],
     # the strip-end drain runs to the last walk (nothing is left to K3h there)
     "nobail": [("constexpr int kBail = 6;", "constexpr int kBail = 0;")],
+    "bail10": [("constexpr int kBail = 6;", "constexpr int kBail = 10;")],
+    "bail16": [("constexpr int kBail = 6;", "constexpr int kBail = 16;")],
+    "bail3": [("constexpr int kBail = 6;", "constexpr int kBail = 3;")],
     "strip128": [("    g.strip_cells = k3::kStripCells / 2;", "    g.strip_cells = k3::kStripCells;")],
     "strip32": [("    g.strip_cells = k3::kStripCells / 2;", "    g.strip_cells = k3::kStripCells / 4;")],
     # plain instead of non-temporal row stores
