@@ -8,6 +8,7 @@ publishes no tests or fixtures of its own, so these vector
 pin for every parity claim.
 
     PYTHONDONTWRITEBYTECODE=1 python3 tests/golden/make_golden.py
+    PROSSTT_GOLDEN_OUT=/tmp/check python3 tests/golden/make_golden.py      # regenerate elsewhere, then compare
 
 Everything stored is data: inputs (seeds, topologies, parameters) and the
 reference's outputs.  No reference source text is stored.
@@ -31,7 +32,7 @@ from prosstt import simulation as rsim                 # noqa: E402
 from prosstt import sim_utils as rsut                  # noqa: E402
 from prosstt import count_model as rcm                 # noqa: E402
 
-OUT = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("PROSSTT_GOLDEN_OUT") or os.path.dirname(os.path.abspath(__file__))   # (a scratch directory to re-check the committed files)
 
 # The five topologies of SURVEY section 8(c) G3/G5 (+ an unequal-length one).
 TREES = {
