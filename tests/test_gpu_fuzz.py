@@ -1,0 +1,67 @@
+"""
+-m gpu: seeded random shapes and parameter mixes against the scalar C model, count for count.  What the
+fixed cases of test_gpu_sampler.py pick by hand is drawn here: ragged N and G (one cell, one gene, G % 4 != 0,
+strips and tiles one short of / one past a boundary), padded output rows (ld_out > G), arbitrary global cell
+ids, dense and sparse gamma-Poisson genes (list regions that overflow next to regions that do not), long
+inversion walks, library-size factors over six orders of magnitude, degenerate genes.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(rng):
+    edge = [1, 2, 3, 4, 5, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 513, 1000]
+    N = int(rng.choice(edge + [int(rng.integers(1, 1500))]))
+    G = int(rng.choice(edge + [int(rng.integers(1, 1500))]))
+    rows = int(rng.integers(1, 40))
+    base = np.exp(rng.normal(rng.uniform(-1.0, 2.5), rng.uniform(0.3, 1.6), G))
+    means = (np.exp(rng.normal(0.0, 0.5, (rows, G))) * base).astype(np.float32)
+    kind = rng.integers(0, 5)
+    if kind == 1:                                   # a dense block of gamma-Poisson genes somewhere
+        lo = int(rng.integers(0, G))
+        means[:, lo:lo + int(rng.integers(1, 300))] *= float(rng.choice([50.0, 200.0, 3000.0]))
+    elif kind == 2:                                 # sparse gamma-Poisson genes
+        means[:, rng.random(G) < rng.uniform(0.0, 0.08)] *= 200.0
+    elif kind == 3:                                 # long inversion walks
+        means = np.exp(rng.uniform(np.log(10), np.log(110), (rows, G))).astype(np.float32)
+    roc = rng.integers(0, rows, N).astype(np.int32)
+    sc = np.exp(rng.normal(0, rng.choice([0.1, 0.7, 3.0]), N))
+    al = np.exp(rng.normal(np.log(0.2), np.log(1.5), G))
+    be = np.exp(rng.normal(0.0, np.log(1.5), G)) + 1
+    if kind == 3:
+        al, be = rng.uniform(0.0, 0.15, G), rng.uniform(1.5, 6.0, G)
+    if kind == 4:                                   # degenerate genes: Poisson limit, zero variance parameters
+        al[rng.random(G) < 0.3] = 0.0
+        be[rng.random(G) < 0.3] = 1.0 + 1e-8
+        be[rng.random(G) < 0.1] = 1.0
+    return means, roc, sc, al, be
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PROSSTT_FUZZ_CASES", "150"))))
+def test_random_case_equals_the_model(seed):
+    import torch
+    from prosstt_amd import device
+    from oracle import nb_model
+    ctx = device.get_context()
+    rng = np.random.default_rng(1000 + seed)
+    means, roc, sc, al, be = _case(rng)
+    N, G = len(roc), means.shape[1]
+    draw_seed = int(rng.integers(0, 2 ** 63))
+    mode = seed % 3
+    if mode == 0:                                   # contiguous global ids from an offset
+        offset = int(rng.integers(0, 2 ** 40))
+        got = ctx.sample_counts(means, roc, sc, al, be, seed=draw_seed, cell_offset=offset, check_domain=False)
+        want = nb_model.sample_counts(means, roc, sc, al, be, draw_seed, cell_offset=offset)
+    elif mode == 1:                                 # arbitrary global ids (a shard of a larger plan)
+        ids = np.sort(rng.choice(10 * N + 5, N, replace=False)).astype(np.int64)
+        got = ctx.sample_counts(means, roc, sc, al, be, seed=draw_seed, cell_index=ids, check_domain=False)
+        want = nb_model.sample_counts(means, roc, sc, al, be, draw_seed, cell_index=ids)
+    else:                                           # rows of a wider output buffer (ld_out > G), offset 0
+        pad = int(rng.choice([1, 3, 4, 60]))
+        buf = torch.full((N, G + pad), -7, dtype=torch.int32, device=ctx.torch_device)
+        got = ctx.sample_counts(means, roc, sc, al, be, seed=draw_seed, out=buf[:, :G], check_domain=False)
+        assert bool((buf[:, G:] == -7).all()), "the padding of the output rows was written"
+        want = nb_model.sample_counts(means, roc, sc, al, be, draw_seed)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
