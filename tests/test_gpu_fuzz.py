@@ -65,3 +65,34 @@ def test_random_case_equals_the_model(seed):
         assert bool((buf[:, G:] == -7).all()), "the padding of the output rows was written"
         want = nb_model.sample_counts(means, roc, sc, al, be, draw_seed)
     np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_lineage_attempt_batches_match_numpy(seed):
+    """K2a over random shapes: B attempts x T steps x K programs against G genes and 0..3 siblings of other
+    lengths -- the maximum of programs @ H and the per-sibling counts of anticorrelated genes (simulation.py:269-272,
+    sim_utils.py:145-168) against binary64 numpy; a count may differ by the genes whose r is 0 to rounding."""
+    import torch
+    from prosstt_amd import device
+    from oracle import ref_numpy
+    ctx = device.get_context()
+    rng = np.random.default_rng(7000 + seed)
+    B, T, K = int(rng.integers(1, 20)), int(rng.integers(2, 70)), int(rng.integers(1, 45))
+    G = int(rng.choice([1, 2, 63, 64, 65, 255, 257, 1000, int(rng.integers(1, 4000))]))
+    walk = lambda t: rng.normal(0, 0.1, (t, K)).cumsum(axis=0) + np.log(rng.uniform(0.05, 1.5, K))
+    P = np.stack([walk(T) for _ in range(B)])
+    H = rng.standard_gamma(0.05, (K, G))
+    if G > 3:
+        H[:, G // 3] = 0.0                           # a constant gene: r is NaN, never < 0
+    sibs = [walk(int(rng.integers(2, 80))) for _ in range(int(rng.integers(0, 4)))]
+    tops, counts = ctx.lineage_attempt_batch(P, torch.as_tensor(H, device=ctx.torch_device), sibs)
+    assert tops.shape == (B,) and counts.shape == (B, len(sibs))
+    for b in range(B):
+        rel = P[b] @ H
+        assert tops[b] == pytest.approx(rel.max(), rel=1e-12, abs=1e-12)
+        for j, S in enumerate(sibs):
+            c = min(T, S.shape[0])
+            r = ref_numpy.pearson_columns(rel[:c], (S @ H)[:c])
+            with np.errstate(invalid="ignore"):
+                want, ties = int(np.sum(r < 0)), int(np.sum(np.abs(r) < 1e-12))
+            assert abs(int(counts[b, j]) - want) <= ties
