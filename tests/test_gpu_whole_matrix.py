@@ -32,7 +32,38 @@ def _whole_matrix_vs_model(name, n_cells, block):
         got = X[sl].cpu().numpy()
         differing += int((got != want).sum())
     assert differing == 0, "%d of %d counts differ from the model" % (differing, X.numel())
-    print("[%s] %d x %d counts equal the model's" % (name, n_cells, work.tree.G))
+    # and the reference's law at this scale: first two moments of the whole matrix against mean mu and variance
+    # v = alpha*mu^2 + beta*mu (count_model.py:131-161), in binary64 on the device, each against its own sampling
+    # error: Var[X] = v, Var[(X - mu)^2] = kappa4 + 2 v^2 with the NB's kappa4 = v (1 + 6 theta + 6 theta^2),
+    # theta = v/mu - 1 (a few high-expression genes carry most of both sums, so the errors are not tiny)
+    d_rows = torch.as_tensor(rows, device=X.device).long()
+    d_sc = torch.as_tensor(sc, device=X.device)
+    d_al = torch.as_tensor(work.alpha, device=X.device)
+    d_be = torch.as_tensor(work.beta, device=X.device)
+    sx = smu = sdev = svar = sk = chi = chi_var = chi_n = 0.0
+    for lo in range(0, n_cells, 2048):                # bounded temporaries
+        sl = slice(lo, min(lo + 2048, n_cells))
+        mu = means[d_rows[sl]].double() * d_sc[sl, None]
+        x = X[sl].double()
+        v = d_al * mu * mu + d_be * mu
+        theta = v / mu - 1.0
+        sx += float(x.sum()); smu += float(mu.sum())
+        sdev += float(((x - mu) ** 2).sum()); svar += float(v.sum())
+        k4 = v * (1.0 + 6.0 * theta + 6.0 * theta * theta)
+        sk += float((k4 + 2.0 * v * v).sum())
+        # the same per sample in units of its own variance, over the samples with mu >= 0.05 (below that a sample's
+        # term is almost always ~0 and rarely 1/v: the sum would hang on a handful of them): every sample counts
+        # alike (mean 1, variance 2 + kappa4/v^2)
+        big = mu >= 0.05
+        chi += float(((x - mu) ** 2 / v)[big].sum()); chi_var += float((2.0 + k4 / (v * v))[big].sum()); chi_n += float(big.sum())
+    z1 = (sx - smu) / svar ** 0.5
+    z2 = (sdev - svar) / sk ** 0.5
+    n = chi_n
+    z3 = (chi - n) / chi_var ** 0.5
+    assert abs(z1) < 5 and abs(z2) < 5 and abs(z3) < 5, (z1, z2, z3, sx / smu, sdev / svar, chi / n)
+    print("[%s] %d x %d counts equal the model's; sum(X)/sum(mu) = %.5f (z = %.2f), sum((X-mu)^2)/sum(alpha mu^2 + beta mu) = %.5f "
+          "(z = %.2f), mean((X-mu)^2/v) over the %.3g samples with mu >= 0.05 = %.6f (z = %.2f)"
+          % (name, n_cells, work.tree.G, sx / smu, z1, sdev / svar, z2, n, chi / n, z3))
 
 
 def test_c3_entire_matrix_equals_the_model():
