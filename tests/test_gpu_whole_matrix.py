@@ -41,6 +41,7 @@ def _whole_matrix_vs_model(name, n_cells, block):
     d_al = torch.as_tensor(work.alpha, device=X.device)
     d_be = torch.as_tensor(work.beta, device=X.device)
     sx = smu = sdev = svar = sk = chi = chi_var = chi_n = 0.0
+    obs_k, exp_k, var_k = (torch.zeros(10, dtype=torch.float64, device=X.device) for _ in range(3))
     for lo in range(0, n_cells, 2048):                # bounded temporaries
         sl = slice(lo, min(lo + 2048, n_cells))
         mu = means[d_rows[sl]].double() * d_sc[sl, None]
@@ -55,12 +56,26 @@ def _whole_matrix_vs_model(name, n_cells, block):
         # term is almost always ~0 and rarely 1/v: the sum would hang on a handful of them): every sample counts
         # alike (mean 1, variance 2 + kappa4/v^2)
         big = mu >= 0.05
+        r = mu / theta
+        pk = torch.exp(-r * torch.log1p(theta))
+        ratio = theta / (1.0 + theta)
+        for k in range(10):
+            obs_k[k] += (X[sl] == k).sum()
+            exp_k[k] += pk.sum(); var_k[k] += (pk * (1.0 - pk)).sum()
+            pk = pk * (r + k) / (k + 1.0) * ratio
         chi += float(((x - mu) ** 2 / v)[big].sum()); chi_var += float((2.0 + k4 / (v * v))[big].sum()); chi_n += float(big.sum())
+    # and the histogram of the whole matrix against the pmf itself: for k = 0..9 the number of samples equal to k
+    # against the sum of P(X = k) over all samples (binary64 recurrence from P(X = 0) = (1+theta)^(-mu/theta)), within
+    # its sampling error sqrt(sum p (1 - p)); at 1e9 samples that resolves 3e-5 of a probability
+    zk = (obs_k - exp_k) / var_k.sqrt()
+    assert float(zk.abs().max()) < 5, (zk.tolist(), (obs_k / exp_k).tolist())
     z1 = (sx - smu) / svar ** 0.5
     z2 = (sdev - svar) / sk ** 0.5
     n = chi_n
     z3 = (chi - n) / chi_var ** 0.5
     assert abs(z1) < 5 and abs(z2) < 5 and abs(z3) < 5, (z1, z2, z3, sx / smu, sdev / svar, chi / n)
+    print("[%s] histogram k = 0..9, observed/expected - 1: %s; z: %s" % (name, ["%.1e" % v for v in (obs_k / exp_k - 1).tolist()],
+                                                                        ["%.1f" % v for v in zk.tolist()]))
     print("[%s] %d x %d counts equal the model's; sum(X)/sum(mu) = %.5f (z = %.2f), sum((X-mu)^2)/sum(alpha mu^2 + beta mu) = %.5f "
           "(z = %.2f), mean((X-mu)^2/v) over the %.3g samples with mu >= 0.05 = %.6f (z = %.2f)"
           % (name, n_cells, work.tree.G, sx / smu, z1, sdev / svar, z2, n, chi / n, z3))
