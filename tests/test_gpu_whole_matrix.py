@@ -41,6 +41,7 @@ def _whole_matrix_vs_model(name, n_cells, block):
     d_al = torch.as_tensor(work.alpha, device=X.device)
     d_be = torch.as_tensor(work.beta, device=X.device)
     sx = smu = sdev = svar = sk = chi = chi_var = chi_n = 0.0
+    h_n = h_x = h_mu = h_v = h_chi = h_chi_var = h_zero = h_p0 = h_p0_var = 0.0
     obs_k, exp_k, var_k = (torch.zeros(10, dtype=torch.float64, device=X.device) for _ in range(3))
     for lo in range(0, n_cells, 2048):                # bounded temporaries
         sl = slice(lo, min(lo + 2048, n_cells))
@@ -57,6 +58,13 @@ def _whole_matrix_vs_model(name, n_cells, block):
         # alike (mean 1, variance 2 + kappa4/v^2)
         big = mu >= 0.05
         r = mu / theta
+        # the gamma-Poisson class on its own (theta > 16 or -log P(0) > 19: 0.1-0.4 % of the samples, drawn by K3h)
+        hv = (theta > 16.0) | (r * torch.log1p(theta) > 19.0)
+        h_n += float(hv.sum()); h_x += float(x[hv].sum()); h_mu += float(mu[hv].sum()); h_v += float(v[hv].sum())
+        h_chi += float(((x - mu) ** 2 / v)[hv].sum()); h_chi_var += float((2.0 + k4 / (v * v))[hv].sum())
+        h_zero += float((x[hv] == 0).sum())
+        p0h = torch.exp(-r * torch.log1p(theta))[hv]
+        h_p0 += float(p0h.sum()); h_p0_var += float((p0h * (1.0 - p0h)).sum())
         pk = torch.exp(-r * torch.log1p(theta))
         ratio = theta / (1.0 + theta)
         for k in range(10):
@@ -69,6 +77,10 @@ def _whole_matrix_vs_model(name, n_cells, block):
     # its sampling error sqrt(sum p (1 - p)); at 1e9 samples that resolves 3e-5 of a probability
     zk = (obs_k - exp_k) / var_k.sqrt()
     assert float(zk.abs().max()) < 5, (zk.tolist(), (obs_k / exp_k).tolist())
+    zh = ((h_x - h_mu) / h_v ** 0.5, (h_chi - h_n) / h_chi_var ** 0.5, (h_zero - h_p0) / max(h_p0_var, 1e-300) ** 0.5)
+    assert h_n > 1e4 and max(abs(z) for z in zh) < 5, (h_n, zh)
+    print("[%s] gamma-Poisson class alone, %.3g samples: sum(X)/sum(mu) = %.5f (z = %.2f), mean((X-mu)^2/v) = %.5f (z = %.2f), "
+          "zeros observed/expected = %.5f (z = %.2f)" % (name, h_n, h_x / h_mu, zh[0], h_chi / h_n, zh[1], h_zero / max(h_p0, 1e-300), zh[2]))
     z1 = (sx - smu) / svar ** 0.5
     z2 = (sdev - svar) / sk ** 0.5
     n = chi_n
