@@ -107,6 +107,8 @@ VARIANTS = {
     "bail10": [("constexpr int kBail = 6;", "constexpr int kBail = 10;")],
     "bail16": [("constexpr int kBail = 6;", "constexpr int kBail = 16;")],
     "bail3": [("constexpr int kBail = 6;", "constexpr int kBail = 3;")],
+    "bail24": [("constexpr int kBail = 6;", "constexpr int kBail = 24;")],
+    "bail32": [("constexpr int kBail = 6;", "constexpr int kBail = 32;")],
     "strip128": [("    g.strip_cells = k3::kStripCells / 2;", "    g.strip_cells = k3::kStripCells;")],
     "strip32": [("    g.strip_cells = k3::kStripCells / 2;", "    g.strip_cells = k3::kStripCells / 4;")],
     # plain instead of non-temporal row stores
