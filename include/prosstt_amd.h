@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PROSSTT_AMD_VERSION 300 /* 0.3.0: PRNB-3 sampler (binary32 remainder), prosstt_amd_last_list; the tile-per-block kernel is gone */
+#define PROSSTT_AMD_VERSION 310 /* 0.3.1: PRNB-4 sampler (binary32 remainder, one-fma term ratio), prosstt_amd_last_list; the tile-per-block kernel is gone */
 
 enum {
     PROSSTT_AMD_OK = 0,
@@ -66,7 +66,7 @@ int prosstt_amd_last_kernel_ms(prosstt_amd_ctx* ctx, float* ms);
  *   scipy.stats.nbinom(n=r, p=1-p).rvs()        simulation.py:647-648
  * out[n*ld_out + g] ~ NB(mean m, variance alpha*m^2 + beta*m),
  *   m = means[row_of_cell[n]*G + g] * scaling[n],
- * drawn by the PRNB-3 counter-based sampler keyed by
+ * drawn by the PRNB-4 counter-based sampler keyed by
  * (seed, global cell id, g); the global id of cell n is cell_index[n] when
  * cell_index is given, cell_offset + n otherwise.
  *   means        [rows][G] binary32, row-major: the (branch, time, gene) mean tensor

@@ -3,7 +3,7 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library; prosstt_amd never does.
  *
- * Scalar C model of the *device* count sampler ("PRNB-3"): the
+ * Scalar C model of the *device* count sampler ("PRNB-4"): the
  * fused  gather * scale -> get_pr_umi -> negative-binomial draw  that replaces
  *   simulation.draw_counts           /root/reference/prosstt/simulation.py:602-651
  *   count_model.get_pr_umi           /root/reference/prosstt/count_model.py:131-161
@@ -11,7 +11,7 @@
  *
  * The reference draws from numpy's sequential MT19937 stream, which no
  * parallel device can reproduce (SURVEY.md section 0 "RNG reality check"); the count
- * law, not the stream, is the contract.  PRNB-3 is a counter-based sampler of
+ * law, not the stream, is the contract.  PRNB-4 is a counter-based sampler of
  * the SAME law  NB(n = r, p = 1-p)  with  theta = a*m + b - 1,  r = m/theta,
  * p = theta/(1+theta)  (the algebraic form of get_pr_umi), defined so that
  * every sample is a pure function of (M, s, a, b, seed, cell, gene):
@@ -36,7 +36,7 @@
 #define PRNB_CLONES
 #endif
 
-/* ---- sampler constants (part of the PRNB-3 definition) ------------------ */
+/* ---- sampler constants (part of the PRNB-4 definition) ------------------ */
 #define PRNB_LIGHT_T      19.0f        /* inversion iff theta <= 16 and t = -log P(X=0) <= 19: P0 * 2^32 >= 24 */
 #define PRNB_LIGHT_THETA  16.0f        /* tail ratio theta/(1+theta) <= 16/17: the walk ends far below the 1/k table's 511 entries */
 #define PRNB_THETA_MIN    8.6736174e-19f /* 2^-60: below this NB == Poisson in binary32 */
@@ -201,24 +201,23 @@ __attribute__((constructor)) static void prnb_init(void)
  * below 1 -- the pmf has fallen under 2^-32: mass lost to rounding, < 1e-6, or the 0 sentinel that ends
  * the 1/k table -- the draw is that group's last k.
  * (PRNB-2 kept the remainder as a 32-bit integer and subtracted floor(term): one float->int conversion
- * per term; PRNB-3's terms are pure binary32 multiply/add/subtract, which the device's float pipe runs
- * beside its integer pipe.)
+ * per term; PRNB-3's terms were pure binary32 multiply/add/subtract, four operations each; PRNB-4 forms the
+ * term's ratio with one fma: three.  The cancellation in q + (mp - q)/(k+1) when mp << q costs at most
+ * ulp(q) of the ratio, 6e-8 * q/mp of the terms k >= 2 relative -- times P(X >= 2) that is under 2e-7 absolute.)
  */
 static inline int32_t chop_down(uint32_t w, float p0, float mp, float q)
 {
     float ps = fminf(p0, 0.99999994f) * 4294967296.0f;      /* exact scaling */
-    float num = mp;
+    const float d = mp - q;
     float rem = (float)w;
     for (int k = 0; ; ) {
         rem = rem - ps;
         if (rem < 0.0f) return k;
         if ((k & 3) == 2 && ps < 1.0f) return k;          /* k = 2, 6, 10, ...: a group's last term */
-        ps = (ps * num) * g_inv_k[k + 1];
+        /* PRNB-4: the ratio (mp + k*q)/(k+1) = q + (mp - q)/(k+1) by ONE fma from the table's 1/(k+1), the term by
+         * ONE multiplication (PRNB-3: numerator by addition, two multiplications); k = 0 keeps ps * mp */
+        ps = (k == 0) ? ps * mp : ps * FMA(d, g_inv_k[k + 1], q);
         ++k;
-        /* numerator mp + k*q: one fma where a group of four terms starts (k = 3, 7, ...), by addition
-         * inside a group -- summing q term after term would let its rounding errors pile up over a
-         * long walk (1e-4 of the pmf after 300 terms) */
-        num = ((k & 3) == 3) ? FMA((float)k, q, mp) : num + q;
     }
 }
 
@@ -461,7 +460,7 @@ PRNB_EXPORT PRNB_CLONES void prnb_walk_detail(const float* means, int64_t rows, 
         float t2 = t * 1.44269504f;
         uint32_t w[4];
         philox_count((uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)g >> 2, 0u, k0, k1, w);
-        float ps = fminf(det_exp(-t), 0.99999994f) * 4294967296.0f, num = mp, rem = (float)w[g & 3];
+        float ps = fminf(det_exp(-t), 0.99999994f) * 4294967296.0f, rem = (float)w[g & 3];
         float closest = INFINITY, tail = INFINITY;
         for (int k = 0; ; ) {
             const float margin = margin0 + t2 * margin_per_t2 + margin_per_term * (k < 3 ? 2.0f : (float)(4 * ((k - 3) / 4) + 6));
@@ -472,9 +471,8 @@ PRNB_EXPORT PRNB_CLONES void prnb_walk_detail(const float* means, int64_t rows, 
                 tail = fminf(tail, fabsf(ps - 1.0f));
                 if (ps < 1.0f) break;
             }
-            ps = (ps * num) * g_inv_k[k + 1];
+            ps = (k == 0) ? ps * mp : ps * FMA(mp - q, g_inv_k[k + 1], q);
             ++k;
-            num = ((k & 3) == 3) ? FMA((float)k, q, mp) : num + q;
         }
         out_t2[i] = t2; out_close[i] = closest; out_tail[i] = tail;
     }

@@ -1,5 +1,5 @@
 // K3h: the samples the streaming kernel (k3_stream.h) listed instead of drawing them: the
-// gamma-Poisson class of PRNB-3 (prnb_device.h; theta above 16 or -log P(X = 0) above 19, one or
+// gamma-Poisson class of PRNB-4 (prnb_device.h; theta above 16 or -log P(X = 0) above 19, one or
 // two in a thousand of a typical workload), the inversion walks whose hardware-math evaluation came
 // too close to a threshold, and the walks that were still running when their strip was done
 // (all redone here from k = 0 with the definition's arithmetic).
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
     // lane's walk lives in registers across passes and an idle lane takes the next entry of the redo stack:
     // a pass runs with more than half of the lanes walking, and new walks start at least 32 at a time.
     int32_t wk = -1;                                  // next term of this lane's walk; -1: idle
-    float wps = 0.0f, wnum = 0.0f, wrem = 0.0f, wmp = 0.0f, wq = 0.0f;
+    float wps = 0.0f, wrem = 0.0f, wd = 0.0f, wq = 0.0f;         // the next term, the remainder, mp - q, q
     int32_t wn = 0, wg = 0;
     auto light_start = [&]() {
         // idle lanes take entries: parameters, P(X = 0) and the terms k = 0, 1, 2 (the chop-down's first
@@ -226,14 +226,12 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
         const prnb::Words w = prnb::philox_count((uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)e.g >> 2, 0u, k0, k1);
         const uint32_t sel = (uint32_t)e.g & 3u;
         const uint32_t wj = sel == 0u ? w.w[0] : (sel == 1u ? w.w[1] : (sel == 2u ? w.w[2] : w.w[3]));
-        const float mp = P.m * P.inv_u1, q = P.theta * P.inv_u1;
+        const float mp = P.m * P.inv_u1, q = P.theta * P.inv_u1, d = mp - q;
         const float ps = __builtin_fminf(prnb::det_exp(-P.t), 0.99999994f) * 4294967296.0f;
         const float r0 = (float)wj - ps;
-        const float p1 = (ps * mp) * inv_k[1];
-        const float n1 = mp + q;
+        const float p1 = ps * mp;
         const float r1 = r0 - p1;
-        const float p2 = (p1 * n1) * inv_k[2];
-        const float n2 = n1 + q;
+        const float p2 = p1 * PRNB_FMA(d, inv_k[2], q);
         const float r2 = r1 - p2;
         const bool done = (r0 < 0.0f) || (r1 < 0.0f) || (r2 < 0.0f) || (p2 < 1.0f);
         const int32_t x = (r0 < 0.0f) ? 0 : ((r1 < 0.0f) ? 1 : 2);
@@ -242,10 +240,9 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
                 if (x != 0) out[(int64_t)e.n * ld + e.g] = x;
             } else {
                 wk = 3;
-                wps = (p2 * n2) * inv_k[3];
-                wnum = PRNB_FMA(3.0f, q, mp);
+                wps = p2 * PRNB_FMA(d, inv_k[3], q);
                 wrem = r2;
-                wmp = mp; wq = q; wn = e.n; wg = e.g;
+                wd = d; wq = q; wn = e.n; wg = e.g;
             }
         }
     };
@@ -257,26 +254,19 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
         const float4 ia = *reinterpret_cast<const float4*>(__builtin_assume_aligned(tab, 16));
         const float4 ib = *reinterpret_cast<const float4*>(__builtin_assume_aligned(tab + 4, 16));
         const float a1 = wrem - wps;
-        const float q2 = (wps * wnum) * ia.x;
-        const float m2 = wnum + wq;
+        const float q2 = wps * PRNB_FMA(wd, ia.x, wq);
         const float a2 = a1 - q2;
-        const float q3 = (q2 * m2) * ia.y;
-        const float m3 = m2 + wq;
+        const float q3 = q2 * PRNB_FMA(wd, ia.y, wq);
         const float a3 = a2 - q3;
-        const float q4 = (q3 * m3) * ia.z;
-        const float m4 = m3 + wq;
+        const float q4 = q3 * PRNB_FMA(wd, ia.z, wq);
         const float a4 = a3 - q4;
-        const float q5 = (q4 * m4) * ia.w;
-        const float m5 = PRNB_FMA((float)(wk + 4), wq, wmp);
+        const float q5 = q4 * PRNB_FMA(wd, ia.w, wq);
         const float b1 = a4 - q5;
-        const float q6 = (q5 * m5) * ib.x;
-        const float m6 = m5 + wq;
+        const float q6 = q5 * PRNB_FMA(wd, ib.x, wq);
         const float b2 = b1 - q6;
-        const float q7 = (q6 * m6) * ib.y;
-        const float m7 = m6 + wq;
+        const float q7 = q6 * PRNB_FMA(wd, ib.y, wq);
         const float b3 = b2 - q7;
-        const float q8 = (q7 * m7) * ib.z;
-        const float m8 = m7 + wq;
+        const float q8 = q7 * PRNB_FMA(wd, ib.z, wq);
         const float b4 = b3 - q8;
         // the remainders only fall: one of a group's four is negative iff its last one is
         const bool end_a = (a4 < 0.0f) || (q4 < 1.0f);
@@ -291,9 +281,8 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
             }
         }
         if (wk >= 0) {
-            wps = (q8 * m8) * ib.w;
+            wps = q8 * PRNB_FMA(wd, ib.w, wq);
             wk += 8;
-            wnum = PRNB_FMA((float)wk, wq, wmp);
             wrem = b4;
         }
     };

@@ -2,7 +2,7 @@
 // on its own strip of the count matrix, with LDS stacks between the stages so that every
 // stage executes with (nearly) all 64 lanes busy.
 //
-// The scalar algorithm (PRNB-3, prnb_device.h) has very different costs per sample:
+// The scalar algorithm (PRNB-4, prnb_device.h) has very different costs per sample:
 //   ~65 % of the samples of the headline workload are zeros that a 6-instruction bound
 //         settles (exp(-m * phi_gene) <= P(X = 0), prnb::zero_test_factor);
 //   the rest need P(X = 0) exactly (reciprocal + log1p + exp, ~100 VALU), and
@@ -29,7 +29,7 @@
 //   serialises them); sample_counts_heavy_kernel (k3_heavy.h) draws them afterwards.
 //
 // Stages 2 and 3 evaluate P(X = 0) with the hardware's v_rcp/v_log/v_exp (each within 1.2e-7 of
-// the true value on gfx950, tools/hwmath_probe.hip) instead of PRNB-3's deterministic binary32
+// the true value on gfx950, tools/hwmath_probe.hip) instead of PRNB-4's deterministic binary32
 // arithmetic -- a third of the instructions.  The result must still be the model's, bit for bit:
 // a walk's answer is the first k whose subtraction leaves the remainder negative, so it can
 // only differ from the exact evaluation's when a remainder lies within the two evaluations' distance
@@ -47,7 +47,7 @@
 // left shift, mbcnt, 3-operand integer forms, 64-bit multiply) occupy a second unit for ~4.3 cycles
 // each (simple integer add/xor/and/or/right shift ~2.4 there, transcendentals ~8.3), and scalar
 // instructions issue beside both.  The kernel is bound by that second unit, so the walk is pure
-// binary32 arithmetic on a binary32 remainder (PRNB-3), hits are counted from sign bits, wave-level
+// binary32 arithmetic on a binary32 remainder (PRNB-4), hits are counted from sign bits, wave-level
 // tests are lane masks formed by ONE compare each, and per-cell values arrive by scalar loads.
 #pragma once
 #include "prnb_device.h"
@@ -66,8 +66,9 @@ constexpr int kRing = 8;           // rows of the strip kept in LDS (8 bits per 
 // three times the worst-case distance between the two evaluations of a running pmf sum C_k --
 //   P0:  |t_exact - t_hw| <= (6.1e-7 + 3.5e-7) * t  (det_log1p 2.5e-7, det_rcp 1.2e-7, four roundings |
 //        log2(u1)*rcp(u1-1) 2.9e-7 measured over (0, 16], one rounding), exp 2.0e-7 + 0.9e-7;
-//   numerators: none (mp and q are formed by PRNB-2's own arithmetic here), so a term adds only
-//        the two paths' rounding differences, 2 * 2^-24 each at most.
+//   ratios: none (mp - q and q are formed by PRNB-4's own arithmetic here, so the ratio q + (mp - q)/(k+1) of a term
+//        is the same number in both paths): a term adds only the rounding difference of its one multiplication,
+//        2^-24 at most.
 //   the remainder itself: both paths subtract their terms from a binary32 remainder below 2^32, so
 //        each subtraction can round differently by up to ulp(2^32)/2 = 256 units -- far less for the
 //        small remainders of a walk that is about to end, but the margin does not rely on that.
@@ -120,7 +121,7 @@ __device__ __forceinline__ prnb::Words philox_count_row(const uint32_t ph[4], ui
 }
 
 struct S1Entry { float m, theta, wf; uint32_t pos; };  // theta = a*m + b - 1, not yet clamped; wf = (float)(32-bit uniform)
-struct S2Entry { float ps, mp, q, rem; };             // pmf (x 2^32) at k = 3 and what is left of wf; the numerator of step k is mp + k*q
+struct S2Entry { float ps, mp, q, rem; };             // pmf (x 2^32) at k = 3 and what is left of wf; `mp` holds mp - q: the ratio of step k is q + (mp - q)/(k+1)
 // S2 meta word: the threshold margin of the terms k = 3..6 (binary32, rounded up to 16 significant bits
 // -- it is a bound, and the model knows nothing of it) with pos in the 16 bits that frees
 
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
     constexpr uint32_t kNoHeavy = 0xffffffffu;
     uint32_t hpend = kNoHeavy;                       // pos of the sample this lane holds for the next append to K3h's list
     // stage-3 lane state
-    float ps = 0.0f, mp = 0.0f, q = 0.0f, kf = 0.0f;   // kf = (float)k of a busy lane
+    float ps = 0.0f, mp = 0.0f, q = 0.0f;              // of a busy lane: the next term, mp - q, q
     float rem = 0.0f, dl = 0.0f;                     // what is left of wf; this lane's threshold margin (grows with k)
     uint32_t pos = 0u;
     constexpr int kIdle = -5;        // k + 1 = 0 mod 4 (the aligned read of four reciprocals), k + 3 < 0 (no result)
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
     // ---- stage 3: four pmf steps for every busy lane; idle lanes pull from S2 ------------------
     // A lane is idle iff k == kIdle, and an idle lane keeps ps = 0: its "count" k + 3 is negative,
     // which keeps it out of every mask below, so the arithmetic never asks which lanes are busy.
-    // PRNB-3's walk (the chop-down of prnb_device.h): the terms are subtracted from a binary32 remainder, the count
+    // PRNB-4's walk (the chop-down of prnb_device.h): the terms are subtracted from a binary32 remainder, the count
     // is the first k whose subtraction leaves it negative; when a group of four ends without that
     // and its last term is under 1 (the pmf has fallen under 2^-32) the count is the group's last k.
     // A walk enters at k = 3 and advances by 4: the four reciprocals 1/(k+1)..1/(k+4) are one aligned
@@ -320,22 +321,17 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
                 pos = md & 0xffffu;
                 dl = prnb::u2f(md);                   // pos rides in the low bits: the margin only grows by it
                 k = 3;
-                kf = 3.0f;
                 inv = *reinterpret_cast<const float4*>(&inv_k[4]);
             }
             const int left = s2_top - __popcll(idle_m);
             s2_top = left > 0 ? left : 0;
         }
-        const float num = PRNB_FMA(kf, q, mp);          // the group's first numerator by fma, the others by addition
         const float r1 = rem - ps;
-        const float ps1 = (ps * num) * inv.x;
-        const float num1 = num + q;
+        const float ps1 = ps * PRNB_FMA(mp, inv.x, q);          // (`mp` holds mp - q here: PRNB-4's ratio q + (mp - q)/(k+1))
         const float r2 = r1 - ps1;
-        const float ps2 = (ps1 * num1) * inv.y;
-        const float num2 = num1 + q;
+        const float ps2 = ps1 * PRNB_FMA(mp, inv.y, q);
         const float r3 = r2 - ps2;
-        const float ps3 = (ps2 * num2) * inv.z;
-        const float num3 = num2 + q;
+        const float ps3 = ps2 * PRNB_FMA(mp, inv.z, q);
         const float r4 = r3 - ps3;
         const unsigned long long hit_m = K3_MASK(r4 < 0.0f);
         const unsigned long long tail_m = K3_MASK(ps3 < 1.0f);
@@ -352,8 +348,7 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
         const unsigned long long give_m = (close_m | (big_m & (hit_m | tail_m))) & busy_m;
         deliver(done_m & busy_m & ~close_m & ~big_m, give_m, pos, (uint32_t)res_k);
         rem = r4;
-        const float ps4 = (ps3 * num3) * inv.w;
-        kf = kf + 4.0f;
+        const float ps4 = ps3 * PRNB_FMA(mp, inv.w, q);
         dl = dl + 4.0f * kMarginPerTerm;
         // done lanes go idle (ps = 0, k = kIdle)
         asm("v_cndmask_b32 %0, %1, 0, %2" : "=v"(ps) : "v"(ps4), "s"(done_m));
@@ -364,7 +359,7 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
     // ---- stage 2: P(X = 0), class test, then the terms k = 0, 1, 2, for up to 64 entries of S1 -------
     // prnb::make_params with the hardware's log2, reciprocal and exp2 for P(X = 0):
     // log1p(theta)/theta = log(u1)/(u1 - 1) (u1 = fl(1 + theta): the rounding of the sum cancels),
-    // P0 = 2^-t2; mp and q by PRNB-3's own arithmetic (they multiply
+    // P0 = 2^-t2; mp and q by PRNB-4's own arithmetic (they multiply
     // into every term of a walk).  What the approximation cannot decide -- the class of a sample with t within
     // 2^-16 of 19, a remainder within the margin -- goes to K3h's list.
     const uint32_t s2_lds = (uint32_t)(uintptr_t)&L.s2[0];
@@ -395,12 +390,12 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
         const float ps0 = __builtin_amdgcn_exp2f(-t2) * 4294967296.0f;       // pmf scaled by 2^32 (exact scaling)
         // threshold margin of this sample at k = 2 (in units of 2^-32)
         const float d2 = PRNB_FMA(t2, kMarginPerT2, kMargin0 + 2.0f * kMarginPerTerm);
+        // PRNB-4's terms: P(k+1) = P(k) * (q + (mp - q)/(k+1)), the ratio by one fma from the 1/k table (k = 0: P(0) * mp)
+        const float dd = mpp - qq;
         const float r0 = e.wf - ps0;
-        const float ps1 = ps0 * mpp;                  // (* 1/1)
-        const float num1 = mpp + qq;
+        const float ps1 = ps0 * mpp;
         const float r1 = r0 - ps1;
-        const float ps2 = (ps1 * num1) * 0.5f;
-        const float num2 = num1 + qq;
+        const float ps2 = ps1 * PRNB_FMA(dd, 0.5f, qq);
         const float r2 = r1 - ps2;
         const unsigned long long hit_m = K3_MASK(r2 < 0.0f);
         const unsigned long long tail_m = K3_MASK(ps2 < 1.0f);
@@ -418,8 +413,8 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
             const uint32_t slot = (uint32_t)s2_top + (uint32_t)lane_rank(push_m);
             typedef float f32x4 __attribute__((ext_vector_type(4)));
             f32x4 e2;
-            e2.x = (ps2 * num2) * 0.33333334f;       // pmf at k = 3 (the 1/k table's 1/3)
-            e2.y = mpp;
+            e2.x = ps2 * PRNB_FMA(dd, 0.33333334f, qq);      // pmf at k = 3 (the 1/k table's 1/3)
+            e2.y = dd;
             e2.z = qq;
             e2.w = r2;
             // margin of the terms k = 3..6, rounded up to 16 significant bits, | pos
@@ -507,7 +502,7 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
             // The compare mask goes straight into an SGPR pair (every lane is active here, so it is
             // the ballot), the push is one LDS store under exec = mask: no branch, no exec save.
             // (The stage-1 loop must stay wave-uniform: the asm below ends with exec = -1.)
-            const float wf = (float)W.w[j];                    // PRNB-3's remainder starts as this
+            const float wf = (float)W.w[j];                    // PRNB-4's remainder starts as this
             unsigned long long push_m;
             asm("v_cmp_nlt_f32 %0, %1, %2" : "=s"(push_m) : "v"(wf), "v"(bound32));   // not settled as 0 (or NaN)
             u32x4 e;                                           // S1Entry {m, theta, wf, pos}

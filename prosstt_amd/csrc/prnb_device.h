@@ -1,4 +1,4 @@
-// PRNB-3 count sampler, device side (gfx950).  DESIGN.md section 4 defines it; this header holds
+// PRNB-4 count sampler, device side (gfx950).  DESIGN.md section 4 defines it; this header holds
 // its building blocks -- the counter generator, the binary32 functions of the definition, the
 // parameters of a sample, the inversion walk -- that the kernels (k3_stream.h, k3_heavy.h,
 // nb_params_kernel) are made of.  Replaces, per (cell, gene):
@@ -64,7 +64,7 @@ __device__ __forceinline__ Words philox4x32(uint32_t c0, uint32_t c1, uint32_t c
     return r;
 }
 
-// The count sampler (PRNB-3) draws from Philox4x32-7: the fewest rounds of Philox4x32 that pass BigCrush
+// The count sampler (PRNB-4) draws from Philox4x32-7: the fewest rounds of Philox4x32 that pass BigCrush
 // (Salmon et al. 2011, section 5 and table 2: "Crush-resistant"; 10 rounds are the library default for
 // margin).  Every counter is used once, a sample's uniforms are never compared with a neighbour's, and
 // the statistical tests of tests/ run on this generator; the three rounds are 3 % of the whole kernel.
@@ -179,13 +179,12 @@ __device__ __forceinline__ float det_sqrt(float x) { return __builtin_sqrtf(x); 
 
 // Inversion by chop-down on a binary32 remainder; inv_k = LDS table of 1/k
 // (16-byte aligned, 0 from the sentinel k = KTAB-1 on, 8 more zeros behind it).
-// P(k+1) = P(k) * num_k / (k+1), num_k = mp + k*q, carried scaled by 2^32.  The remainder starts as
+// P(k+1) = P(k) * (q + (mp - q)/(k+1)) -- the ratio (mp + k*q)/(k+1) by ONE fma from the table's 1/(k+1); k = 0:
+// P(0) * mp --, carried scaled by 2^32.  The remainder starts as
 // (float)w and every term is subtracted from it; the draw is the first k whose subtraction leaves it
 // negative.  Terms come in groups (k = 0..2, then four at a time: the streaming kernel's passes); when
 // a group ends without a negative remainder and its last term is below 1 (the pmf has fallen under
-// 2^-32 before w is used up: mass lost to rounding, < 1e-6) the draw is that group's last k.  The numerator
-// mp + k*q is ONE fma where a group of four terms starts (k = 3, 7, ...) and grows by addition inside a
-// group (the rounding errors of a running sum would pile up over a long walk).
+// 2^-32 before w is used up: mass lost to rounding, < 1e-6) the draw is that group's last k.
 //
 // For a whole wave at once (K3h): every lane carries its own walk, all lanes are at the same k.  A group
 // of four terms is evaluated without a branch per term (terms behind a lane's draw are computed and ignored), and the
@@ -196,38 +195,32 @@ __device__ __forceinline__ int32_t chop_down_wave(bool active, uint32_t w, float
 {
     float ps = __builtin_fminf(p0, 0.99999994f) * 4294967296.0f;
     float rem = (float)w;
+    const float d = mp - q;
     // k = 0, 1, 2
     const float r0 = rem - ps;
-    const float p1 = (ps * mp) * inv_k[1];
-    const float n1 = mp + q;
+    const float p1 = ps * mp;
     const float r1 = r0 - p1;
-    const float p2 = (p1 * n1) * inv_k[2];
-    const float n2 = n1 + q;
+    const float p2 = p1 * PRNB_FMA(d, inv_k[2], q);
     const float r2 = r1 - p2;
     int32_t res = (r0 < 0.0f) ? 0 : ((r1 < 0.0f) ? 1 : 2);
     bool busy = active && !((r0 < 0.0f) || (r1 < 0.0f) || (r2 < 0.0f) || (p2 < 1.0f));
-    ps = (p2 * n2) * inv_k[3];
-    float num = PRNB_FMA(3.0f, q, mp);
+    ps = p2 * PRNB_FMA(d, inv_k[3], q);
     rem = r2;
     const float4* tab = reinterpret_cast<const float4*>(__builtin_assume_aligned(inv_k + 4, 16));
     int k = 3;
     auto group = [&](const float4 inv) {
         const float a1 = rem - ps;
-        const float q2 = (ps * num) * inv.x;
-        const float m2 = num + q;
+        const float q2 = ps * PRNB_FMA(d, inv.x, q);
         const float a2 = a1 - q2;
-        const float q3 = (q2 * m2) * inv.y;
-        const float m3 = m2 + q;
+        const float q3 = q2 * PRNB_FMA(d, inv.y, q);
         const float a3 = a2 - q3;
-        const float q4 = (q3 * m3) * inv.z;
-        const float m4 = m3 + q;
+        const float q4 = q3 * PRNB_FMA(d, inv.z, q);
         const float a4 = a3 - q4;
         const bool end = (a1 < 0.0f) || (a2 < 0.0f) || (a3 < 0.0f) || (a4 < 0.0f) || (q4 < 1.0f);
         const int32_t at = (a1 < 0.0f) ? k : ((a2 < 0.0f) ? k + 1 : ((a3 < 0.0f) ? k + 2 : k + 3));
         if (busy && end) { res = at; busy = false; }
-        ps = (q4 * m4) * inv.w;
+        ps = q4 * PRNB_FMA(d, inv.w, q);
         k += 4;
-        num = PRNB_FMA((float)k, q, mp);
         rem = a4;
     };
     // two groups per LDS round trip (the table ends in zeros: a walk stops at the sentinel at the latest,

@@ -1,7 +1,7 @@
 """
 -m gpu: the HIP count sampler (K3) against the oracle, through the C ABI.
 
- * counts: BIT-EXACT against oracle/nb_model.c (the scalar C model of PRNB-2) on the
+ * counts: BIT-EXACT against oracle/nb_model.c (the scalar C model of PRNB-4) on the
    same seeded inputs -- integer work, no tolerance;
  * (mu, p, r): bit-exact against the model AND within rtol 1e-6 of the reference's
    float64 get_pr_umi (count_model.py:156-158) -- the stated fp32 tolerance;
