@@ -7,6 +7,7 @@ bash tools/profile_bench.sh $TAG > /dev/null 2>&1; grep "under the tracer\|deriv
 python3 bench.py 2> $O/bench_default.err | tail -1 > $O/bench_default.json
 PROSSTT_BENCH_BACKEND=gloo PROSSTT_BENCH_ONE_GPU=1 timeout 900 python3 bench.py --gpus 2 --steps 5 --warmup 2 2> $O/bench2.err | tail -1 > $O/bench_2ranks_gloo_one_gpu.json
 for c in C2 C4 C5; do KBENCH_CELLS=$([ $c = C5 ] && echo 125000 || echo 0) ; if [ $c = C5 ]; then export KBENCH_CELLS=125000; else unset KBENCH_CELLS; fi; timeout 600 python3 tools/kbench_ab.py $c 10 shipped 2>&1 | grep -v amdgpu; done | tee $O/other_configs.txt
+bash tools/stage_budget.sh $TAG > /dev/null 2>&1; tail -7 gpurun_out/stage_budget_$TAG.txt | cut -c1-170
 bash tools/ablation_record.sh $TAG > /dev/null 2>&1; tail -4 gpurun_out/ablation_$TAG.txt | cut -c1-160
 for c in C3 C4; do timeout 900 python3 tools/list_stats.py $c 2>&1 | grep -v amdgpu | tail -2; done | tee $O/list_stats.txt
 python3 -c "
