@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PROSSTT_AMD_VERSION 310 /* 0.3.1: PRNB-4 sampler (binary32 remainder, one-fma term ratio), prosstt_amd_last_list; the tile-per-block kernel is gone */
+#define PROSSTT_AMD_VERSION 400 /* 0.4.0: PRNB-5 sampler (P(X=0) by the hardware's rcp/log2/exp2, no margins), prosstt_amd_hw_math */
 
 enum {
     PROSSTT_AMD_OK = 0,
@@ -66,7 +66,7 @@ int prosstt_amd_last_kernel_ms(prosstt_amd_ctx* ctx, float* ms);
  *   scipy.stats.nbinom(n=r, p=1-p).rvs()        simulation.py:647-648
  * out[n*ld_out + g] ~ NB(mean m, variance alpha*m^2 + beta*m),
  *   m = means[row_of_cell[n]*G + g] * scaling[n],
- * drawn by the PRNB-4 counter-based sampler keyed by
+ * drawn by the PRNB-5 counter-based sampler keyed by
  * (seed, global cell id, g); the global id of cell n is cell_index[n] when
  * cell_index is given, cell_offset + n otherwise.
  *   means        [rows][G] binary32, row-major: the (branch, time, gene) mean tensor
@@ -77,7 +77,7 @@ int prosstt_amd_last_kernel_ms(prosstt_amd_ctx* ctx, float* ms);
  *                the positions of its cells in that plan: results do not depend on sharding)
  *   out          [N][ld_out] int32 counts (the reference returns int64)
  * Limits, refused with PROSSTT_AMD_EINVAL before anything is allocated: N < 2^31, ld_out >= G,
- * ld_out * 128 < 2^32, ceil(N/64)/4 * ceil(G/256) < 2^29 (chunk the cells beyond that), rows > 0.
+ * ld_out * 128 < 2^29, ceil(N/64)/4 * ceil(G/256) < 2^29 (chunk the cells beyond that), rows > 0.
  * Workspace: the ctx grows its device workspace to about N*G/4 + 36*N + 12*G bytes for the call (one
  * region of the list of samples drawn by the second kernel per 64 x 256 block of the matrix).
  */
@@ -89,8 +89,8 @@ int prosstt_amd_sample_counts(prosstt_amd_ctx* ctx, const float* means, int64_t 
 
 /*
  * The samples that the streaming kernel of the LAST prosstt_amd_sample_counts call on this ctx left
- * to its second kernel (K3h): the gamma-Poisson class, inversion walks whose hardware-math
- * evaluation came within its margin of a threshold, counts above 255.  Decoded to (cell, gene)
+ * to its second kernel (K3h): the gamma-Poisson class, the walks still running when their strip of
+ * 64 cells ended, walks past k = 254.  Decoded to (cell, gene)
  * pairs, cells[i] indexing that call's arrays; at most `cap` pairs are written, *total receives the
  * number listed, *overflowed whether a wave's region of the list was too small (more than one in 16 of
  * its 64 x 256 samples listed; K3h then redoes that region sample by sample, and the list holds the
@@ -110,6 +110,17 @@ int prosstt_amd_nb_params(prosstt_amd_ctx* ctx, const float* means, int64_t rows
                           const int32_t* row_of_cell, const double* scaling, const double* alpha,
                           const double* beta, int64_t N, float* mu, float* p, float* r,
                           int32_t* path, uint32_t flags);
+
+/*
+ * The three hardware functions that the sampler's definition (PRNB-5) takes from gfx950,
+ * tabulated by the device itself over a range of binary32 bit patterns:
+ *   out[i] = f(as_float(first_bits + i)),  i < count;   op 0: f = v_rcp_f32(x), 1: v_log_f32(x), 2: v_exp_f32(-x)
+ * -- the side input of the scalar model that checks the sampler bit for bit (oracle/nb_model.c reads these values
+ * instead of re-implementing the hardware).  Replaces nothing of the reference: its scipy.stats.nbinom draws
+ * (simulation.py:647-648) evaluate log/exp in libm.  `out`: DEVICE, or HOST with PROSSTT_AMD_HOST_OUTPUT.
+ */
+int prosstt_amd_hw_math(prosstt_amd_ctx* ctx, int32_t op, uint32_t first_bits, uint64_t count, float* out,
+                        uint32_t flags);
 
 /*
  * One attempt of the accept/reject loop of simulation.simulate_lineage

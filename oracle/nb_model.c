@@ -3,7 +3,7 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library; prosstt_amd never does.
  *
- * Scalar C model of the *device* count sampler ("PRNB-4"): the
+ * Scalar C model of the *device* count sampler ("PRNB-5"): the
  * fused  gather * scale -> get_pr_umi -> negative-binomial draw  that replaces
  *   simulation.draw_counts           /root/reference/prosstt/simulation.py:602-651
  *   count_model.get_pr_umi           /root/reference/prosstt/count_model.py:131-161
@@ -11,23 +11,33 @@
  *
  * The reference draws from numpy's sequential MT19937 stream, which no
  * parallel device can reproduce (SURVEY.md section 0 "RNG reality check"); the count
- * law, not the stream, is the contract.  PRNB-4 is a counter-based sampler of
+ * law, not the stream, is the contract.  PRNB-5 is a counter-based sampler of
  * the SAME law  NB(n = r, p = 1-p)  with  theta = a*m + b - 1,  r = m/theta,
  * p = theta/(1+theta)  (the algebraic form of get_pr_umi), defined so that
  * every sample is a pure function of (M, s, a, b, seed, cell, gene):
  *   - randomness: Philox4x32-7 (Salmon et al. 2011: the fewest rounds that pass BigCrush), key = seed,
  *     counter = (cell_lo, cell_hi, gene-or-quad, domain);
- *   - arithmetic: IEEE binary32 add/mul/fma/sqrt only, plus the polynomial
- *     log/exp/cos and the Newton reciprocal below -- no libm, no hardware
- *     approximations -- so this C model and the HIP kernel agree BIT FOR BIT.
- * The law itself is pinned on the CPU against scipy/numpy (tests/test_nb_model.py,
- * fixture g7) and the kernel is pinned against this model (tests/test_gpu_*.py).
+ *   - arithmetic: IEEE binary32 add/mul/fma/sqrt, the polynomial log/exp/cos and the Newton
+ *     reciprocal below -- no libm -- and, for P(X = 0) of the inversion class only, three functions of
+ *     the gfx950 hardware: HW_RCP (v_rcp_f32), HW_LOG2 (v_log_f32), HW_EXP2 (v_exp_f32).  This model
+ *     does not re-implement those: it reads their values from TABLES that the product's three-line probe
+ *     kernel (prosstt_amd_hw_math; hw_math_kernel in prosstt_amd.hip: y = v_rcp_f32(x) etc. over a range
+ *     of bit patterns) writes on the device under test -- prnb_set_hw_tables, oracle/nb_model.py:
+ *     install_hw_tables.  With the tables installed this C model and the HIP kernels agree BIT FOR BIT.
+ *     Without them (no GPU: the CPU-only tests) the three functions fall back to libm's
+ *     1/x, log2f, exp2f -- each within an ulp or two of the hardware's values -- which is NOT the
+ *     device's definition bit for bit but the same law to 1e-6: that mode serves the law tests that
+ *     run without a GPU (prnb_hw_mode() tells which is active).
+ * The law itself is pinned against scipy/numpy (tests/test_nb_model.py, fixture g7; on the GPU the same
+ * tests run with the tables) and the kernel is pinned against this model (tests/test_gpu_*.py).
  *
  * Build: see oracle/Makefile  (-O2 -ffp-contract=off; never -ffast-math).
  */
 #include <stdint.h>
 #include <string.h>
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #define PRNB_EXPORT __attribute__((visibility("default")))
 #if defined(__x86_64__)
@@ -36,13 +46,14 @@
 #define PRNB_CLONES
 #endif
 
-/* ---- sampler constants (part of the PRNB-4 definition) ------------------ */
-#define PRNB_LIGHT_T      19.0f        /* inversion iff theta <= 16 and t = -log P(X=0) <= 19: P0 * 2^32 >= 24 */
-#define PRNB_LIGHT_THETA  16.0f        /* tail ratio theta/(1+theta) <= 16/17: the walk ends far below the 1/k table's 511 entries */
-#define PRNB_THETA_MIN    8.6736174e-19f /* 2^-60: below this NB == Poisson in binary32 */
+/* ---- sampler constants (part of the PRNB-5 definition) ------------------ */
+#define PRNB_LIGHT_T2     27.4112f     /* inversion iff theta <= 16 and t2 = -log2 P(X=0) < 27.4112 (19/ln 2): P0 * 2^32 >= 24 */
+#define PRNB_LIGHT_THETA  16.0f        /* tail ratio theta/(1+theta) <= 16/17 */
+#define PRNB_THETA_MIN    1.1920929e-7f  /* 2^-23: 1 + theta > 1 in binary32; below this NB == Poisson to 1e-7 of the variance */
 #define PRNB_THETA_MAX    1.0e18f
 #define PRNB_R_MIN        9.094947e-13f  /* 2^-40: P(X>0) < 2^-32, return 0 */
-#define PRNB_KTAB         512          /* 1/k table size, last entry = 0 sentinel: with theta <= 16 and -log P0 <= 19 (mean <= 107) P(X >= 511) < 1e-10 */
+#define PRNB_WALK_END     1022         /* the group k = 1019..1022 is a walk's last: P(X > 1022) < 1e-25 in the inversion class */
+#define PRNB_KTAB         1032         /* 1/k for 1 <= k < KTAB */
 #define PRNB_POIS_INV     10.0f        /* Poisson: inversion below, PTRS above */
 #define PRNB_LAM_BIG      4194304.0f   /* 2^22: rounded normal above */
 #define PRNB_MAX_TRIES    64
@@ -50,6 +61,50 @@
 static inline uint32_t f2u(float x) { uint32_t u; memcpy(&u, &x, 4); return u; }
 static inline float u2f(uint32_t u) { float x; memcpy(&x, &u, 4); return x; }
 #define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+
+/* ---- the three hardware functions of the definition: values from the device's own tables --------
+ *   rcp_mant[i]  = v_rcp_f32(x) for the 2^23 floats x in [1, 2) (bit pattern 0x3F800000 + i); for any other
+ *                  normal x = 2^e * x1 the value is rcp_mant(x1) * 2^-e  (exact scaling: checked on the
+ *                  device over the whole range the sampler presents, tests/test_gpu_hw_math.py)
+ *   log2_tab[i]  = v_log_f32(x) for bit patterns log2_first + i   (the sampler presents 1 < x <= 17)
+ *   exp2_tab[i]  = v_exp_f32(-x) for bit patterns exp2_first + i  (0 <= x < 27.4112 presented; below the table's
+ *                  first entry, 2^-24, the value is 1.0f: checked on the device for every such x)
+ * A lookup outside a table aborts: never a silent substitute. */
+static const float* g_rcp_mant = 0;
+static const float* g_log2_tab = 0;
+static const float* g_exp2_tab = 0;
+static uint32_t g_log2_first = 0, g_log2_count = 0, g_exp2_first = 0, g_exp2_count = 0;
+
+static void hw_fail(const char* what, float x)
+{
+    fprintf(stderr, "oracle/nb_model.c: %s(%a) is outside the installed hardware table\n", what, (double)x);
+    abort();
+}
+
+static inline float hw_rcp(float x)
+{
+    if (!g_rcp_mant) return 1.0f / x;
+    const uint32_t b = f2u(x);
+    const int32_t e = (int32_t)(b >> 23) - 127;
+    if ((b >> 31) || e < -100 || e > 100) hw_fail("HW_RCP", x);
+    return u2f(f2u(g_rcp_mant[b & 0x7FFFFFu]) - ((uint32_t)e << 23));
+}
+static inline float hw_log2(float x)
+{
+    if (!g_log2_tab) return log2f(x);
+    const uint32_t i = f2u(x) - g_log2_first;
+    if (i >= g_log2_count) hw_fail("HW_LOG2", x);
+    return g_log2_tab[i];
+}
+/* v_exp_f32(-x), x >= 0 */
+static inline float hw_exp2neg(float x)
+{
+    if (!g_exp2_tab) return exp2f(-x);
+    if (x < 5.9604645e-8f) return 1.0f;                    /* 2^-24 */
+    const uint32_t i = f2u(x) - g_exp2_first;
+    if (i >= g_exp2_count) hw_fail("HW_EXP2", -x);
+    return g_exp2_tab[i];
+}
 
 /* ---- Philox4x32-R (Salmon, Moraes, Dror, Shaw 2011) ----------------------- */
 static inline void philox4x32_r(int rounds, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
@@ -186,36 +241,31 @@ static const float LOGFACT[10] = {0.0f, 0.0f, 0.69314718f, 1.7917595f, 3.1780538
 __attribute__((constructor)) static void prnb_init(void)
 {
     g_inv_k[0] = 0.0f;
-    for (int k = 1; k < PRNB_KTAB - 1; ++k) g_inv_k[k] = 1.0f / (float)k;
-    g_inv_k[PRNB_KTAB - 1] = 0.0f;   /* sentinel: the walk ends (pmf 0 -> floor(mp)) at k = KTAB-1 */
+    for (int k = 1; k < PRNB_KTAB; ++k) g_inv_k[k] = 1.0f / (float)k;
 }
 
 /*
  * Inversion by chop-down on a binary32 remainder.  pmf recurrence
- *   P(k+1) = P(k) * num_k / (k+1),   num_k = mp + k*q
- * (NB: mp = m/(1+theta), q = theta/(1+theta);  Poisson: mp = lambda, q = 0), carried scaled by 2^32.
- * `w` is the 32-bit uniform; the remainder starts as (float)w (round to nearest: 24 significant bits,
- * full resolution below 2^24) and every term is subtracted from it in binary32; the draw is the first k
- * whose subtraction leaves the remainder negative.  Terms come in the groups the device walks in
- * (k = 0..2, then four at a time); when a group ends without a negative remainder and its LAST term is
- * below 1 -- the pmf has fallen under 2^-32: mass lost to rounding, < 1e-6, or the 0 sentinel that ends
- * the 1/k table -- the draw is that group's last k.
- * (PRNB-2 kept the remainder as a 32-bit integer and subtracted floor(term): one float->int conversion
- * per term; PRNB-3's terms were pure binary32 multiply/add/subtract, four operations each; PRNB-4 forms the
- * term's ratio with one fma: three.  The cancellation in q + (mp - q)/(k+1) when mp << q costs at most
- * ulp(q) of the ratio, 6e-8 * q/mp of the terms k >= 2 relative -- times P(X >= 2) that is under 2e-7 absolute.)
+ *   P(k+1) = P(k) * (q + (mp - q)/(k+1))      (= P(k) * (mp + k*q)/(k+1);  k = 0: P(0) * mp)
+ * (NB: mp = m/(1+theta), q = theta/(1+theta);  Poisson: mp = lambda, q = 0), carried scaled by 2^32:
+ * `ps` enters as P(0) * 2^32.  `w` is the 32-bit uniform; the remainder starts as (float)w (round to
+ * nearest: 24 significant bits, full resolution below 2^24) and every term is subtracted from it in
+ * binary32; the draw is the first k whose subtraction leaves the remainder negative.  Terms come in the
+ * groups the device walks in (k = 0..2, then four at a time); when a group ends without a negative
+ * remainder and its LAST term is below 1 -- the pmf has fallen under 2^-32: mass lost to rounding, < 1e-6 --
+ * the draw is that group's last k, as it is when the group is the last one (k = PRNB_WALK_END).
+ * The ratio of a term comes by ONE fma from the table's 1/(k+1), the term by ONE multiplication.  The
+ * cancellation in q + (mp - q)/(k+1) when mp << q costs at most ulp(q) of the ratio, 6e-8 * q/mp of the
+ * terms k >= 2 relative -- times P(X >= 2) that is under 2e-7 absolute.
  */
-static inline int32_t chop_down(uint32_t w, float p0, float mp, float q)
+static inline int32_t chop_down(uint32_t w, float ps, float mp, float q)
 {
-    float ps = fminf(p0, 0.99999994f) * 4294967296.0f;      /* exact scaling */
     const float d = mp - q;
     float rem = (float)w;
     for (int k = 0; ; ) {
         rem = rem - ps;
         if (rem < 0.0f) return k;
-        if ((k & 3) == 2 && ps < 1.0f) return k;          /* k = 2, 6, 10, ...: a group's last term */
-        /* PRNB-4: the ratio (mp + k*q)/(k+1) = q + (mp - q)/(k+1) by ONE fma from the table's 1/(k+1), the term by
-         * ONE multiplication (PRNB-3: numerator by addition, two multiplications); k = 0 keeps ps * mp */
+        if ((k & 3) == 2 && (ps < 1.0f || k >= PRNB_WALK_END)) return k;     /* k = 2, 6, 10, ...: a group's last term */
         ps = (k == 0) ? ps * mp : ps * FMA(d, g_inv_k[k + 1], q);
         ++k;
     }
@@ -229,7 +279,7 @@ static inline int32_t poisson_draw(float lam, uint32_t c0, uint32_t c1, uint32_t
     if (!(lam > 0.0f)) return 0;
     if (lam < PRNB_POIS_INV) {
         philox_count(c0, c1, gene, 0x80000000u, k0, k1, w);
-        return chop_down(w[0], det_exp(-lam), lam, 0.0f);
+        return chop_down(w[0], fminf(det_exp(-lam), 0.99999994f) * 4294967296.0f, lam, 0.0f);
     }
     float slam = sqrtf(lam);
     if (!(lam < PRNB_LAM_BIG)) {               /* rounded normal; never reached with abs_max=5000 */
@@ -310,7 +360,7 @@ static inline float gamma_scaled(float r, float theta, uint32_t c0, uint32_t c1,
 
 typedef struct { float m, theta, p, r; int32_t path; } prnb_detail;
 
-/* One count.  path: 0 = degenerate (returns 0), 1 = light NB inversion, 2 = gamma-Poisson. */
+/* One count.  path: 0 = degenerate (returns 0), 1 = NB inversion, 2 = gamma-Poisson. */
 static inline int32_t prnb_one(float M, float s, float a, float bm1, uint32_t k0, uint32_t k1,
                                uint64_t cell, uint32_t gene, prnb_detail* det)
 {
@@ -320,19 +370,21 @@ static inline int32_t prnb_one(float M, float s, float a, float bm1, uint32_t k0
     if (det) { det->m = m; det->theta = theta; det->p = 0.0f; det->r = 0.0f; det->path = 0; }
     if (!(m > 0.0f) || !(theta > 0.0f)) return 0;
     theta = fminf(fmaxf(theta, PRNB_THETA_MIN), PRNB_THETA_MAX);
-    float u1 = 1.0f + theta;
-    float d = det_rcp(theta * u1);
-    float inv_th = d * u1, inv_u1 = d * theta;
-    float q = theta * inv_u1;
-    float r = m * inv_th;
+    const float u1 = 1.0f + theta;                       /* > 1 */
+    const float iu = hw_rcp(u1);
+    const float q = theta * iu;
+    const float inv_th = det_rcp(theta);
+    const float r = m * inv_th;
     if (det) { det->p = q; det->r = r; }
-    /* t = -log P(X = 0) = r * log(1 + theta) */
-    float t = m * (det_log1p(theta) * inv_th);
-    if (theta <= PRNB_LIGHT_THETA && t <= PRNB_LIGHT_T) {
-        uint32_t w[4];
-        if (det) det->path = 1;
-        philox_count(c0, c1, gene >> 2, 0u, k0, k1, w);
-        return chop_down(w[gene & 3u], det_exp(-t), m * inv_u1, q);
+    if (theta <= PRNB_LIGHT_THETA) {
+        /* t2 = -log2 P(X = 0) = m * log2(1 + theta)/theta, the quotient taken at the theta' = u1 - 1 that u1 stands for */
+        const float t2 = m * (hw_log2(u1) * hw_rcp(u1 - 1.0f));
+        if (t2 < PRNB_LIGHT_T2) {
+            uint32_t w[4];
+            if (det) det->path = 1;
+            philox_count(c0, c1, gene >> 2, 0u, k0, k1, w);
+            return chop_down(w[gene & 3u], hw_exp2neg(t2) * 4294967296.0f, m * iu, q);
+        }
     }
     if (det) det->path = 2;
     if (!(r >= PRNB_R_MIN)) return 0;
@@ -360,6 +412,25 @@ PRNB_EXPORT void prnb_philox_rounds(int rounds, const uint32_t ctr[4], const uin
 }
 
 PRNB_EXPORT int prnb_count_rounds(void) { return PRNB_COUNT_ROUNDS; }
+
+/* Install (or, with NULL pointers, remove) the tables of the three hardware functions -- see the comment at hw_rcp.
+ * The arrays stay the caller's and must outlive their use. */
+PRNB_EXPORT void prnb_set_hw_tables(const float* rcp_mant, const float* log2_tab, uint32_t log2_first, uint32_t log2_count,
+                                    const float* exp2_tab, uint32_t exp2_first, uint32_t exp2_count)
+{
+    g_rcp_mant = rcp_mant;
+    g_log2_tab = log2_tab; g_log2_first = log2_first; g_log2_count = log2_tab ? log2_count : 0;
+    g_exp2_tab = exp2_tab; g_exp2_first = exp2_first; g_exp2_count = exp2_tab ? exp2_count : 0;
+}
+/* 1: the device's tables are installed (bit-exact mode); 0: the libm stand-ins (law tests without a GPU) */
+PRNB_EXPORT int prnb_hw_mode(void) { return g_rcp_mant && g_log2_tab && g_exp2_tab; }
+
+/* the model's view of the hardware functions (tests of the tables): which = 0 HW_RCP(x), 1 HW_LOG2(x), 2 HW_EXP2(-x) */
+PRNB_EXPORT void prnb_hw_math(int which, const float* x, float* y, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i)
+        y[i] = which == 0 ? hw_rcp(x[i]) : (which == 1 ? hw_log2(x[i]) : hw_exp2neg(x[i]));
+}
 
 /* elementwise math probes: which = 0 rcp, 1 log, 2 log1p, 3 exp, 4 cos2pi(bits of x), 5 unif(bits) */
 PRNB_EXPORT PRNB_CLONES void prnb_math(int which, const float* x, float* y, int64_t n)
@@ -420,24 +491,13 @@ PRNB_EXPORT PRNB_CLONES void prnb_nb_params(const float* means, int64_t rows, in
     }
 }
 
-/*
- * For tests of the device's give-up protocol: how close the EXACT walk of
- * selected samples comes to a decision that the hardware-math evaluation of the streaming kernel could get
- * wrong.  Per sample i (cell n = cells[i] of the call's arrays, gene genes[i]):
- *   out_path[i]   0 degenerate / 1 inversion / 2 gamma-Poisson          out_count[i]  the count
- *   out_t2[i]     -log2 P(X = 0) in the exact arithmetic (inversion class; else 0)
- *   out_close[i]  min over the evaluated terms of |remainder| / margin, with the device's margins
- *                 margin0 + t2 * margin_per_t2 + margin_per_term * (2 for k = 0..2, 6 for k = 3..6, 10 for 7..10, ...)
- *   out_tail[i]   min over the groups' last terms of |term - 1|  (the end-of-pmf test)
- * (binary32 throughout, the walk exactly as chop_down does it).
- */
-PRNB_EXPORT PRNB_CLONES void prnb_walk_detail(const float* means, int64_t rows, int32_t G, const int32_t* row_of_cell,
-                                              const double* scaling, const double* alpha, const double* beta,
-                                              uint64_t seed, uint64_t cell_offset, const int64_t* cell_index,
-                                              const int64_t* cells, const int32_t* genes, int64_t count,
-                                              float margin0, float margin_per_t2, float margin_per_term,
-                                              int32_t* out_path, int32_t* out_count, float* out_t2,
-                                              float* out_close, float* out_tail)
+/* path (0 degenerate / 1 inversion / 2 gamma-Poisson) and count of selected samples: sample i is cell n = cells[i] of
+ * the call's arrays, gene genes[i] (tests of the list the streaming kernel leaves to its second kernel). */
+PRNB_EXPORT PRNB_CLONES void prnb_sample_selected(const float* means, int64_t rows, int32_t G, const int32_t* row_of_cell,
+                                                  const double* scaling, const double* alpha, const double* beta,
+                                                  uint64_t seed, uint64_t cell_offset, const int64_t* cell_index,
+                                                  const int64_t* cells, const int32_t* genes, int64_t count,
+                                                  int32_t* out_path, int32_t* out_count)
 {
     (void)rows;
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
@@ -450,31 +510,6 @@ PRNB_EXPORT PRNB_CLONES void prnb_walk_detail(const float* means, int64_t rows, 
         out_count[i] = prnb_one(means[(int64_t)row_of_cell[n] * G + g], (float)scaling[n], GENE_A(alpha, g), GENE_BM1(beta, g),
                                 k0, k1, cell, (uint32_t)g, &d);
         out_path[i] = d.path;
-        out_t2[i] = 0.0f; out_close[i] = INFINITY; out_tail[i] = INFINITY;
-        if (d.path != 1) continue;
-        /* the exact walk once more, watching the remainders (prnb_one's arithmetic, chop_down's loop) */
-        float theta = fminf(fmaxf(d.theta, PRNB_THETA_MIN), PRNB_THETA_MAX);
-        float u1 = 1.0f + theta, dd = det_rcp(theta * u1);
-        float inv_th = dd * u1, inv_u1 = dd * theta, q = theta * inv_u1, mp = d.m * inv_u1;
-        float t = d.m * (det_log1p(theta) * inv_th);
-        float t2 = t * 1.44269504f;
-        uint32_t w[4];
-        philox_count((uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)g >> 2, 0u, k0, k1, w);
-        float ps = fminf(det_exp(-t), 0.99999994f) * 4294967296.0f, rem = (float)w[g & 3];
-        float closest = INFINITY, tail = INFINITY;
-        for (int k = 0; ; ) {
-            const float margin = margin0 + t2 * margin_per_t2 + margin_per_term * (k < 3 ? 2.0f : (float)(4 * ((k - 3) / 4) + 6));
-            rem = rem - ps;
-            closest = fminf(closest, fabsf(rem) / margin);
-            if (rem < 0.0f) break;
-            if ((k & 3) == 2) {
-                tail = fminf(tail, fabsf(ps - 1.0f));
-                if (ps < 1.0f) break;
-            }
-            ps = (k == 0) ? ps * mp : ps * FMA(mp - q, g_inv_k[k + 1], q);
-            ++k;
-        }
-        out_t2[i] = t2; out_close[i] = closest; out_tail[i] = tail;
     }
 }
 

@@ -38,11 +38,16 @@ def lib():
                                          ctypes.c_void_p, _i32p, ctypes.c_int64]
         L.prnb_nb_params.argtypes = [_f32p, ctypes.c_int64, ctypes.c_int32, _i32p, _f64p, _f64p, _f64p,
                                      ctypes.c_int64, _f32p, _f32p, _f32p, _i32p]
+        L.prnb_set_hw_tables.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
+                                         ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32]
+        L.prnb_set_hw_tables.restype = None
+        L.prnb_hw_mode.restype = ctypes.c_int
+        L.prnb_hw_math.argtypes = [ctypes.c_int, _f32p, _f32p, ctypes.c_int64]
+        L.prnb_hw_math.restype = None
         _i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
-        L.prnb_walk_detail.argtypes = [_f32p, ctypes.c_int64, ctypes.c_int32, _i32p, _f64p, _f64p, _f64p, ctypes.c_uint64,
-                                       ctypes.c_uint64, ctypes.c_void_p, _i64p, _i32p, ctypes.c_int64, ctypes.c_float,
-                                       ctypes.c_float, ctypes.c_float, _i32p, _i32p, _f32p, _f32p, _f32p]
-        L.prnb_walk_detail.restype = None
+        L.prnb_sample_selected.argtypes = [_f32p, ctypes.c_int64, ctypes.c_int32, _i32p, _f64p, _f64p, _f64p, ctypes.c_uint64,
+                                           ctypes.c_uint64, ctypes.c_void_p, _i64p, _i32p, ctypes.c_int64, _i32p, _i32p]
+        L.prnb_sample_selected.restype = None
         L.prnb_sample_iid.argtypes = [ctypes.c_float, ctypes.c_double, ctypes.c_double, ctypes.c_uint64,
                                       ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int64, _i32p]
         L.prnb_lineage_walk.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, _f64p]
@@ -72,6 +77,61 @@ def count_rounds():
 
 MATH = dict(rcp=0, log=1, log1p=2, exp=3, cos2pi=4, unif=5, log1pmx=6)
 
+# ---- the hardware-function tables of PRNB-5 (see nb_model.c: hw_rcp / hw_log2 / hw_exp2neg) -------------------
+# bit-pattern ranges the tables cover: every argument the sampler can present lies inside
+ONE, TWO, THIRTY_TWO, TWO_M24 = 0x3F800000, 0x40000000, 0x42000000, 0x33800000
+HW_RANGES = dict(rcp=(ONE, TWO - ONE),                       # mantissas: v_rcp_f32 over [1, 2)
+                 log2=(ONE, THIRTY_TWO - ONE),               # v_log_f32 over [1, 32)
+                 exp2neg=(TWO_M24, THIRTY_TWO - TWO_M24))    # v_exp_f32(-x) over [2^-24, 32)
+_HW_TABLES = None      # the installed numpy arrays (kept alive here)
+
+
+def install_hw_tables(probe):
+    """Install the device's tables of the three hardware functions into the model (bit-exact mode).
+    `probe(op, first_bits, count)` returns a float32 array y[i] = HW_op(as_float(first_bits + i)) computed ON THE
+    DEVICE by the product's probe kernel (prosstt_amd.device.Context.hw_math; op in 'rcp', 'log2', 'exp2neg').
+    Idempotent per process."""
+    global _HW_TABLES
+    if _HW_TABLES is not None:
+        return
+    tabs = {}
+    for op, (first, count) in HW_RANGES.items():
+        t = np.ascontiguousarray(probe(op, first, count), np.float32)
+        assert t.shape == (count,)
+        tabs[op] = t
+    lib().prnb_set_hw_tables(tabs["rcp"].ctypes.data, tabs["log2"].ctypes.data, HW_RANGES["log2"][0], HW_RANGES["log2"][1],
+                             tabs["exp2neg"].ctypes.data, HW_RANGES["exp2neg"][0], HW_RANGES["exp2neg"][1])
+    _HW_TABLES = tabs
+
+
+def install_hw_tables_from_device():
+    """install_hw_tables with the product's probe on the current device (tests, smoke(), tools: GPU box only)."""
+    if _HW_TABLES is not None:
+        return
+    from prosstt_amd import device
+    ctx = device.get_context()
+    install_hw_tables(ctx.hw_math)
+
+
+def remove_hw_tables():
+    global _HW_TABLES
+    lib().prnb_set_hw_tables(None, None, 0, 0, None, 0, 0)
+    _HW_TABLES = None
+
+
+def hw_mode():
+    """True: the device's tables are installed (the model equals the kernels bit for bit);
+    False: libm stand-ins (the same law to 1e-6; CPU-only law tests)."""
+    return bool(lib().prnb_hw_mode())
+
+
+def hw_math(op, x):
+    """The model's view of a hardware function (through the installed table, or the libm stand-in)."""
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.empty_like(x)
+    lib().prnb_hw_math(dict(rcp=0, log2=1, exp2neg=2)[op], x, y, x.size)
+    return y
+
 
 def math(which, x):
     x = np.ascontiguousarray(x, np.float32)
@@ -95,25 +155,21 @@ def sample_counts(means, row_of_cell, scaling, alpha, beta, seed, cell_offset=0,
     return out
 
 
-def walk_detail(means, row_of_cell, scaling, alpha, beta, seed, cells, genes, margins, cell_offset=0, cell_index=None):
-    """(path, count, t2, close, tail) of selected samples: how close the exact walk comes to a decision the
-    device's hardware-math evaluation could get wrong (see prnb_walk_detail).  margins = the device's
-    (margin0, margin per unit of t2, margin per term), in units of 2^-32."""
+def sample_selected(means, row_of_cell, scaling, alpha, beta, seed, cells, genes, cell_offset=0, cell_index=None):
+    """(path, count) of the samples (cells[i], genes[i]): path 0 degenerate / 1 inversion / 2 gamma-Poisson."""
     means = np.ascontiguousarray(means, np.float32)
     rows, G = means.shape
     cells = np.ascontiguousarray(cells, np.int64)
     genes = np.ascontiguousarray(genes, np.int32)
-    n = cells.size
-    path, count = np.empty(n, np.int32), np.empty(n, np.int32)
-    t2, close, tail = np.empty(n, np.float32), np.empty(n, np.float32), np.empty(n, np.float32)
+    path, count = np.empty(cells.size, np.int32), np.empty(cells.size, np.int32)
     if cell_index is not None:
         cell_index = np.ascontiguousarray(cell_index, np.int64)
-    lib().prnb_walk_detail(means, rows, G, np.ascontiguousarray(row_of_cell, np.int32),
-                           np.ascontiguousarray(scaling, np.float64), np.ascontiguousarray(alpha, np.float64),
-                           np.ascontiguousarray(beta, np.float64), seed, cell_offset,
-                           cell_index.ctypes.data if cell_index is not None else None, cells, genes, n,
-                           margins[0], margins[1], margins[2], path, count, t2, close, tail)
-    return path, count, t2, close, tail
+    lib().prnb_sample_selected(means, rows, G, np.ascontiguousarray(row_of_cell, np.int32),
+                               np.ascontiguousarray(scaling, np.float64), np.ascontiguousarray(alpha, np.float64),
+                               np.ascontiguousarray(beta, np.float64), seed, cell_offset,
+                               cell_index.ctypes.data if cell_index is not None else None, cells, genes, cells.size,
+                               path, count)
+    return path, count
 
 
 def nb_params(means, row_of_cell, scaling, alpha, beta):

@@ -1,8 +1,7 @@
 // K3h: the samples the streaming kernel (k3_stream.h) listed instead of drawing them: the
-// gamma-Poisson class of PRNB-4 (prnb_device.h; theta above 16 or -log P(X = 0) above 19, one or
-// two in a thousand of a typical workload), the inversion walks whose hardware-math evaluation came
-// too close to a threshold, and the walks that were still running when their strip was done
-// (all redone here from k = 0 with the definition's arithmetic).
+// gamma-Poisson class of PRNB-5 (prnb_device.h; theta above 16 or -log2 P(X = 0) of 27.4 or more, one or
+// two in a thousand of a typical workload), the walks that were still running when their strip was done
+// and the walks that passed k = 254 (both redone here from k = 0).
 // Both halves of the gamma-Poisson path are rejection samplers; run lane-per-sample
 // they would make every wave repeat each half until its unluckiest lane is accepted.  Here
 // every ATTEMPT is a stack entry: a gamma pass runs one Marsaglia-Tsang attempt for 64
@@ -44,11 +43,11 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
     const float* __restrict__ ga, const float* __restrict__ gbm1, int64_t N, uint32_t k0, uint32_t k1,
     uint64_t cell_offset, const int64_t* __restrict__ cell_index, int32_t* __restrict__ out, int64_t ld)
 {
-    __shared__ __attribute__((aligned(16))) float inv_k[prnb::kKTab + 8];   // 0 from the sentinel (k = KTAB-1) on
+    __shared__ __attribute__((aligned(16))) float inv_k[prnb::kKTab];       // 1/k, k < kKTab (a walk ends at kWalkEnd)
     __shared__ HeavyLds lds_all[kHeavyBlock / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     HeavyLds& L = lds_all[wv];
-    for (int k = tid; k < prnb::kKTab + 8; k += kHeavyBlock) inv_k[k] = (k && k < prnb::kKTab - 1) ? 1.0f / (float)k : 0.0f;
+    for (int k = tid; k < prnb::kKTab; k += kHeavyBlock) inv_k[k] = k ? 1.0f / (float)k : 0.0f;
     __syncthreads();
 
     int hg_top = 0, hp_top = 0, hl_top = 0;      // wave-uniform
@@ -202,8 +201,8 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
         while (hp_top >= 64) poisson_pass();
     };
 
-    // ---- inversion walks the streaming kernel left (too close to a threshold, unfinished, above 255): the
-    // definition's arithmetic, every lane walking its own pmf eight terms per pass.  Walks
+    // ---- inversion walks the streaming kernel left (unfinished at the end of their strip, or past k = 254), from
+    // k = 0 again, every lane walking its own pmf eight terms per pass.  Walks
     // differ in length by two orders of magnitude (the unfinished ones are the longest of their strip), so a
     // lane's walk lives in registers across passes and an idle lane takes the next entry of the redo stack:
     // a pass runs with more than half of the lanes walking, and new walks start at least 32 at a time.
@@ -226,8 +225,8 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
         const prnb::Words w = prnb::philox_count((uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)e.g >> 2, 0u, k0, k1);
         const uint32_t sel = (uint32_t)e.g & 3u;
         const uint32_t wj = sel == 0u ? w.w[0] : (sel == 1u ? w.w[1] : (sel == 2u ? w.w[2] : w.w[3]));
-        const float mp = P.m * P.inv_u1, q = P.theta * P.inv_u1, d = mp - q;
-        const float ps = __builtin_fminf(prnb::det_exp(-P.t), 0.99999994f) * 4294967296.0f;
+        const float mp = P.m * P.iu, q = P.theta * P.iu, d = mp - q;
+        const float ps = prnb::hw_exp2(-P.t2) * 4294967296.0f;
         const float r0 = (float)wj - ps;
         const float p1 = ps * mp;
         const float r1 = r0 - p1;
@@ -269,7 +268,7 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
         const float q8 = q7 * PRNB_FMA(wd, ib.z, wq);
         const float b4 = b3 - q8;
         // the remainders only fall: one of a group's four is negative iff its last one is
-        const bool end_a = (a4 < 0.0f) || (q4 < 1.0f);
+        const bool end_a = (a4 < 0.0f) || (q4 < 1.0f) || (wk + 3 >= prnb::kWalkEnd);      // (the walk's last group)
         const bool end_b = (b4 < 0.0f) || (q8 < 1.0f);
         if (__builtin_amdgcn_ballot_w64(busy && (end_a || end_b)) != 0ull) {
             const int32_t at_a = (a1 < 0.0f) ? wk : ((a2 < 0.0f) ? wk + 1 : ((a3 < 0.0f) ? wk + 2 : wk + 3));

@@ -28,16 +28,10 @@
 //   its lanes hold to its own region of a global list -- no atomics: one counter for all waves
 //   serialises them); sample_counts_heavy_kernel (k3_heavy.h) draws them afterwards.
 //
-// Stages 2 and 3 evaluate P(X = 0) with the hardware's v_rcp/v_log/v_exp (each within 1.2e-7 of
-// the true value on gfx950, tools/hwmath_probe.hip) instead of PRNB-4's deterministic binary32
-// arithmetic -- a third of the instructions.  The result must still be the model's, bit for bit:
-// a walk's answer is the first k whose subtraction leaves the remainder negative, so it can
-// only differ from the exact evaluation's when a remainder lies within the two evaluations' distance
-// of 0.  Every lane therefore tracks how close its remainders came to 0 and, when that is
-// within a margin of about three times the worst-case distance (2^-20 + t*2^-19 + k*2^-21 of 2^32,
-// t = -log2 P0), gives the sample up: it goes on the same list, and K3h redoes it with the
-// exact arithmetic (about 1 in 10^3 of the walks).  So does a sample whose class the
-// approximate t cannot decide, and a walk whose end-of-pmf test (a term against 1) is too close to call.
+// P(X = 0) is PRNB-5's: the hardware's v_rcp/v_log/v_exp ARE the definition (prnb_device.h: hw_p0), so
+// stage 2 needs no error margins and no sample is given up because it came close to a threshold (PRNB-4
+// defined P(X = 0) in polynomial arithmetic and paid for margins, a give-up list and K3h redo walks: -5 % of the
+// kernel and -0.03 ms of K3h when removed, profiles/r04_ablation.txt).
 // Results are pure functions of (sample parameters, seed, global cell id, gene), so the
 // order in which the stacks are drained cannot change them.
 //
@@ -62,23 +56,10 @@ constexpr int kS2Cap = 96;         // < 32 left over + 64 pushed by one stage-2 
 constexpr int kS2Run = 32;         // stage 3 runs while S2 holds at least this many entries (8, 16: 3-5 % slower)
 static_assert(kS2Cap >= kS2Run - 1 + 64 && kS1Cap >= 63 + 256, "a stack must take one more pass of pushes");
 constexpr int kRing = 8;           // rows of the strip kept in LDS (8 bits per count) before they are stored; a power of 2
-// Threshold margins of the hardware-math evaluation, in units of 2^-32 (see the header): about
-// three times the worst-case distance between the two evaluations of a running pmf sum C_k --
-//   P0:  |t_exact - t_hw| <= (6.1e-7 + 3.5e-7) * t  (det_log1p 2.5e-7, det_rcp 1.2e-7, four roundings |
-//        log2(u1)*rcp(u1-1) 2.9e-7 measured over (0, 16], one rounding), exp 2.0e-7 + 0.9e-7;
-//   ratios: none (mp - q and q are formed by PRNB-4's own arithmetic here, so the ratio q + (mp - q)/(k+1) of a term
-//        is the same number in both paths): a term adds only the rounding difference of its one multiplication,
-//        2^-24 at most.
-//   the remainder itself: both paths subtract their terms from a binary32 remainder below 2^32, so
-//        each subtraction can round differently by up to ulp(2^32)/2 = 256 units -- far less for the
-//        small remainders of a walk that is about to end, but the margin does not rely on that.
-constexpr float kMargin0 = 4096.0f;          // 2^-20        (worst case 2.9e-7 = 1245 units, + 256)
-constexpr float kMarginPerT2 = 8192.0f;      // 2^-19 per unit of t2 = t / ln 2   (worst case 9.6e-7 * ln 2 = 2858 units)
-constexpr float kMarginPerTerm = 2048.0f;    // 2^-21 per term                   (worst case 1.2e-7 = 515 units, + 256)
-constexpr float kTailBand = 9.765625e-4f;    // a group's last term within 2^-10 of 1: the end-of-pmf test is K3h's
-constexpr float kT2Sure = 27.41120f * (1.0f - 1.53e-5f);   // 19 / ln 2, less 2^-16: surely t <= 19
 constexpr int kBail = 6;           // walks left to K3h when a strip has nothing else to do (see the drain)
 constexpr int kLateCap = 128;      // results that missed their row wait here for one burst of stores (< 64 left + 64)
+constexpr int kRingMaxK3 = 254;    // a walk whose group k3-3..k3 with k3 = 254 ends undecided goes to K3h: counts fit the ring's 8 bits
+constexpr int kInvTab = 260;       // 1/k for k < 260: the reciprocals a pass at k3 <= 254 reads ahead (k3 + 5)
 
 // What stage 1 needs to know about a cell, packed by the preparation kernel so that one scalar load
 // fetches it: byte offset of the cell's row in the mean tensor, library-size factor, (cell index
@@ -121,15 +102,13 @@ __device__ __forceinline__ prnb::Words philox_count_row(const uint32_t ph[4], ui
 }
 
 struct S1Entry { float m, theta, wf; uint32_t pos; };  // theta = a*m + b - 1, not yet clamped; wf = (float)(32-bit uniform)
-struct S2Entry { float ps, mp, q, rem; };             // pmf (x 2^32) at k = 3 and what is left of wf; `mp` holds mp - q: the ratio of step k is q + (mp - q)/(k+1)
-// S2 meta word: the threshold margin of the terms k = 3..6 (binary32, rounded up to 16 significant bits
-// -- it is a bound, and the model knows nothing of it) with pos in the 16 bits that frees
+struct S2Entry { float ps, d, q, rem; };              // pmf (x 2^32) at k = 3, d = mp - q (the ratio of step k is q + d/(k+1)), q, what is left of wf
 
 struct WaveLds {
     S1Entry s1_null;               // m = 0: what a lane of stage 2 reads when the stack holds fewer than 64 entries
     S1Entry s1[kS1Cap];
     S2Entry s2[kS2Cap];
-    uint32_t s2m[kS2Cap];
+    uint32_t s2p[kS2Cap];          // pos of the S2 entries
     uint8_t ring[kRing * 256];     // [row slot][gene-in-tile]; a count of 256 or more is left to K3h
     uint32_t late[kLateCap];       // (pos << 16) | count of results whose row has left the ring already
 };
@@ -158,8 +137,8 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
     int64_t N, uint32_t k0, uint32_t k1, int32_t* __restrict__ out, int64_t ld, int32_t strips,
     int32_t strip_cells, HeavyList heavy)
 {
-    // 1/k for k = -4 .. KTAB+7: 0 below k = 1 (an idle stage-3 lane reads there) and from the sentinel (k = KTAB-1) on
-    __shared__ __attribute__((aligned(16))) float inv_k_store[4 + prnb::kKTab + 8];
+    // 1/k for k = -4 .. kInvTab-1: 0 below k = 1 (never used: an idle stage-3 lane reads anywhere in the block's LDS)
+    __shared__ __attribute__((aligned(16))) float inv_k_store[4 + kInvTab];
     float* const inv_k = inv_k_store + 4;
     __shared__ WaveLds lds_all[kBlock / 64];
 
@@ -167,7 +146,7 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     WaveLds& L = lds_all[wv];
 
-    for (int k = tid - 4; k < prnb::kKTab + 8; k += kBlock) inv_k[k] = (k > 0 && k < prnb::kKTab - 1) ? 1.0f / (float)k : 0.0f;
+    for (int k = tid - 4; k < kInvTab; k += kBlock) inv_k[k] = k > 0 ? 1.0f / (float)k : 0.0f;
     __syncthreads();
 
     // block -> (gene tile, group of 4 strips); adjacent blocks share the gene tile (L2 reuse of
@@ -196,55 +175,68 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
         phi[j] = in ? gphi[g0 + j] : 1.0f;
     }
 
-    int s1_top = 0, s2_top = 0;                      // wave-uniform
+    // The stacks' tops are LDS byte addresses (wave-uniform): s1_at points behind the last S1 entry.
+    const uint32_t s1_lds = (uint32_t)(uintptr_t)&L.s1[0];
+    uint32_t s1_at = s1_lds;
+    int s2_top = 0;                                  // wave-uniform
     constexpr uint32_t kNoHeavy = 0xffffffffu;
     uint32_t hpend = kNoHeavy;                       // pos of the sample this lane holds for the next append to K3h's list
-    // stage-3 lane state
-    float ps = 0.0f, mp = 0.0f, q = 0.0f;              // of a busy lane: the next term, mp - q, q
-    float rem = 0.0f, dl = 0.0f;                     // what is left of wf; this lane's threshold margin (grows with k)
+    // stage-3 lane state: st = {the next term (k = k3 - 3), d = mp - q, q, what is left of wf}; pos; k3 = the walk's
+    // group ends at k3 (6, 10, ...).  An idle lane has st.x = NaN (it then takes part in no mask: NaN compares false)
+    // and a k3 far below zero that the +4 of a pass cannot bring to zero within a strip.
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int kIdleK3 = -(1 << 30) + 2;          // = 2 mod 4: the read-ahead of four reciprocals stays 16-byte aligned
+    f32x4 st = {__builtin_nanf(""), 0.0f, 0.0f, 0.0f};
     uint32_t pos = 0u;
-    constexpr int kIdle = -5;        // k + 1 = 0 mod 4 (the aligned read of four reciprocals), k + 3 < 0 (no result)
-    int k = kIdle;
-    float4 inv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // 1/(k+1) .. 1/(k+4): read one pass ahead
+    int k3 = kIdleK3;
+    f32x4 inv = {0.0f, 0.0f, 0.0f, 0.0f};               // 1/(k+1) .. 1/(k+4): read one pass ahead
+    float nan_v = __builtin_nanf("");
+    int idle_v = kIdleK3;
+    asm volatile("" : "+v"(nan_v), "+v"(idle_v));    // constants kept in registers (v_cndmask below takes them beside an SGPR mask)
 
     // S1/S2 entries carry pos = (cell-in-strip << 8) | gene-in-tile
     int32_t* const strip_out = out + n0 * ld + gbase;
-    const uint32_t ld32 = (uint32_t)ld;              // strip rows * ld < 2^32, checked by the host
+    const uint32_t ld32 = (uint32_t)ld;              // strip rows * ld * 4 < 2^31, checked by the host
     // pos of the last sample whose row has already left the ring (wave-uniform; -1: none)
     int32_t flushed_pos = -1;
     for (int i = lane; i < kRing * 64; i += 64) reinterpret_cast<uint32_t*>(L.ring)[i] = 0u;
     if (lane < 4) reinterpret_cast<uint32_t*>(&L.s1_null)[lane] = 0u;
 
+    // Rows are stored through a buffer resource over the strip's part of the matrix: the row is the scalar offset,
+    // and a lane whose genes lie beyond G carries a vector offset of 2^31 = num_records, which the hardware's range
+    // check drops (gfx950 checks soffset + voffset: tools/buffer_probe.hip) -- no exec switch around the store.
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(strip_out, 0, 0x80000000u, 0x00020000);
+    const uint32_t store_voff = g0 < G ? (uint32_t)lane * 16u : 0x80000000u;
+    uint32_t flush_off = 0u;                         // byte offset of the next row to store (wave-uniform)
+
     // store row `cl` of the strip from ring slot cl % kRing and clear the slot
-    auto flush_row = [&](int cl, int32_t* row_ptr) {
+    auto flush_row = [&](int cl) {
         uint32_t* slot = reinterpret_cast<uint32_t*>(L.ring + (cl & (kRing - 1)) * 256) + lane;
         const uint32_t packed = *slot;
         *slot = 0u;
         const int32_t v[4] = {(int32_t)(packed & 0xffu), (int32_t)((packed >> 8) & 0xffu),
                               (int32_t)((packed >> 16) & 0xffu), (int32_t)(packed >> 24)};
-        int32_t* dst = row_ptr + lane * 4;
-        if (g0 < G) {
-            if (VEC) {
-                // non-temporal: the matrix is written once; keeping it out of L2 leaves that to the mean tensor (-3.8 % on C3)
-                typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
-                const i32x4 row4 = {v[0], v[1], v[2], v[3]};
-                __builtin_nontemporal_store(row4, reinterpret_cast<i32x4*>(dst));
-            } else {
+        if (VEC) {
+            // non-temporal: the matrix is written once; keeping it out of L2 leaves that to the mean tensor (-3.8 % on C3)
+            typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+            const u32x4_ row4 = {(uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]};
+            __builtin_amdgcn_raw_buffer_store_b128(row4, out_rsrc, store_voff, flush_off, 2 /* nt */);
+        } else {
+            int32_t* dst = strip_out + (int64_t)cl * ld + lane * 4;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (g0 + j < G) dst[j] = v[j];
-            }
+            for (int j = 0; j < 4; ++j)
+                if (g0 + j < G) dst[j] = v[j];
         }
+        flush_off += ld32 * 4u;
         flushed_pos = (cl << 8) | 255;
     };
 
     // a finished count (> 0) goes into the row ring while its row is still there, else (rare) on
     // the late list; a burst of 4-B stores empties the list when it is full and when the strip ends,
     // always after the rows' own stores.  That a late 4-B store lands on top of its row's 16-B store rests
-    // on the gfx9 rule that a wave's global_* operations are performed in issue order (it is what makes
+    // on the gfx9 rule that a wave's global_* / buffer_* operations are performed in issue order (it is what makes
     // vmcnt a counter: MI355X_MICROARCH.md, "s_waitcnt vmcnt"; flat_* would not be) -- tests/test_kernel_isa.py
     // checks that this kernel has no flat_ instruction, the whole-matrix tests that no late count is lost.
-    // Every lane of the wave calls this (res = 0: nothing to deliver).
     int late_top = 0;                                // wave-uniform
     auto flush_late = [&]() {
         for (int i = lane; i < late_top; i += 64) {
@@ -297,130 +289,114 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
         }
     };
     // ---- stage 3: four pmf steps for every busy lane; idle lanes pull from S2 ------------------
-    // A lane is idle iff k == kIdle, and an idle lane keeps ps = 0: its "count" k + 3 is negative,
-    // which keeps it out of every mask below, so the arithmetic never asks which lanes are busy.
-    // PRNB-4's walk (the chop-down of prnb_device.h): the terms are subtracted from a binary32 remainder, the count
+    // PRNB-5's walk (the chop-down of prnb_device.h): the terms are subtracted from a binary32 remainder, the count
     // is the first k whose subtraction leaves it negative; when a group of four ends without that
     // and its last term is under 1 (the pmf has fallen under 2^-32) the count is the group's last k.
     // A walk enters at k = 3 and advances by 4: the four reciprocals 1/(k+1)..1/(k+4) are one aligned
     // 16-byte LDS read.  The remainders only fall, so there is a hit iff the last one is negative, and
-    // the hit is at term 4 - (number of negative remainders): sign bits, no compares.
-    // Margin (see the header): a remainder within dl of 0, or the last term within 2^-10 of 1, may come
-    // out differently in the exact arithmetic: the lane stops and leaves its sample to K3h.
+    // the count is k3 less the number of negative remainders among the first three: arithmetic shifts of the
+    // sign bits, no compares.  An idle lane's NaN term makes every remainder NaN: it is in no mask, whatever
+    // its integers hold, so the pass never asks which lanes are busy.
+    const uint32_t s2_lds = (uint32_t)(uintptr_t)&L.s2[0];
+    const uint32_t s2p_lds = (uint32_t)(uintptr_t)&L.s2p[0];
+    const uint32_t inv47_lds = (uint32_t)(uintptr_t)&inv_k[4];
     auto stage3_pass = [&]() {
         unsigned long long idle_m;
-        asm("v_cmp_eq_u32 %0, -5, %1" : "=s"(idle_m) : "v"(k));
-        static_assert(kIdle == -5, "the inline constant above");
+        asm("v_cmp_gt_i32 %0, 0, %1" : "=s"(idle_m) : "v"(k3));
         if (idle_m != 0ull && s2_top > 0) {
+            // the idle lanes take the top entries of S2, under exec = (idle and an entry left): loads only
             const int rank = lane_rank(idle_m);
-            if (k == kIdle && rank < s2_top) {
-                const int idx = s2_top - 1 - rank;
-                const S2Entry e = L.s2[idx];
-                ps = e.ps; mp = e.mp; q = e.q; rem = e.rem;
-                const uint32_t md = L.s2m[idx];
-                pos = md & 0xffffu;
-                dl = prnb::u2f(md);                   // pos rides in the low bits: the margin only grows by it
-                k = 3;
-                inv = *reinterpret_cast<const float4*>(&inv_k[4]);
-            }
+            const unsigned long long take_m = idle_m & K3_MASK(rank < s2_top);
+            const uint32_t idx = (uint32_t)(s2_top - 1 - rank);
+            asm volatile("s_mov_b64 exec, %[tm]\n\t"
+                         "ds_read_b128 %[st], %[ea]\n\t"
+                         "ds_read_b32 %[pos], %[pa]\n\t"
+                         "ds_read_b128 %[inv], %[ia]\n\t"
+                         "v_mov_b32 %[k3], 6\n\t"
+                         "s_mov_b64 exec, -1\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : [st] "+v"(st), [pos] "+v"(pos), [inv] "+v"(inv), [k3] "+v"(k3)
+                         : [tm] "s"(take_m), [ea] "v"(s2_lds + (idx << 4)), [pa] "v"(s2p_lds + (idx << 2)), [ia] "v"(inv47_lds)
+                         : "memory");
             const int left = s2_top - __popcll(idle_m);
             s2_top = left > 0 ? left : 0;
         }
-        const float r1 = rem - ps;
-        const float ps1 = ps * PRNB_FMA(mp, inv.x, q);          // (`mp` holds mp - q here: PRNB-4's ratio q + (mp - q)/(k+1))
+        const float d = st.y, q = st.z;
+        const float r1 = st.w - st.x;
+        const float ps1 = st.x * PRNB_FMA(d, inv.x, q);
         const float r2 = r1 - ps1;
-        const float ps2 = ps1 * PRNB_FMA(mp, inv.y, q);
+        const float ps2 = ps1 * PRNB_FMA(d, inv.y, q);
         const float r3 = r2 - ps2;
-        const float ps3 = ps2 * PRNB_FMA(mp, inv.z, q);
+        const float ps3 = ps2 * PRNB_FMA(d, inv.z, q);
         const float r4 = r3 - ps3;
         const unsigned long long hit_m = K3_MASK(r4 < 0.0f);
         const unsigned long long tail_m = K3_MASK(ps3 < 1.0f);
-        const float near = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fabsf(r1), __builtin_fabsf(r2)),
-                                                           __builtin_fabsf(r3)), __builtin_fabsf(r4));
-        const unsigned long long close_m = K3_MASK(near < dl) | K3_MASK(__builtin_fabsf(ps3 - 1.0f) < kTailBand);
-        const uint32_t nneg = (prnb::f2u(r1) >> 31) + (prnb::f2u(r2) >> 31) + (prnb::f2u(r3) >> 31) + (prnb::f2u(r4) >> 31);
-        const int k4 = k + 4;
-        // a hit at term 4 - nneg: k + 4 - nneg; no hit: the group's last k = k + 3 (taken when the tail test ends the walk)
-        const int32_t res_k = k4 - (int32_t)(nneg > 1u ? nneg : 1u);
-        const unsigned long long busy_m = K3_MASK(res_k > 0);          // an idle lane's is -2
-        const unsigned long long big_m = K3_MASK(res_k > 255);         // does not fit the ring's 8 bits (1 in 10^4): K3h's as well
-        const unsigned long long done_m = hit_m | tail_m | close_m;    // (idle lanes: their ps3 = 0 is under 1)
-        const unsigned long long give_m = (close_m | (big_m & (hit_m | tail_m))) & busy_m;
-        deliver(done_m & busy_m & ~close_m & ~big_m, give_m, pos, (uint32_t)res_k);
-        rem = r4;
-        const float ps4 = ps3 * PRNB_FMA(mp, inv.w, q);
-        dl = dl + 4.0f * kMarginPerTerm;
-        // done lanes go idle (ps = 0, k = kIdle)
-        asm("v_cndmask_b32 %0, %1, 0, %2" : "=v"(ps) : "v"(ps4), "s"(done_m));
-        asm("v_cndmask_b32 %0, %1, -5, %2" : "=v"(k) : "v"(k4), "s"(done_m));
-        inv = *reinterpret_cast<const float4*>(__builtin_assume_aligned(&inv_k[k + 1], 16));   // k + 1 = 0 mod 4
+        const unsigned long long big_m = K3_MASK(k3 >= kRingMaxK3);       // undecided there: the rest of the walk is K3h's
+        // the count: k3 less one for each of r1, r2, r3 that is negative (no hit: they are not, and the count is k3)
+        const int32_t res_k = (k3 + ((int32_t)prnb::f2u(r1) >> 31) + ((int32_t)prnb::f2u(r2) >> 31)) + ((int32_t)prnb::f2u(r3) >> 31);
+        const unsigned long long end_m = hit_m | tail_m;
+        deliver(end_m, big_m & ~end_m, pos, (uint32_t)res_k);
+        const unsigned long long done_m = end_m | big_m;
+        const float ps4 = ps3 * PRNB_FMA(d, inv.w, q);
+        const int k3n = k3 + 4;
+        st.w = r4;
+        // done lanes go idle
+        float ps_next;
+        asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(ps_next) : "v"(ps4), "v"(nan_v), "s"(done_m));
+        st.x = ps_next;
+        asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(k3) : "v"(k3n), "v"(idle_v), "s"(done_m));
+        inv = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(&inv_k[k3 - 2], 16));   // 1/(k+1..k+4), k = k3 - 3
     };
 
     // ---- stage 2: P(X = 0), class test, then the terms k = 0, 1, 2, for up to 64 entries of S1 -------
-    // prnb::make_params with the hardware's log2, reciprocal and exp2 for P(X = 0):
-    // log1p(theta)/theta = log(u1)/(u1 - 1) (u1 = fl(1 + theta): the rounding of the sum cancels),
-    // P0 = 2^-t2; mp and q by PRNB-4's own arithmetic (they multiply
-    // into every term of a walk).  What the approximation cannot decide -- the class of a sample with t within
-    // 2^-16 of 19, a remainder within the margin -- goes to K3h's list.
-    const uint32_t s2_lds = (uint32_t)(uintptr_t)&L.s2[0];
-    const uint32_t s2m_lds = (uint32_t)(uintptr_t)&L.s2m[0];
+    // PRNB-5's parameters (prnb::hw_p0) and first group.  Samples of the gamma-Poisson class go to K3h's list.
     auto stage2_pass = [&]() {
         // Straight-line for every lane (a lane beyond the entries reads a null entry, which is invalid):
         // every wave-level test below is a lane mask formed outside divergent control flow.
-        const int cnt = s1_top < 64 ? s1_top : 64;
-        const int at = s1_top - 1 - lane;
-        const S1Entry e = (&L.s1[0])[at >= 0 ? at : -1];      // s1[-1] is s1_null: invalid, so no mask of the lanes that hold an entry
-        const uint32_t p2 = e.pos;
+        const uint32_t top = s1_at;
+        const int32_t at_b = (int32_t)(top - 16u) - lane * 16;               // byte address of this lane's entry
+        const int32_t at_c = at_b >= (int32_t)s1_lds ? at_b : (int32_t)s1_lds - 16;     // s1[-1] is s1_null: invalid
+        typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+        u32x4_ raw;
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(raw) : "v"(at_c) : "memory");
+        const float m = prnb::u2f(raw.x), theta_raw = prnb::u2f(raw.y), wf = prnb::u2f(raw.z);
+        const uint32_t p2 = raw.w;
         // (m <= 0 or theta <= 0: the count is 0 by definition; stage 1 does not test that)
-        const unsigned long long valid_m = K3_MASK(e.m > 0.0f) & K3_MASK(e.theta > 0.0f);
-        float theta, thetaq;                          // (plain v_max_f32: the builtin puts a canonicalising copy in front)
-        asm("v_max_f32 %0, 0x21800000, %1" : "=v"(theta) : "v"(e.theta));      // prnb::kThetaMin = 2^-60
-        asm("v_max_f32 %0, 0x34000000, %1" : "=v"(thetaq) : "v"(e.theta));     // 2^-23
-        const float u1 = 1.0f + theta;
-        const float inv_u1 = prnb::det_rcp(theta * u1) * theta;
-        const float qq = theta * inv_u1;
-        const float mpp = e.m * inv_u1;
-        // t2 = -log2 P(X = 0) = m * log2(1+theta)/theta; below 2^-23, where 1 + theta is 1 in binary32, the
-        // quotient is taken at 2^-23 (it is log2(e) * (1 - theta/2 + ...): 6e-8 off, well inside the margins)
-        const float u1q = 1.0f + thetaq;
-        const float t2 = e.m * (__builtin_amdgcn_logf(u1q) * __builtin_amdgcn_rcpf(u1q - 1.0f));
-        // inversion class for sure: theta <= 16 and t = t2 * ln 2 below 19 by more than the two
-        // evaluations can differ (NaN: not); every other valid sample is K3h's
-        const unsigned long long light_m = K3_MASK(theta <= prnb::kLightTheta) & K3_MASK(t2 < kT2Sure);
-        const float ps0 = __builtin_amdgcn_exp2f(-t2) * 4294967296.0f;       // pmf scaled by 2^32 (exact scaling)
-        // threshold margin of this sample at k = 2 (in units of 2^-32)
-        const float d2 = PRNB_FMA(t2, kMarginPerT2, kMargin0 + 2.0f * kMarginPerTerm);
-        // PRNB-4's terms: P(k+1) = P(k) * (q + (mp - q)/(k+1)), the ratio by one fma from the 1/k table (k = 0: P(0) * mp)
+        const unsigned long long valid_m = K3_MASK(m > 0.0f) & K3_MASK(theta_raw > 0.0f);
+        const float theta = prnb::clamp_theta_min(theta_raw);
+        const prnb::HwP0 h = prnb::hw_p0(m, theta);
+        const float qq = theta * h.iu;
+        const float mpp = m * h.iu;
+        // inversion class: theta <= 16 and t2 < 19 / ln 2 (NaN: not); every other valid sample is K3h's
+        const unsigned long long light_m = K3_MASK(theta <= prnb::kLightTheta) & K3_MASK(h.t2 < prnb::kLightT2);
+        const float ps0 = prnb::hw_exp2(-h.t2) * 4294967296.0f;       // pmf scaled by 2^32 (exact scaling)
+        // the terms: P(k+1) = P(k) * (q + (mp - q)/(k+1)), the ratio by one fma from the 1/k table (k = 0: P(0) * mp)
         const float dd = mpp - qq;
-        const float r0 = e.wf - ps0;
+        const float r0 = wf - ps0;
         const float ps1 = ps0 * mpp;
         const float r1 = r0 - ps1;
         const float ps2 = ps1 * PRNB_FMA(dd, 0.5f, qq);
         const float r2 = r1 - ps2;
         const unsigned long long hit_m = K3_MASK(r2 < 0.0f);
         const unsigned long long tail_m = K3_MASK(ps2 < 1.0f);
-        const float near = __builtin_fminf(__builtin_fminf(__builtin_fabsf(r0), __builtin_fabsf(r1)), __builtin_fabsf(r2));
-        const unsigned long long close_m = K3_MASK(near < d2) | K3_MASK(__builtin_fabsf(ps2 - 1.0f) < kTailBand);
-        const uint32_t nneg = (prnb::f2u(r0) >> 31) + (prnb::f2u(r1) >> 31) + (prnb::f2u(r2) >> 31);
-        // a hit at term 3 - nneg; no hit: 2 if the tail test ends the walk here
-        const uint32_t res = 3u - (nneg > 1u ? nneg : 1u);
-        const unsigned long long walk_m = valid_m & light_m & ~close_m;       // decided by this kernel
+        // a hit: 2 less one for each of r0, r1 that is negative; no hit: 2 if the tail test ends the walk here
+        const uint32_t res = (uint32_t)((2 + ((int32_t)prnb::f2u(r0) >> 31)) + ((int32_t)prnb::f2u(r1) >> 31));
+        const unsigned long long walk_m = valid_m & light_m;                  // decided by this kernel
+        const unsigned long long end_m = hit_m | tail_m;
         const unsigned long long nz_m = K3_MASK(res != 0u);
-        deliver(walk_m & (hit_m | tail_m) & nz_m, valid_m & ~walk_m, p2, res);
-        s1_top -= cnt;
-        const unsigned long long push_m = walk_m & ~(hit_m | tail_m);
+        deliver(walk_m & end_m & nz_m, valid_m & ~light_m, p2, res);
+        const uint32_t taken = top - s1_lds < 1024u ? top - s1_lds : 1024u;
+        s1_at = top - taken;
+        const unsigned long long push_m = walk_m & ~end_m;
         {
             const uint32_t slot = (uint32_t)s2_top + (uint32_t)lane_rank(push_m);
-            typedef float f32x4 __attribute__((ext_vector_type(4)));
             f32x4 e2;
             e2.x = ps2 * PRNB_FMA(dd, 0.33333334f, qq);      // pmf at k = 3 (the 1/k table's 1/3)
             e2.y = dd;
             e2.z = qq;
             e2.w = r2;
-            // margin of the terms k = 3..6, rounded up to 16 significant bits, | pos
-            const uint32_t m2 = ((prnb::f2u(d2 + 4.0f * kMarginPerTerm) + 0xffffu) & 0xffff0000u) | p2;
             asm volatile("s_mov_b64 exec, %0\n\tds_write_b128 %1, %2\n\tds_write_b32 %3, %4\n\ts_mov_b64 exec, -1"
-                         :: "s"(push_m), "v"(s2_lds + (slot << 4)), "v"(e2), "v"(s2m_lds + (slot << 2)), "v"(m2) : "memory");
+                         :: "s"(push_m), "v"(s2_lds + (slot << 4)), "v"(e2), "v"(s2p_lds + (slot << 2)), "v"(p2) : "memory");
         }
         s2_top += __popcll(push_m);
     };
@@ -432,10 +408,8 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
     // is waited for inside the pass that needs it.
     static_assert(kStripCells == 128, "pos keeps the cell in 7 bits above the gene's 8");
     const CellInfo* cinfo = cellinfo + n0;                   // wave-uniform running pointers
-    int32_t* flush_ptr = strip_out;                          // row cl - kRing of the strip
     const uint32_t lane4 = (uint32_t)lane * 4u;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const uint32_t s1_lds = (uint32_t)(uintptr_t)&L.s1[0];     // LDS byte address of the stack
     const int32_t gload = VEC ? (g0 < G ? g0 : G - 4) - gbase : 0;
     const float* const mcol = means + gbase;
     struct Seg { float M[4]; };
@@ -466,10 +440,7 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
         // every lane runs the whole pass: the stack tops must stay wave-uniform, so no ballot
         // may sit under a divergent branch
         const float M[4] = {cur.M[0], cur.M[1], cur.M[2], cur.M[3]};
-        if (cl >= kRing) {
-            flush_row(cl - kRing, flush_ptr);
-            flush_ptr += ld;
-        }
+        if (cl >= kRing) flush_row(cl - kRing);
         // The scalar loads go out only now, behind the flush's LDS read: scalar and LDS returns
         // share one counter that can only be waited down to zero, and the next LDS read is a
         // whole Philox call away.  (The mean load behind the row store, not in front of it: measured
@@ -485,13 +456,15 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
         ++cinfo;
         __builtin_amdgcn_sched_barrier(0);
         const prnb::Words W = philox_count_row(ph, quad_hi, quad_lo, k0, k1);
-        uint32_t s1_at = s1_lds + ((uint32_t)s1_top << 4);     // LDS byte address of the stack's top (wave-uniform)
         // P(X=0) = exp(-m*log1p(theta)/theta) >= exp(-x) >= 1 - x + x^2/2 - x^3/6, x = m * phi
         // (prnb::zero_test_factor).  The polynomial is evaluated times 2^32 with 1e-5 taken off
-        // the constant term: far more than every rounding of the exact evaluation, so a sample
-        // settled here is one the exact path would also call 0 (and a sample with theta <= 0 is
-        // 0 by definition); it is negative from x = 1.6 on, which keeps every sample of the
+        // the constant term: far more than every rounding and the hardware functions' error of the exact
+        // evaluation, so a sample settled here is one the exact path would also call 0 (and a sample with
+        // theta <= 0 is 0 by definition); it is negative from x = 1.6 on, which keeps every sample of the
         // gamma-Poisson class out.
+        u32x4 e[4];                                            // S1Entry {m, theta, wf, pos}
+        unsigned long long push_m[4];
+        const uint32_t pos4 = posbase | lane4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float m = M[j] * s;
@@ -499,25 +472,55 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
             const float x = m * phi[j];
             const float bound32 = PRNB_FMA(PRNB_FMA(PRNB_FMA(-715827882.7f, x, 2147483648.0f), x, -4294967296.0f),
                                            x, 4294924346.0f);
-            // The compare mask goes straight into an SGPR pair (every lane is active here, so it is
-            // the ballot), the push is one LDS store under exec = mask: no branch, no exec save.
-            // (The stage-1 loop must stay wave-uniform: the asm below ends with exec = -1.)
-            const float wf = (float)W.w[j];                    // PRNB-4's remainder starts as this
-            unsigned long long push_m;
-            asm("v_cmp_nlt_f32 %0, %1, %2" : "=s"(push_m) : "v"(wf), "v"(bound32));   // not settled as 0 (or NaN)
-            u32x4 e;                                           // S1Entry {m, theta, wf, pos}
-            e.x = __float_as_uint(m);
-            e.y = __float_as_uint(PRNB_FMA(a[j], m, bm1[j]));
-            e.z = __float_as_uint(wf);
-            e.w = posbase | (lane4 + j);
-            uint32_t slot;                                     // top of the stack + 16 * rank among the pushing lanes
-            asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(slot) : "v"(lane_rank(push_m)), "s"(s1_at));
-            asm volatile("s_mov_b64 exec, %0\n\tds_write_b128 %1, %2\n\ts_mov_b64 exec, -1"
-                         :: "s"(push_m), "v"(slot), "v"(e) : "memory");
-            asm("s_lshl4_add_u32 %0, %1, %0" : "+s"(s1_at) : "s"(__popcll(push_m)) : "scc");
+            const float wf = (float)W.w[j];                    // the walk's remainder starts as this
+            // The compare mask goes straight into an SGPR pair (every lane is active here, so it is the ballot)
+            asm("v_cmp_nlt_f32 %0, %1, %2" : "=s"(push_m[j]) : "v"(wf), "v"(bound32));   // not settled as 0 (or NaN)
+            e[j].x = __float_as_uint(m);
+            e[j].y = __float_as_uint(PRNB_FMA(a[j], m, bm1[j]));
+            e[j].z = __float_as_uint(wf);
+            e[j].w = pos4 | (uint32_t)j;
         }
-        s1_top = (int)((s1_at - s1_lds) >> 4);
-        while (s1_top >= 64) {
+        // The four pushes: one LDS store each under exec = its mask, at the stack's top + 16 * (rank among the pushing
+        // lanes) -- no branch, no exec save, exec restored once.  (v_mbcnt counts the bits of the mask it is GIVEN below
+        // the lane, so it runs under the mask as well.)
+        {
+            uint32_t t0, t1, t2, t3, c_;
+            asm volatile(
+                "s_mov_b64 exec, %[m0]\n\t"
+                "v_mbcnt_lo_u32_b32 %[t0], exec_lo, 0\n\t"
+                "v_mbcnt_hi_u32_b32 %[t0], exec_hi, %[t0]\n\t"
+                "v_lshl_add_u32 %[t0], %[t0], 4, %[at]\n\t"
+                "ds_write_b128 %[t0], %[e0]\n\t"
+                "s_bcnt1_i32_b64 %[c], exec\n\t"
+                "s_lshl4_add_u32 %[at], %[c], %[at]\n\t"
+                "s_mov_b64 exec, %[m1]\n\t"
+                "v_mbcnt_lo_u32_b32 %[t1], exec_lo, 0\n\t"
+                "v_mbcnt_hi_u32_b32 %[t1], exec_hi, %[t1]\n\t"
+                "v_lshl_add_u32 %[t1], %[t1], 4, %[at]\n\t"
+                "ds_write_b128 %[t1], %[e1]\n\t"
+                "s_bcnt1_i32_b64 %[c], exec\n\t"
+                "s_lshl4_add_u32 %[at], %[c], %[at]\n\t"
+                "s_mov_b64 exec, %[m2]\n\t"
+                "v_mbcnt_lo_u32_b32 %[t2], exec_lo, 0\n\t"
+                "v_mbcnt_hi_u32_b32 %[t2], exec_hi, %[t2]\n\t"
+                "v_lshl_add_u32 %[t2], %[t2], 4, %[at]\n\t"
+                "ds_write_b128 %[t2], %[e2]\n\t"
+                "s_bcnt1_i32_b64 %[c], exec\n\t"
+                "s_lshl4_add_u32 %[at], %[c], %[at]\n\t"
+                "s_mov_b64 exec, %[m3]\n\t"
+                "v_mbcnt_lo_u32_b32 %[t3], exec_lo, 0\n\t"
+                "v_mbcnt_hi_u32_b32 %[t3], exec_hi, %[t3]\n\t"
+                "v_lshl_add_u32 %[t3], %[t3], 4, %[at]\n\t"
+                "ds_write_b128 %[t3], %[e3]\n\t"
+                "s_bcnt1_i32_b64 %[c], exec\n\t"
+                "s_lshl4_add_u32 %[at], %[c], %[at]\n\t"
+                "s_mov_b64 exec, -1"
+                : [at] "+s"(s1_at), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [c] "=&s"(c_)
+                : [m0] "s"(push_m[0]), [m1] "s"(push_m[1]), [m2] "s"(push_m[2]), [m3] "s"(push_m[3]),
+                  [e0] "v"(e[0]), [e1] "v"(e[1]), [e2] "v"(e[2]), [e3] "v"(e[3])
+                : "memory", "scc");
+        }
+        while (s1_at - s1_lds >= 64u * 16u) {
             stage2_pass();
             while (s2_top >= kS2Run) stage3_pass();
         }
@@ -530,7 +533,7 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
     }
 
     // ---- drain ------------------------------------------------------------------------------------
-    while (s1_top > 0) {
+    while (s1_at != s1_lds) {
         stage2_pass();
         while (s2_top >= kS2Run) stage3_pass();
     }
@@ -538,18 +541,18 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
     // pass per cell on the headline workload): once nothing waits on S2 and at most kBail lanes still walk,
     // their samples go on K3h's list instead, which redoes them from the start.
     for (;;) {
-        const unsigned long long busy_m = __builtin_amdgcn_ballot_w64(k != kIdle);
+        const unsigned long long busy_m = __builtin_amdgcn_ballot_w64(k3 > 0);
         if (s2_top == 0) {
             if (busy_m == 0ull) break;
             if (__popcll(busy_m) <= kBail) {
                 if ((busy_m & __builtin_amdgcn_ballot_w64(hpend != kNoHeavy)) != 0ull) flush_heavy();
-                if (k != kIdle) hpend = pos;
+                if (k3 > 0) hpend = pos;
                 break;
             }
         }
         stage3_pass();
     }
-    for (int cl = (cells > kRing ? cells - kRing : 0); cl < cells; ++cl) flush_row(cl, strip_out + (int64_t)cl * ld);
+    for (int cl = (cells > kRing ? cells - kRing : 0); cl < cells; ++cl) flush_row(cl);
     flush_late();
     if (__builtin_amdgcn_ballot_w64(hpend != kNoHeavy) != 0ull) flush_heavy();
     if (lane == 0) {

@@ -1,28 +1,36 @@
-// PRNB-4 count sampler, device side (gfx950).  DESIGN.md section 4 defines it; this header holds
-// its building blocks -- the counter generator, the binary32 functions of the definition, the
+// PRNB-5 count sampler, device side (gfx950).  DESIGN.md section 4 defines it; this header holds
+// its building blocks -- the counter generator, the functions of the definition, the
 // parameters of a sample, the inversion walk -- that the kernels (k3_stream.h, k3_heavy.h,
 // nb_params_kernel) are made of.  Replaces, per (cell, gene):
 //   count_model.get_pr_umi                 /root/reference/prosstt/count_model.py:131-161
 //   scipy.stats.nbinom(n=r,p=1-p).rvs()    /root/reference/prosstt/simulation.py:647-648
 //
-// Every arithmetic step is an IEEE binary32 add / mul / fma / sqrt or an integer
-// op, so results do not depend on the hardware's approximate v_rcp/v_log/v_exp:
-// the translation unit is compiled with -ffp-contract=off and every fused
-// multiply-add below is spelled out.  (Quarter-rate transcendentals would be
-// cheaper per call, but a sampler whose integer output can be checked bit for
-// bit against a scalar model is worth the extra VALU work.)
+// Arithmetic of the definition: IEEE binary32 add / mul / fma / sqrt and integer ops (the translation
+// unit is compiled with -ffp-contract=off and every fused multiply-add below is spelled out), plus --
+// for the inversion class only -- three functions of the gfx950 hardware, HW_RCP = v_rcp_f32,
+// HW_LOG2 = v_log_f32, HW_EXP2 = v_exp_f32 (hw_rcp / hw_log2 / hw_exp2 below: one instruction each,
+// deterministic on the chip).  The scalar model (oracle/nb_model.c) takes the values of those three
+// from tables that a three-line probe kernel (hw_math_kernel, prosstt_amd.hip) writes on the device
+// under test; everything else of the model is its own C.  So counts still compare bit for bit.
+// (PRNB-4 defined P(X = 0) by polynomial log/exp and a Newton reciprocal and let the streaming kernel
+// use the hardware functions inside error margins, with a give-up list for samples near a threshold:
+// a fifth of the kernel's instructions; profiles/r04_ablation.txt.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace prnb {
 
-constexpr float kLightT = 19.0f;       // inversion iff theta <= 16 and t = -log P(X=0) <= 19: P0 * 2^32 >= 24
-constexpr float kLightTheta = 16.0f;   // tail ratio <= 16/17: the walk ends far below the 1/k table's 511 entries
-constexpr float kThetaMin = 8.6736174e-19f;  // 2^-60
+constexpr float kLightT2 = 27.4112f;   // inversion iff theta <= 16 and t2 = -log2 P(X=0) < 27.4112 (= 19 / ln 2): P0 * 2^32 >= 24
+constexpr float kLightTheta = 16.0f;   // tail ratio <= 16/17
+constexpr float kThetaMin = 1.1920929e-7f;   // 2^-23: 1 + theta > 1 in binary32 (below this NB == Poisson to 1e-7 of the variance)
 constexpr float kThetaMax = 1.0e18f;
 constexpr float kRMin = 9.094947e-13f;       // 2^-40
-constexpr int kKTab = 512;                   // entries of the 1/k table; the last one is a 0 sentinel (P(X >= 511) < 1e-10 in the inversion class)
+// The inversion walk ends at k = kWalkEnd at the latest: the group k = 1019..1022 is the last one, and when it ends
+// without a negative remainder the count is 1022 (in the inversion class the mean is below 108 and the tail ratio at
+// most 16/17: P(X > 1022) < 1e-25).  The 1/k table holds 1/k for 1 <= k < kKTab (the K3h walk reads two groups ahead).
+constexpr int kWalkEnd = 1022;
+constexpr int kKTab = 1032;
 constexpr float kPoisInv = 10.0f;
 constexpr float kLamBig = 4194304.0f;        // 2^22
 constexpr int kMaxTries = 64;
@@ -33,6 +41,12 @@ __device__ __forceinline__ uint32_t f2u(float x) { return __float_as_uint(x); }
 __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
 
 struct Words { uint32_t w[4]; };
+
+// The three hardware functions of the definition (one instruction each; the model reads their values from tables
+// written by hw_math_kernel on the same device).
+__device__ __forceinline__ float hw_rcp(float x) { return __builtin_amdgcn_rcpf(x); }     // v_rcp_f32
+__device__ __forceinline__ float hw_log2(float x) { return __builtin_amdgcn_logf(x); }    // v_log_f32
+__device__ __forceinline__ float hw_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
 
 // Philox4x32-R (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11).  Rounds
 // from kXor3From on spell the two 3-input xors as one v_bitop3_b32 each (gfx950); callers whose counter is
@@ -178,18 +192,19 @@ __device__ __forceinline__ float unif(uint32_t w) { return ((float)w + 0.5f) * 2
 __device__ __forceinline__ float det_sqrt(float x) { return __builtin_sqrtf(x); }  // IEEE (see Makefile)
 
 // Inversion by chop-down on a binary32 remainder; inv_k = LDS table of 1/k
-// (16-byte aligned, 0 from the sentinel k = KTAB-1 on, 8 more zeros behind it).
+// (16-byte aligned, kKTab entries).
 // P(k+1) = P(k) * (q + (mp - q)/(k+1)) -- the ratio (mp + k*q)/(k+1) by ONE fma from the table's 1/(k+1); k = 0:
 // P(0) * mp --, carried scaled by 2^32.  The remainder starts as
 // (float)w and every term is subtracted from it; the draw is the first k whose subtraction leaves it
 // negative.  Terms come in groups (k = 0..2, then four at a time: the streaming kernel's passes); when
 // a group ends without a negative remainder and its last term is below 1 (the pmf has fallen under
-// 2^-32 before w is used up: mass lost to rounding, < 1e-6) the draw is that group's last k.
+// 2^-32 before w is used up: mass lost to rounding, < 1e-6) the draw is that group's last k, as it is
+// when the group is the last one (k = kWalkEnd).
 //
-// For a whole wave at once (K3h): every lane carries its own walk, all lanes are at the same k.  A group
-// of four terms is evaluated without a branch per term (terms behind a lane's draw are computed and ignored), and the
-// reciprocals of two groups come from one wave-uniform LDS round trip.  Must be called by all
-// lanes of the wave (`active` = this lane has a walk); returns when no lane is walking any more.
+// For a whole wave at once (K3h's Poisson draws below lambda = 10: q = 0): every lane carries its own walk, all
+// lanes are at the same k.  A group of four terms is evaluated without a branch per term (terms behind a lane's
+// draw are computed and ignored), and the reciprocals of two groups come from one wave-uniform LDS round trip.
+// Must be called by all lanes of the wave (`active` = this lane has a walk); returns when no lane is walking any more.
 __device__ __forceinline__ int32_t chop_down_wave(bool active, uint32_t w, float p0, float mp, float q,
                                                   const float* inv_k)
 {
@@ -216,15 +231,15 @@ __device__ __forceinline__ int32_t chop_down_wave(bool active, uint32_t w, float
         const float a3 = a2 - q3;
         const float q4 = q3 * PRNB_FMA(d, inv.z, q);
         const float a4 = a3 - q4;
-        const bool end = (a1 < 0.0f) || (a2 < 0.0f) || (a3 < 0.0f) || (a4 < 0.0f) || (q4 < 1.0f);
+        const bool end = (a1 < 0.0f) || (a2 < 0.0f) || (a3 < 0.0f) || (a4 < 0.0f) || (q4 < 1.0f) || (k + 3 >= kWalkEnd);
         const int32_t at = (a1 < 0.0f) ? k : ((a2 < 0.0f) ? k + 1 : ((a3 < 0.0f) ? k + 2 : k + 3));
         if (busy && end) { res = at; busy = false; }
         ps = q4 * PRNB_FMA(d, inv.w, q);
         k += 4;
         rem = a4;
     };
-    // two groups per LDS round trip (the table ends in zeros: a walk stops at the sentinel at the latest,
-    // which is the last group this loop can reach)
+    // two groups per LDS round trip (k + 3 reaches kWalkEnd in a first group: the second one then runs with
+    // busy = false everywhere and reads 1/k up to k = kWalkEnd + 5 < kKTab)
     while (__builtin_amdgcn_ballot_w64(busy) != 0ull) {
         const float4 ia = tab[(k - 3) >> 2], ib = tab[((k - 3) >> 2) + 1];
         group(ia);
@@ -250,10 +265,12 @@ __device__ __forceinline__ float logfact_small(int k)
 }
 
 struct Params {
-    float m, theta, inv_th, inv_u1;
-    float t;      // -log P(X = 0) = m * log1p(theta) / theta
-    bool valid;   // m > 0 and theta > 0
-    bool light;   // inversion class: theta <= 16 and t <= 19
+    float m, theta;
+    float iu;      // HW_RCP(1 + theta):  mp = m * iu,  q = theta * iu
+    float t2;      // -log2 P(X = 0) = m * (HW_LOG2(1 + theta) * HW_RCP((1 + theta) - 1))
+    float inv_th;  // det_rcp(theta): r = m * inv_th (gamma-Poisson class)
+    bool valid;    // m > 0 and a*m + b - 1 > 0
+    bool light;    // inversion class: theta <= 16 and t2 < kLightT2
 };
 
 // Per-gene factor of the streaming kernel's zero test.  With theta = a*m + b - 1 >= b - 1 =: c
@@ -272,28 +289,46 @@ __device__ __forceinline__ float zero_test_factor(float a, float bm1)
     return phi;
 }
 
-__device__ __forceinline__ Params make_params_m(float m, float a, float bm1);
-__device__ __forceinline__ Params make_params(float M, float s, float a, float bm1)
+// theta >= 2^-23 as a plain v_max_f32 (the builtin puts a canonicalising copy in front)
+__device__ __forceinline__ float clamp_theta_min(float theta_raw)
 {
-    return make_params_m(M * s, a, bm1);
+    float theta;
+    asm("v_max_f32 %0, 0x34000000, %1" : "=v"(theta) : "v"(theta_raw));
+    return theta;
 }
 
-// the same from the scaled mean m = M * s
+// P(X = 0) of the inversion class by the hardware functions: u1 = fl(1 + theta) > 1; log2(u1)/(u1 - 1) is
+// log2(1 + th')/th' of the th' = u1 - 1 that u1 stands for exactly (the rounding of the sum cancels), within
+// 6e-8 of the same quotient at theta.
+struct HwP0 { float iu, t2; };
+__device__ __forceinline__ HwP0 hw_p0(float m, float theta)
+{
+    HwP0 h;
+    const float u1 = 1.0f + theta;
+    h.iu = hw_rcp(u1);
+    h.t2 = m * (hw_log2(u1) * hw_rcp(u1 - 1.0f));
+    return h;
+}
+
+// the parameters of a sample from its scaled mean m = M * s
 __device__ __forceinline__ Params make_params_m(float m, float a, float bm1)
 {
     Params P;
     P.m = m;
-    float theta = PRNB_FMA(a, P.m, bm1);
-    P.valid = (P.m > 0.0f) && (theta > 0.0f);
-    theta = __builtin_fminf(__builtin_fmaxf(theta, kThetaMin), kThetaMax);
-    const float u1 = 1.0f + theta;
-    const float d = det_rcp(theta * u1);
+    const float theta_raw = PRNB_FMA(a, m, bm1);
+    P.valid = (m > 0.0f) && (theta_raw > 0.0f);
+    const float theta = __builtin_fminf(clamp_theta_min(theta_raw), kThetaMax);
+    const HwP0 h = hw_p0(m, theta);
     P.theta = theta;
-    P.inv_th = d * u1;
-    P.inv_u1 = d * theta;
-    P.t = P.m * (det_log1p(theta) * P.inv_th);
-    P.light = (theta <= kLightTheta) && (P.t <= kLightT);
+    P.iu = h.iu;
+    P.t2 = h.t2;
+    P.inv_th = det_rcp(theta);
+    P.light = (theta <= kLightTheta) && (h.t2 < kLightT2);
     return P;
+}
+__device__ __forceinline__ Params make_params(float M, float s, float a, float bm1)
+{
+    return make_params_m(M * s, a, bm1);
 }
 
 }  // namespace prnb

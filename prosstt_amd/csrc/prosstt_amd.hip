@@ -174,9 +174,20 @@ __global__ void nb_params_kernel(const float* __restrict__ means, int32_t G,
     row = row < 0 ? 0 : (row >= rows ? rows - 1 : row);      // device pointers are unchecked: never a wild read
     const prnb::Params P = prnb::make_params(means[row * G + g], scal[n], ga[g], gbm1[g]);
     if (mu) mu[i] = P.m;
-    if (p) p[i] = P.valid ? P.theta * P.inv_u1 : 0.0f;
+    if (p) p[i] = P.valid ? P.theta * P.iu : 0.0f;
     if (r) r[i] = P.valid ? P.m * P.inv_th : 0.0f;
     if (path) path[i] = !P.valid ? 0 : (P.light ? 1 : 2);
+}
+
+// The probe of PRNB-5's three hardware functions (prnb_device.h: hw_rcp, hw_log2, hw_exp2): their values over a
+// range of binary32 bit patterns, written by the device itself.  The scalar model (oracle/nb_model.c) reads these
+// tables instead of re-implementing the functions.  op: 0 v_rcp_f32(x), 1 v_log_f32(x), 2 v_exp_f32(-x).
+__global__ void hw_math_kernel(int32_t op, uint32_t first_bits, uint64_t count, float* __restrict__ y)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float(first_bits + (uint32_t)i);
+        y[i] = op == 0 ? prnb::hw_rcp(x) : (op == 1 ? prnb::hw_log2(x) : prnb::hw_exp2(-x));
+    }
 }
 
 // order-preserving map double -> uint64 so that max() can be an integer atomic
@@ -573,8 +584,8 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
     if (N > 0 && G > 0) {
         if (!out) return fail(PROSSTT_AMD_EINVAL, "out is NULL");
         if (ld_out < G) return fail(PROSSTT_AMD_EINVAL, "ld_out %lld < G %d", (long long)ld_out, G);
-        if (ld_out * k3::kStripCells >= ((int64_t)1 << 32))
-            return fail(PROSSTT_AMD_EINVAL, "ld_out too large for 32-bit strip offsets");
+        if (ld_out * k3::kStripCells >= ((int64_t)1 << 29))
+            return fail(PROSSTT_AMD_EINVAL, "ld_out too large: a strip's rows must span less than 2 GiB");
         if (N > 0x7fffffffll) return fail(PROSSTT_AMD_EINVAL, "too many cells; chunk them");
         if ((uint64_t)(rows > 0 ? rows : 0) * (uint64_t)G >= ((uint64_t)1 << 61)) return fail(PROSSTT_AMD_EINVAL, "mean tensor too large");
     }
@@ -718,6 +729,32 @@ PA_EXPORT int prosstt_amd_nb_params(prosstt_amd_ctx* c, const float* means, int6
         for (int i = 0; i < 4; ++i)
             if (h[i]) HIP_TRY(hipMemcpyAsync(h[i], d[i], bytes, hipMemcpyDeviceToHost, c->stream));
     if (flags & (PROSSTT_AMD_HOST_OUTPUT | PROSSTT_AMD_HOST_INPUTS)) HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+PA_EXPORT int prosstt_amd_hw_math(prosstt_amd_ctx* c, int32_t op, uint32_t first_bits, uint64_t count, float* out,
+                                  uint32_t flags)
+{
+    if (!c || !out) return fail(PROSSTT_AMD_EINVAL, "NULL argument");
+    if (op < 0 || op > 2) return fail(PROSSTT_AMD_EINVAL, "op must be 0 (rcp), 1 (log2) or 2 (exp2 of -x)");
+    if ((uint64_t)first_bits + count > ((uint64_t)1 << 32)) return fail(PROSSTT_AMD_EINVAL, "the range leaves the 32-bit patterns");
+    if (count == 0) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    float* d = out;
+    Staging st;
+    if (flags & PROSSTT_AMD_HOST_OUTPUT) {
+        void* p = nullptr;
+        int rc = st.alloc(&p, count * 4);
+        if (rc) return rc;
+        d = (float*)p;
+    }
+    const uint64_t blocks = (count + 255) / 256;
+    hw_math_kernel<<<dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, c->stream>>>(op, first_bits, count, d);
+    HIP_TRY(hipGetLastError());
+    if (flags & PROSSTT_AMD_HOST_OUTPUT) {
+        HIP_TRY(hipMemcpyAsync(out, d, count * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     return 0;
 }
 

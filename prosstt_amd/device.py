@@ -119,6 +119,18 @@ class Context:
         n = min(cap, total.value)
         return cells[:n], genes[:n], total.value, bool(over.value)
 
+    HW_OPS = dict(rcp=0, log2=1, exp2neg=2)
+
+    def hw_math(self, op, first_bits, count):
+        """float32 host array y[i] = f(as_float(first_bits + i)), i < count, of one of the three hardware
+        functions of the sampler's definition ('rcp', 'log2', 'exp2neg'), computed by the device
+        (prosstt_amd_hw_math): the tables the checking model is given."""
+        out = np.empty(int(count), np.float32)
+        _native.check(self._lib.prosstt_amd_hw_math(
+            self._h, self.HW_OPS[op], ctypes.c_uint32(first_bits), ctypes.c_uint64(int(count)),
+            out.ctypes.data_as(ctypes.c_void_p), _native.HOST_OUTPUT))
+        return out
+
     def nb_params(self, means, row_of_cell, scaling, alpha, beta):
         """(mu, p, r, path) device tensors (N, G) -- the sampler's deterministic intermediates."""
         torch = _torch()

@@ -43,3 +43,18 @@ def has_gpu():
         return torch.cuda.is_available()
     except Exception:
         return False
+
+
+@pytest.fixture(scope="session", autouse=True)
+def device_hw_tables():
+    """On a GPU box: give the scalar model (oracle/nb_model.c) the device's own tables of the three hardware
+    functions of the sampler's definition (v_rcp_f32, v_log_f32, v_exp_f32 -- written by the product's probe kernel,
+    prosstt_amd_hw_math), so that every comparison of device counts with the model is bit for bit.  Without a GPU
+    the model stays on its libm stand-ins (the same law; no device result is compared then)."""
+    if not has_gpu():
+        yield False
+        return
+    from oracle import nb_model
+    nb_model.install_hw_tables_from_device()
+    assert nb_model.hw_mode()
+    yield True

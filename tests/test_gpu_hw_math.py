@@ -1,0 +1,63 @@
+"""
+-m gpu: the three hardware functions of the sampler's definition (PRNB-5: v_rcp_f32, v_log_f32, v_exp_f32) as the
+scalar model sees them.  The model (oracle/nb_model.c) reads their values from tables written by the product's probe
+kernel (prosstt_amd_hw_math); two of its lookups rest on properties of the hardware that are checked here over
+EVERY argument the sampler can present:
+  * v_rcp_f32(2^e * x) == v_rcp_f32(x) * 2^-e for x in [1, 2): the model keeps one table of 2^23 mantissas;
+  * v_exp_f32(-x) == 1.0 for every 0 <= x < 2^-24 (denormals included): the model's table starts at 2^-24.
+And the accuracy the law rests on (each function within 2e-7 of the true value), and that the probe is what the
+model then returns.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rcp_scales_exactly_with_the_exponent():
+    from prosstt_amd import device
+    ctx = device.get_context()
+    mant = ctx.hw_math("rcp", 0x3F800000, 1 << 23)                  # x in [1, 2)
+    assert mant[0] == 1.0 and (mant > 0.5).all() and (mant <= 1.0).all()
+    # the sampler presents 1 + theta in (1, 1e18] and (1 + theta) - 1 in [2^-23, 1e18]; check 2^-30 .. 2^70
+    for e in range(-30, 70):
+        got = ctx.hw_math("rcp", (127 + e) << 23, 1 << 23)
+        want = np.ldexp(mant, -e)
+        assert np.array_equal(got, want), "exponent %d: %d values differ" % (e, int((got != want).sum()))
+
+
+def test_exp2_of_tiny_arguments_is_one():
+    from prosstt_amd import device
+    ctx = device.get_context()
+    first, end = 0, 0x33800000                                      # bit patterns of [0, 2^-24)
+    step = 1 << 26
+    for lo in range(first, end, step):
+        y = ctx.hw_math("exp2neg", lo, min(step, end - lo))
+        assert (y == 1.0).all(), "v_exp_f32(-x) != 1 for some x with bits in [%#x, %#x)" % (lo, lo + step)
+
+
+def test_accuracy_and_model_lookup():
+    from prosstt_amd import device
+    from oracle import nb_model
+    assert nb_model.hw_mode()
+    ctx = device.get_context()
+    rng = np.random.default_rng(5)
+    # log2 over (1, 17], the quotient log2(u)/(u - 1), exp2(-t2) over [0, 27.4112): relative to binary64
+    u = np.concatenate([1.0 + np.exp(rng.uniform(np.log(2.0 ** -23), np.log(16.0), 400000)), [1.0 + 2.0 ** -23, 17.0]]).astype(np.float32)
+    lg = nb_model.hw_math("log2", u)
+    ref = np.log2(u.astype(np.float64))
+    assert np.max(np.abs(lg - ref) / np.abs(ref)) < 2e-7
+    um1 = (u - np.float32(1.0)).astype(np.float32)
+    quo = (lg * nb_model.hw_math("rcp", um1)).astype(np.float64)
+    assert np.max(np.abs(quo / (ref / um1.astype(np.float64)) - 1)) < 4e-7
+    t2 = np.concatenate([rng.uniform(0, 27.4112, 400000), np.exp(rng.uniform(np.log(1e-9), 0, 100000))]).astype(np.float32)
+    ex = nb_model.hw_math("exp2neg", t2)
+    assert np.max(np.abs(ex / np.exp2(-t2.astype(np.float64)) - 1)) < 2e-7
+    r = nb_model.hw_math("rcp", u)
+    assert np.max(np.abs(r * u.astype(np.float64) - 1)) < 1.5e-7
+    # the model's lookups are the probe's values
+    for op, x in (("log2", u), ("rcp", u), ("rcp", um1), ("exp2neg", t2[t2 >= 2.0 ** -24])):
+        bits = x.view(np.uint32)
+        pick = rng.choice(len(bits), 2000, replace=False)
+        dev = np.array([ctx.hw_math(op, int(b), 1)[0] for b in bits[pick[:200]]])
+        assert np.array_equal(dev, nb_model.hw_math(op, x[pick[:200]]))

@@ -1,8 +1,7 @@
 """
 -m gpu: whole matrices, not samples of them.
   * C3 (50 000 x 20 000 = 1e9 counts, the headline workload), C4 (200 000 x 20 000) and C2 (5 000 x 5 000) compared with the
-    scalar C model count for count: every class of sample, every threshold margin of the hardware-math
-    evaluation, every late result and list entry of the full launch (the model runs on all host cores,
+    scalar C model count for count: every class of sample, every late result and list entry of the full launch (the model runs on all host cores,
     block by block, so the host never holds more than one block of expected counts);
   * C5 at its full 1 000 000 cells x 30 000 genes on ONE GPU, the way eight GPUs would split it: the
     eight branch shards (cell_index = positions in the global plan) give, cell for cell, the row
@@ -154,16 +153,12 @@ def test_c5_full_size_eight_shards_on_one_gpu():
           % (N, G, work.info["attempts"], work.info["lineage_s"], total / mu_sum))
 
 
-def test_the_give_up_path_is_live_and_every_listed_sample_has_a_reason():
-    """Stages 2 and 3 of the streaming kernel evaluate P(X = 0) with the hardware's log/rcp/exp and leave a
-    sample to the second kernel when the exact arithmetic could decide otherwise.
-    On C3: the list of the last launch is read back (prosstt_amd_last_list) and every entry must have a
-    reason in the EXACT arithmetic of the model: the gamma-Poisson class, a class the approximate t cannot
-    decide, a count above 255, a remainder within (a generous multiple of) the margin of zero, an
-    end-of-pmf term near 1, or a walk still running when its strip was otherwise done (a few per wave).  The margins themselves must be doing work (near-threshold walks > 0), the list
-    must stay far below its capacity, and -- the other direction -- samples that are NOT listed and come
-    close to a threshold in the exact arithmetic must be rare and still drawn right (the whole-matrix
-    tests above compare every count)."""
+def test_every_listed_sample_has_a_reason():
+    """The streaming kernel draws the inversion class itself and lists for the second kernel (K3h) only: the
+    gamma-Poisson class, the few walks still running when their strip of 64 cells had nothing else to do (at most
+    k3::kBail = 6 per wave), and walks past k = 254 (the row ring holds 8 bits).  On C3 the list of the last launch
+    is read back (prosstt_amd_last_list): every entry must be one of those in the model, no sample of the
+    gamma-Poisson class of a block of cells may be missing from it, and what K3h wrote is the model's count."""
     import torch
     from prosstt_amd import device, workloads
     from oracle import nb_model
@@ -175,43 +170,26 @@ def test_the_give_up_path_is_live_and_every_listed_sample_has_a_reason():
     X = ctx.sample_counts(means, rows, sc, work.alpha, work.beta, seed=424242)
     cells, genes, total, overflowed = ctx.last_list()
     assert not overflowed and total == len(cells)
-    assert 2e5 < total < 0.01 * N * work.tree.G            # ~1.5e6 of 1e9 samples
-    margins = (4096.0, 8192.0, 2048.0)                    # k3_stream.h: kMargin0, kMarginPerT2, kMarginPerTerm
-    path, count, t2, close, tail = nb_model.walk_detail(means.cpu().numpy(), rows, sc, work.alpha, work.beta, 424242,
-                                                        cells, genes, margins)
-    # what the second kernel wrote for them is the model's count
+    assert 2e5 < total < 0.01 * N * work.tree.G            # ~1.4e6 of 1e9 samples
+    host_means = means.cpu().numpy()
+    path, count = nb_model.sample_selected(host_means, rows, sc, work.alpha, work.beta, 424242, cells, genes)
     got = X[torch.as_tensor(cells, device=X.device), torch.as_tensor(genes.astype(np.int64), device=X.device)].cpu().numpy()
     np.testing.assert_array_equal(got, count)
-    heavy = path == 2
-    big = (path == 1) & (count > 255)
-    t2_sure = 27.41120 * (1.0 - 1.53e-5)
-    undecided = (path == 1) & (t2 >= t2_sure * (1 - 3e-6))            # the approximate t2 may differ by 1e-6 relative
-    near = (path == 1) & (close < 1.5)                                # device remainder within its margin => exact one within 1.5 margins
-    tailband = (path == 1) & (tail < 2 * 9.765625e-4)
-    explained = heavy | big | undecided | near | tailband
     assert path.min() >= 1                                            # degenerate samples are never listed
-    # what is left: walks that were still running when their strip had nothing else to do (at most k3::kBail = 6
-    # per wave; they entered stage 3, so the count is at least 3)
-    leftover = ~explained
+    heavy = path == 2
+    big = (path == 1) & (count > 254)
+    leftover = ~(heavy | big)                                         # unfinished walks: they entered stage 3, so count >= 3
     waves = -(-N // 64) * -(-work.tree.G // 256)
     assert leftover.sum() <= 6 * waves and (count[leftover] >= 3).all(), \
         "%d listed samples without a reason" % int((leftover & (count < 3)).sum())
-    assert heavy.sum() > 1e5 and near.sum() > 1e4                     # both classes of entries occur
-    print("[list] %d entries: gamma-Poisson %d, near a threshold %d, undecidable class %d, above 255: %d, tail band %d, "
-          "unfinished at the end of their strip %d"
-          % (total, heavy.sum(), (near & ~heavy).sum(), undecided.sum(), big.sum(), tailband.sum(), leftover.sum()))
-    # the other direction, on a block of cells: exact walks that come within a THIRD of the margin of a threshold
-    # (where the two evaluations may really disagree) must all have been listed
+    assert heavy.sum() > 1e5
+    print("[list] %d entries: gamma-Poisson %d, above 254: %d, unfinished at the end of their strip %d"
+          % (total, heavy.sum(), big.sum(), leftover.sum()))
+    # the other direction, on a block of cells: every sample of the gamma-Poisson class is on the list
     blk = np.arange(2000, 2300)
-    bc = np.repeat(blk, work.tree.G).astype(np.int64)
-    bg = np.tile(np.arange(work.tree.G, dtype=np.int32), len(blk))
-    bpath, bcount, bt2, bclose, btail = nb_model.walk_detail(means.cpu().numpy(), rows, sc, work.alpha, work.beta, 424242,
-                                                             bc, bg, margins)
-    risky = (bpath == 1) & (bclose < 1.0 / 3.0) & (bt2 < t2_sure)
-    listed = set(zip(cells[(cells >= 2000) & (cells < 2300)].tolist(), genes[(cells >= 2000) & (cells < 2300)].tolist()))
-    # a walk ends at its first negative remainder: only thresholds up to there count, which is what `close` tracks
-    missing = [(int(c), int(g)) for c, g in zip(bc[risky], bg[risky]) if (int(c), int(g)) not in listed]
-    stage1_zero = [cg for cg in missing if bcount[(bc == cg[0]) & (bg == cg[1])][0] == 0]
-    # (a sample settled as 0 by stage 1's bound never reaches the margin test: its uniform is below the bound,
-    # hence more than 1e-5 * 2^32 below the first threshold -- it cannot be `risky`)
-    assert not missing, "%d risky samples were not listed (%d of them zeros)" % (len(missing), len(stage1_zero))
+    bpath = nb_model.nb_params(host_means, rows[blk], sc[blk], work.alpha, work.beta)[3]
+    bc, bg = np.nonzero(bpath == 2)
+    in_blk = (cells >= 2000) & (cells < 2300)
+    listed = set(zip(cells[in_blk].tolist(), genes[in_blk].tolist()))
+    missing = [(int(c) + 2000, int(g)) for c, g in zip(bc, bg) if (int(c) + 2000, int(g)) not in listed]
+    assert len(bc) > 100 and not missing, "%d samples of the gamma-Poisson class were not listed" % len(missing)

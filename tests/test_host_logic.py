@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_native.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert _native.load().prosstt_amd_version() == 310
+    assert _native.load().prosstt_amd_version() == 400
 
 
 def test_no_cpu_fallback():

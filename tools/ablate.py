@@ -118,6 +118,30 @@ VARIANTS = {
               ("constexpr int kLateCap = 128;", "constexpr int kLateCap = 64;")],
     "run40": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 40;"), ("constexpr int kS2Cap = 96;", "constexpr int kS2Cap = 104;"),
               ("constexpr int kLateCap = 128;", "constexpr int kLateCap = 64;")],
+    # round 4: what the margin protocol costs (timing only): no near/dl/tail-band/close_m, v_rcp_f32 for det_rcp, no margin word
+    "nomargin": [
+        ("        const float near = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fabsf(r1), __builtin_fabsf(r2)),\n"
+         "                                                           __builtin_fabsf(r3)), __builtin_fabsf(r4));\n"
+         "        const unsigned long long close_m = K3_MASK(near < dl) | K3_MASK(__builtin_fabsf(ps3 - 1.0f) < kTailBand);",
+         "        const unsigned long long close_m = 0ull;"),
+        ("        dl = dl + 4.0f * kMarginPerTerm;\n", ""),
+        ("        const float inv_u1 = prnb::det_rcp(theta * u1) * theta;", "        const float inv_u1 = __builtin_amdgcn_rcpf(u1);"),
+        ("        const float near = __builtin_fminf(__builtin_fminf(__builtin_fabsf(r0), __builtin_fabsf(r1)), __builtin_fabsf(r2));\n"
+         "        const unsigned long long close_m = K3_MASK(near < d2) | K3_MASK(__builtin_fabsf(ps2 - 1.0f) < kTailBand);",
+         "        const unsigned long long close_m = 0ull;"),
+        ("            const uint32_t m2 = ((prnb::f2u(d2 + 4.0f * kMarginPerTerm) + 0xffffu) & 0xffff0000u) | p2;", "            const uint32_t m2 = p2;"),
+        ("        const unsigned long long light_m = K3_MASK(theta <= prnb::kLightTheta) & K3_MASK(t2 < kT2Sure);",
+         "        const unsigned long long light_m = K3_MASK(theta <= prnb::kLightTheta) & K3_MASK(t2 < 27.4112f);"),
+    ],
+    # round 4: K3h on a second stream with no dependency on the stream kernel (it reads the PREVIOUS call's list: timing only) --
+    # the upper bound of what overlapping the two kernels can give
+    "k3h_overlap": [
+        ("    k3::sample_counts_heavy_kernel<<<dim3((unsigned)c->heavy_grid), dim3(k3::kHeavyBlock), 0, c->stream>>>(",
+         "    static hipStream_t s2 = nullptr; static hipEvent_t e2 = nullptr;\n"
+         "    if (!s2) { HIP_TRY(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&e2, hipEventDisableTiming)); }\n"
+         "    k3::sample_counts_heavy_kernel<<<dim3((unsigned)c->heavy_grid), dim3(k3::kHeavyBlock), 0, s2>>>("),
+        ("    c->list = heavy.list;\n", "    HIP_TRY(hipEventRecord(e2, s2)); HIP_TRY(hipStreamWaitEvent(c->stream, e2, 0));\n    c->list = heavy.list;\n"),
+    ],
     # mean segments one cell ahead, requested at the END of a pass (one register rotation; the row store gets a whole pass before anything waits behind it)
     "pf1": [("        const Seg nn = load_seg(row2);\n        const uint64_t row3 = cinfo[3].row_bytes;",
              "        const uint64_t row3 = cinfo[3].row_bytes;"),
