@@ -44,6 +44,7 @@
 // binary32 arithmetic on a binary32 remainder (PRNB-4), hits are counted from sign bits, wave-level
 // tests are lane masks formed by ONE compare each, and per-cell values arrive by scalar loads.
 #pragma once
+#include <type_traits>
 #include "prnb_device.h"
 
 namespace k3 {
@@ -350,15 +351,18 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
 
     // ---- stage 2: P(X = 0), class test, then the terms k = 0, 1, 2, for up to 64 entries of S1 -------
     // PRNB-5's parameters (prnb::hw_p0) and first group.  Samples of the gamma-Poisson class go to K3h's list.
-    auto stage2_pass = [&]() {
+    uint32_t lane16p = (uint32_t)lane * 16u + 16u;
+    asm volatile("" : "+v"(lane16p));          // (kept as one register: top - lane16p is one instruction)
+    // full = the stack holds at least 64 entries (every pass of the strip loop; the drain's may not)
+    auto stage2_pass = [&](auto full_tag) {
+        constexpr bool kFull = decltype(full_tag)::value;
         // Straight-line for every lane (a lane beyond the entries reads a null entry, which is invalid):
         // every wave-level test below is a lane mask formed outside divergent control flow.
         const uint32_t top = s1_at;
-        const int32_t at_b = (int32_t)(top - 16u) - lane * 16;               // byte address of this lane's entry
-        const int32_t at_c = at_b >= (int32_t)s1_lds ? at_b : (int32_t)s1_lds - 16;     // s1[-1] is s1_null: invalid
+        int32_t at_c = (int32_t)(top - lane16p);                               // byte address of this lane's entry
+        if (!kFull) at_c = at_c > (int32_t)(s1_lds - 16u) ? at_c : (int32_t)(s1_lds - 16u);      // s1[-1] is s1_null: invalid
         typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
-        u32x4_ raw;
-        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(raw) : "v"(at_c) : "memory");
+        const u32x4_ raw = *reinterpret_cast<const __attribute__((address_space(3))) u32x4_*>((uint32_t)at_c);
         const float m = prnb::u2f(raw.x), theta_raw = prnb::u2f(raw.y), wf = prnb::u2f(raw.z);
         const uint32_t p2 = raw.w;
         // (m <= 0 or theta <= 0: the count is 0 by definition; stage 1 does not test that)
@@ -383,9 +387,8 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
         const uint32_t res = (uint32_t)((2 + ((int32_t)prnb::f2u(r0) >> 31)) + ((int32_t)prnb::f2u(r1) >> 31));
         const unsigned long long walk_m = valid_m & light_m;                  // decided by this kernel
         const unsigned long long end_m = hit_m | tail_m;
-        const unsigned long long nz_m = K3_MASK(res != 0u);
-        deliver(walk_m & end_m & nz_m, valid_m & ~light_m, p2, res);
-        const uint32_t taken = top - s1_lds < 1024u ? top - s1_lds : 1024u;
+        deliver(walk_m & end_m, valid_m & ~light_m, p2, res);        // (a count of 0 is written as well: the ring slot holds 0 anyway)
+        const uint32_t taken = kFull ? 1024u : (top - s1_lds < 1024u ? top - s1_lds : 1024u);
         s1_at = top - taken;
         const unsigned long long push_m = walk_m & ~end_m;
         {
@@ -439,14 +442,16 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
     for (int cl = 0; cl < cells; ++cl) {
         // every lane runs the whole pass: the stack tops must stay wave-uniform, so no ballot
         // may sit under a divergent branch
-        const float M[4] = {cur.M[0], cur.M[1], cur.M[2], cur.M[3]};
+        const float m4[4] = {cur.M[0] * s, cur.M[1] * s, cur.M[2] * s, cur.M[3] * s};
         if (cl >= kRing) flush_row(cl - kRing);
         // The scalar loads go out only now, behind the flush's LDS read: scalar and LDS returns
         // share one counter that can only be waited down to zero, and the next LDS read is a
         // whole Philox call away.  (The mean load behind the row store, not in front of it: measured
         // 4 % faster, although the end-of-pass wait for the load then includes the store -- hipcc waits
         // for vmcnt(0) whenever a load and a store are both pending; a hand-counted vmcnt(1) behind a
-        // load issued first bought nothing.)
+        // load issued first bought nothing.  Two cells ahead: loading the next cell's segment and record in
+        // place, into the registers this pass has just finished with, saves the ten moves of the rotation
+        // below and is 4-5 % slower -- profiles/r04_ablation.txt, inplace1.)
         __builtin_amdgcn_sched_barrier(0);
         const Seg nn = load_seg(row2);
         const uint64_t row3 = cinfo[3].row_bytes;
@@ -456,6 +461,7 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
         ++cinfo;
         __builtin_amdgcn_sched_barrier(0);
         const prnb::Words W = philox_count_row(ph, quad_hi, quad_lo, k0, k1);
+        const uint32_t pos4 = posbase | lane4;
         // P(X=0) = exp(-m*log1p(theta)/theta) >= exp(-x) >= 1 - x + x^2/2 - x^3/6, x = m * phi
         // (prnb::zero_test_factor).  The polynomial is evaluated times 2^32 with 1e-5 taken off
         // the constant term: far more than every rounding and the hardware functions' error of the exact
@@ -464,10 +470,9 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
         // gamma-Poisson class out.
         u32x4 e[4];                                            // S1Entry {m, theta, wf, pos}
         unsigned long long push_m[4];
-        const uint32_t pos4 = posbase | lane4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float m = M[j] * s;
+            const float m = m4[j];
             // (packed binary32 instructions for two bounds at a time were tried: fewer instructions, 2 % slower)
             const float x = m * phi[j];
             const float bound32 = PRNB_FMA(PRNB_FMA(PRNB_FMA(-715827882.7f, x, 2147483648.0f), x, -4294967296.0f),
@@ -521,7 +526,7 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
                 : "memory", "scc");
         }
         while (s1_at - s1_lds >= 64u * 16u) {
-            stage2_pass();
+            stage2_pass(std::true_type{});
             while (s2_top >= kS2Run) stage3_pass();
         }
         cur = nxt;
@@ -534,7 +539,7 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
 
     // ---- drain ------------------------------------------------------------------------------------
     while (s1_at != s1_lds) {
-        stage2_pass();
+        stage2_pass(std::false_type{});
         while (s2_top >= kS2Run) stage3_pass();
     }
     // The last walks of a strip would run with a handful of busy lanes (13 % of the lanes over a quarter of a

@@ -142,6 +142,29 @@ VARIANTS = {
          "    k3::sample_counts_heavy_kernel<<<dim3((unsigned)c->heavy_grid), dim3(k3::kHeavyBlock), 0, s2>>>("),
         ("    c->list = heavy.list;\n", "    HIP_TRY(hipEventRecord(e2, s2)); HIP_TRY(hipStreamWaitEvent(c->stream, e2, 0));\n    c->list = heavy.list;\n"),
     ],
+    # round 4 (real variant): the next cell's record loaded mid-pass into the registers this pass has finished with (no scalar rotation)
+    "inplace_scalars": [
+        ("""        const float s_next = cinfo[1].s;
+        const uint32_t posbase_next = cinfo[1].pos_base;
+        const uint32_t ph_next[4] = {cinfo[1].ph[0], cinfo[1].ph[1], cinfo[1].ph[2], cinfo[1].ph[3]};
+        ++cinfo;
+        __builtin_amdgcn_sched_barrier(0);
+        const prnb::Words W = philox_count_row(ph, quad_hi, quad_lo, k0, k1);
+        const uint32_t pos4 = posbase | lane4;
+""", """        __builtin_amdgcn_sched_barrier(0);
+        const prnb::Words W = philox_count_row(ph, quad_hi, quad_lo, k0, k1);
+        const uint32_t pos4 = posbase | lane4;
+        __builtin_amdgcn_sched_barrier(0);
+        s = cinfo[1].s; posbase = cinfo[1].pos_base;
+        ph[0] = cinfo[1].ph[0]; ph[1] = cinfo[1].ph[1]; ph[2] = cinfo[1].ph[2]; ph[3] = cinfo[1].ph[3];
+        ++cinfo;
+        __builtin_amdgcn_sched_barrier(0);
+"""),
+        ("""        s = s_next;
+        ph[0] = ph_next[0]; ph[1] = ph_next[1]; ph[2] = ph_next[2]; ph[3] = ph_next[3];
+        posbase = posbase_next;
+""", ""),
+    ],
     # mean segments one cell ahead, requested at the END of a pass (one register rotation; the row store gets a whole pass before anything waits behind it)
     "pf1": [("        const Seg nn = load_seg(row2);\n        const uint64_t row3 = cinfo[3].row_bytes;",
              "        const uint64_t row3 = cinfo[3].row_bytes;"),
@@ -165,7 +188,7 @@ def build(name):
     for fn, text in files.items():
         open(os.path.join(work, "prosstt_amd", "csrc", fn), "w").write(text)
     lib = os.path.join(OUT, "libprosstt_amd_%s.so" % name)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
                            "-fPIC", "-shared", "-fvisibility=hidden", "-o", lib,
                            os.path.join(work, "prosstt_amd", "csrc", "prosstt_amd.hip")])
     shutil.rmtree(work, ignore_errors=True)
