@@ -19,9 +19,10 @@ carries ``gather_ms`` (the one exchange of the path: count rows to rank 0, point
 ``strong_scaling``: C4 (200 000 cells) and C5 (1 000 000 cells) split over the N GPUs.
 
 One JSON line on rank 0.
- * ``ms_per_step`` / ``value``: the sampler as bench.py calls it (no domain check);
-   ``ms_per_step_strict``: the product API's default (``strict=True``: the domain check of the
-   reference's scipy call -- three more kernels, a copy back and a sync).
+ * ``ms_per_step`` / ``value`` (= ``ms_per_step_strict``): the sampler as the product API calls it by default
+   (``strict=True``: the reference's argument check rides in the call's own kernels, its verdict is read
+   behind the timed steps); ``ms_per_step_unchecked``: the same without the check; ``ms_per_step_cold``: the
+   first five steps of the process, before any clock ramp (what a user's first calls see).
  * ``roofline``: the dominant kernel (k3::sample_counts_stream_kernel): algorithmic bytes per
    launch (DESIGN.md section 6) / its mean duration from HIP events on the launch stream;
    ``frac_whole_step`` prices the same bytes against ms_per_step (K3h, prep kernels, launch gaps
@@ -273,10 +274,24 @@ def run_case(job, config, scaling, cells_per_gpu, steps, warmup, strict_steps, g
     d_idx = ctx.tensor(mine, torch.int64)
     out = torch.empty((len(mine), G), dtype=torch.int32, device=ctx.torch_device)
 
-    def step(seed, timed=False, strict=False):
-        ctx.sample_counts(means, d_rows, d_sc, d_al, d_be, seed=seed, out=out, cell_index=d_idx,
-                          check_domain=strict, time_kernel=timed)
+    token = tree.means_token()
 
+    def step(seed, timed=False, strict=True):
+        # strict: the product API's default -- the reference's argument check (scipy behind simulation.py:647-648), riding in
+        # the call's own kernels, its verdict read once behind the timed steps (simulation.draw_counts reads it behind the
+        # copy to the host); the per-row flags of the mean tensor are kept while the tensor is unchanged
+        ctx.sample_counts(means, d_rows, d_sc, d_al, d_be, seed=seed, out=out, cell_index=d_idx,
+                          check_domain="deferred" if strict else False, time_kernel=timed, means_token=token)
+
+    # The first steps of a process, before anything has loaded the device: idle clocks, cold code (reported as
+    # ms_per_step_cold; a user's first calls see this, not the steady state below).
+    job.fence()
+    t0 = time.perf_counter()
+    for i in range(5):
+        step(3000 + i)
+    ctx.domain_status()
+    job.fence()
+    ms_cold = job.max_over_ranks(time.perf_counter() - t0) / 5 * 1e3
     # The device comes out of the (mostly host-side) setup at idle clocks and takes a few hundred ms of load to
     # reach the clock it then holds (measured: the same kernel 1.88 ms in the first 3 steps, 1.63 ms after 60);
     # the W warmup steps of the contract are too short for that, so untimed passes of the same step run first.
@@ -290,26 +305,29 @@ def run_case(job, config, scaling, cells_per_gpu, steps, warmup, strict_steps, g
             ramp_calls += 8
     for i in range(warmup):
         step(1000 + i)
+    ctx.domain_status()
     job.fence()
     t0 = time.perf_counter()
     for i in range(steps):
         step(i, timed=True)                    # HIP events bracket K3 on the launch stream
+    ctx.domain_status()                        # the verdict of the K checked steps (synchronises; inside the timed region)
     job.fence()
     elapsed = job.max_over_ranks(time.perf_counter() - t0)
     kms = job.max_over_ranks(ctx.last_kernel_ms())      # mean over the K launches of the timed region
     res = dict(work=work, plan=(pt, br, sc), G=G, n_total=n_total, per_gpu=per_gpu, cells_on_rank=int(len(mine)),
                ms_per_step=elapsed / steps * 1e3, value=n_total * G / (elapsed / steps), kernel_ms=kms,
-               rows_total=work.info["resident_rows"], ms_strict=None, gather_ms=None, ramp_calls=ramp_calls)
+               rows_total=work.info["resident_rows"], ms_unchecked=None, ms_cold=ms_cold, gather_ms=None,
+               ramp_calls=ramp_calls)
 
-    # the product API's default: with the domain check of the reference's scipy call
+    # the same steps without the domain check (strict=False)
     if strict_steps > 0:
-        step(99, strict=True)
+        step(99, strict=False)
         job.fence()
         t0 = time.perf_counter()
         for i in range(strict_steps):
-            step(i, strict=True)
+            step(i, strict=False)
         job.fence()
-        res["ms_strict"] = job.max_over_ranks(time.perf_counter() - t0) / strict_steps * 1e3
+        res["ms_unchecked"] = job.max_over_ranks(time.perf_counter() - t0) / strict_steps * 1e3
 
     # sanity inside the bench: first moment of this rank's shard (catches a silently dead kernel)
     mu_sum = float((means.double().sum(dim=1)[d_rows.long()] * d_sc).sum())
@@ -362,7 +380,7 @@ def main():
     ap.add_argument("--cpu-cells", type=int, default=10000, help="cells timed by the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-procs", type=int, default=-1,
                     help="host processes of the all-cores CPU baseline (-1: one per physical core, 0: skip)")
-    ap.add_argument("--strict-steps", type=int, default=5, help="steps timed with the domain check on (0 = skip)")
+    ap.add_argument("--strict-steps", type=int, default=5, help="steps also timed WITHOUT the domain check (0 = skip)")
     ap.add_argument("--strong-configs", default="C4,C5",
                     help="with N > 1: configurations also run at their own cell count split over the GPUs "
                          "(reported under 'strong_scaling'; '' = none)")
@@ -494,7 +512,8 @@ def assemble_line(args, job, main_case, strong, end_to_end, extras_error):
     line = {
         "metric": "simulated cells*genes per second (count sampling: sample_density -> draw_counts)",
         "value": main_case["value"], "unit": "cells*genes/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": ms_per_step, "ms_per_step_strict": main_case["ms_strict"],
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "ms_per_step_strict": ms_per_step,
+        "ms_per_step_unchecked": main_case["ms_unchecked"], "ms_per_step_cold": main_case["ms_cold"],
         "higher_is_better": True,
         "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %d-branch tree (T=50, K=25), %d genes, %d cells per GPU "

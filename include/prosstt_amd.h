@@ -43,6 +43,11 @@ enum {
 #define PROSSTT_AMD_HOST_OUTPUT  2u /* every output array is a host pointer */
 #define PROSSTT_AMD_CHECK_DOMAIN 4u /* synchronise and return EDOMAIN like scipy's argument check */
 #define PROSSTT_AMD_TIME_KERNEL  8u /* bracket the main kernel with HIP events (last_kernel_ms) */
+#define PROSSTT_AMD_CHECK_DEFERRED 16u /* the same check without synchronising: the verdict stays in the ctx until
+                                          prosstt_amd_domain_status reads it (no kernel is added to the call: the per-cell and
+                                          per-gene tests ride in the preparation kernel) */
+#define PROSSTT_AMD_MEANS_CACHED 32u /* with a checked call: the mean tensor (same pointer, rows, G) has not changed since the
+                                        previous checked call on this ctx -- its per-row flags are reused, not rescanned */
 
 typedef struct prosstt_amd_ctx prosstt_amd_ctx;
 
@@ -86,6 +91,14 @@ int prosstt_amd_sample_counts(prosstt_amd_ctx* ctx, const float* means, int64_t 
                               const double* alpha, const double* beta, int64_t N, uint64_t seed,
                               uint64_t cell_offset, const int64_t* cell_index, int32_t* out,
                               int64_t ld_out, uint32_t flags);
+
+/*
+ * The verdict of the PROSSTT_AMD_CHECK_DEFERRED calls since the last time, read and cleared (synchronises the stream):
+ * *status = 0, PROSSTT_AMD_EDOMAIN (a mean <= 0 or alpha*m + beta < 1: where scipy's argument check behind
+ * simulation.py:647-648 raises ValueError) or PROSSTT_AMD_EINVAL (a row index outside the mean tensor); the message is in
+ * prosstt_amd_last_error().  Returns 0 unless the HIP runtime failed.
+ */
+int prosstt_amd_domain_status(prosstt_amd_ctx* ctx, int32_t* status);
 
 /*
  * The samples that the streaming kernel of the LAST prosstt_amd_sample_counts call on this ctx left

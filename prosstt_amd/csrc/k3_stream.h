@@ -2,7 +2,7 @@
 // on its own strip of the count matrix, with LDS stacks between the stages so that every
 // stage executes with (nearly) all 64 lanes busy.
 //
-// The scalar algorithm (PRNB-4, prnb_device.h) has very different costs per sample:
+// The scalar algorithm (PRNB-5, prnb_device.h) has very different costs per sample:
 //   ~65 % of the samples of the headline workload are zeros that a 6-instruction bound
 //         settles (exp(-m * phi_gene) <= P(X = 0), prnb::zero_test_factor);
 //   the rest need P(X = 0) exactly (reciprocal + log1p + exp, ~100 VALU), and
@@ -41,7 +41,7 @@
 // left shift, mbcnt, 3-operand integer forms, 64-bit multiply) occupy a second unit for ~4.3 cycles
 // each (simple integer add/xor/and/or/right shift ~2.4 there, transcendentals ~8.3), and scalar
 // instructions issue beside both.  The kernel is bound by that second unit, so the walk is pure
-// binary32 arithmetic on a binary32 remainder (PRNB-4), hits are counted from sign bits, wave-level
+// binary32 arithmetic on a binary32 remainder, hits are counted from sign bits, wave-level
 // tests are lane masks formed by ONE compare each, and per-cell values arrive by scalar loads.
 #pragma once
 #include <type_traits>

@@ -78,7 +78,7 @@ __device__ __forceinline__ Words philox4x32(uint32_t c0, uint32_t c1, uint32_t c
     return r;
 }
 
-// The count sampler (PRNB-4) draws from Philox4x32-7: the fewest rounds of Philox4x32 that pass BigCrush
+// The count sampler draws from Philox4x32-7: the fewest rounds of Philox4x32 that pass BigCrush
 // (Salmon et al. 2011, section 5 and table 2: "Crush-resistant"; 10 rounds are the library default for
 // margin).  Every counter is used once, a sample's uniforms are never compared with a neighbour's, and
 // the statistical tests of tests/ run on this generator; the three rounds are 3 % of the whole kernel.

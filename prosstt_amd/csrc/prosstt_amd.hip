@@ -65,6 +65,13 @@ struct prosstt_amd_ctx {
     uint32_t list_cap = 0;
     int64_t list_groups = 0, list_strip_cells = 0;
     int heavy_grid = 1536;       // blocks of K3h that are resident at once on this device (one round: measured best)
+    // domain check: one byte per row of the mean tensor last scanned ("has an entry that is not > 0"), and which tensor that was
+    uint8_t* row_bad = nullptr;
+    size_t row_bad_cap = 0;
+    const float* row_bad_means = nullptr;
+    int64_t row_bad_rows = 0;
+    int32_t row_bad_G = 0;
+    uint32_t call_parity = 0;    // the full-test request word of a call is scratch[6 + parity]; a call clears the other one
 };
 
 // next (start, stop) event pair of the ctx's pool
@@ -82,10 +89,18 @@ static int next_event_pair(prosstt_amd_ctx* c, hipEvent_t* a, hipEvent_t* b)
     c->events_used += 2;
     return 0;
 }
-constexpr int kScratchWords = 128 + 32 * 16;   // [0] domain flag, [1..] lineage results, [128..] ticket heads, 128 B apart
+// scratch words: [3] list overflow of the last sample_counts call; [4] sticky "domain error", [5] sticky "row index outside
+// the tensor" (both set by checked calls, read and cleared by prosstt_amd_domain_status); [6], [7] "some gene has alpha < 0 or
+// beta < 1: run the full test" of calls of even / odd parity
+constexpr int kScratchWords = 128 + 32 * 16;
+constexpr int kStickyDomain = 4, kStickyRow = 5, kFullReq = 6;
 
 static int ws_reserve(prosstt_amd_ctx* c, size_t bytes)
 {
+    // every user of the workspace overwrites what the last sample_counts call left there: its list is gone
+    c->list = nullptr;
+    c->list_count = nullptr;
+    c->list_regions = 0;
     if (bytes <= c->ws_bytes) return 0;
     if (c->ws) {
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -125,23 +140,41 @@ struct Staging {
 // One launch prepares a sample_counts call: binary64 scaling/alpha/beta -> the binary32 sampler
 // parameters (and the zero-test factor), the per-cell records of the streaming kernel (k3::CellInfo;
 // N + 4 entries, the last cell repeated; skipped when `info` is NULL), and the call's flag words.
+// With `row_bad` (a checked call) it is also the per-cell and per-gene part of the domain check: scipy's argument
+// check in the reference fails iff some mean m = M*s is <= 0 (or NaN) or some theta = a*m + b - 1 is < 0.  With every
+// scaling > 0 the first holds iff a USED row of the mean tensor has an entry that is not > 0 (row_bad, from
+// row_flags_kernel); with every a >= 0 and b >= 1 the second cannot happen -- only when a gene has a < 0 or b < 1
+// is the full N x G test needed (flags[kFullReq + parity], read by domain_full_kernel).
 __global__ void prep_kernel(const double* __restrict__ scaling, int64_t N,
                             const double* __restrict__ alpha, const double* __restrict__ beta, int32_t G,
                             float* __restrict__ scal_f, float* __restrict__ a_f,
                             float* __restrict__ bm1_f, float* __restrict__ phi_f,
                             const int32_t* __restrict__ row_of_cell, int64_t rows, uint64_t cell_offset,
                             const int64_t* __restrict__ cell_index, int32_t strip_cells,
-                            uint32_t k0, uint32_t k1, k3::CellInfo* __restrict__ info, int64_t* __restrict__ flags)
+                            uint32_t k0, uint32_t k1, k3::CellInfo* __restrict__ info, int64_t* __restrict__ flags,
+                            const uint8_t* __restrict__ row_bad, uint32_t parity)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (flags && i < 4) flags[i] = 0;      // [0] domain flag, [1] row index outside the tensor, [2] full-test request, [3] list overflow
-    if (i < N) scal_f[i] = (float)scaling[i];
+    if (flags && i == 0) {
+        flags[3] = 0;                       // list overflow of this call (set by the streaming kernel)
+        flags[kFullReq + (parity ^ 1u)] = 0;  // the NEXT call's full-test request (this call's was cleared by the previous one)
+    }
+    if (i < N) {
+        const float s = (float)scaling[i];
+        scal_f[i] = s;
+        if (row_bad) {
+            const int64_t r = row_of_cell[i];
+            if (r < 0 || r >= rows) flags[kStickyRow] = 1;     // reported as EINVAL, never read through
+            else if (row_bad[r] || !(s > 0.0f)) flags[kStickyDomain] = 1;
+        }
+    }
     if (i < G) {
         const float a = (float)alpha[i];
         const float bm1 = (float)(beta[i] - 1.0);   // binary64 subtraction: beta = 1 + 1e-8 must survive
         a_f[i] = a;
         bm1_f[i] = bm1;
         phi_f[i] = prnb::zero_test_factor(a, bm1);
+        if (row_bad && (!(a >= 0.0f) || !(bm1 >= 0.0f))) flags[kFullReq + parity] = 1;
     }
     if (info && i < N + 4) {
         const int64_t n = i < N ? i : N - 1;
@@ -344,42 +377,27 @@ __global__ __launch_bounds__(256) void means_from_rel_kernel(const double* __res
     }
 }
 
-// ---- domain check of the streaming path (PROSSTT_AMD_CHECK_DOMAIN) ----------------------------
-// scipy's argument check in the reference fails iff some mean m = M*s is <= 0 (or NaN) or some
-// theta = a*m + b - 1 is < 0.  With every scaling > 0 the first holds iff a USED row of the mean
-// tensor has an entry <= 0; with every a >= 0 and b >= 1 the second cannot happen.  Only when a
-// gene has a < 0 or b < 1 is the full N x G test needed.
-__global__ void domain_rows_kernel(const int32_t* __restrict__ row_of_cell, const float* __restrict__ scal,
-                                   int64_t N, const float* __restrict__ ga, const float* __restrict__ gbm1,
-                                   int32_t G, int64_t rows, uint8_t* __restrict__ rows_used,
-                                   int64_t* __restrict__ flagp)
+// ---- domain check of the streaming path (PROSSTT_AMD_CHECK_DOMAIN / _CHECK_DEFERRED; see prep_kernel) ----------
+// row_bad[r] = 1 iff row r of the mean tensor has an entry that is not > 0 (zero, negative, NaN): one block per row.
+// Scanned once per mean tensor (the ctx remembers which tensor its flags belong to).
+__global__ __launch_bounds__(256) void row_flags_kernel(const float* __restrict__ means, int64_t rows, int64_t G,
+                                                        uint8_t* __restrict__ row_bad)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) {
-        const int64_t r = row_of_cell[i];
-        if (r >= 0 && r < rows) rows_used[r] = 1;
-        else flagp[1] = 1;                             // an index outside the tensor: reported as EINVAL, never written through
-        if (!(scal[i] > 0.0f)) flagp[0] = 1;
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        const float* row = means + r * G;
+        int bad = 0;
+        for (int64_t g = threadIdx.x; g < G; g += blockDim.x) bad |= !(row[g] > 0.0f);
+        bad = __syncthreads_or(bad);
+        if (threadIdx.x == 0) row_bad[r] = (uint8_t)(bad != 0);
     }
-    if (i < G && (!(ga[i] >= 0.0f) || !(gbm1[i] >= 0.0f))) flagp[2] = 1;     // needs the full test
-}
-
-__global__ void domain_means_kernel(const float* __restrict__ means, int64_t rows, int64_t G,
-                                    const uint8_t* __restrict__ rows_used, int64_t* __restrict__ flagp)
-{
-    const int64_t total = rows * G;
-    bool bad = false;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
-        bad = bad || (rows_used[i / G] && !(means[i] > 0.0f));
-    if (bad) flagp[0] = 1;
 }
 
 __global__ void domain_full_kernel(const float* __restrict__ means, int32_t G,
                                    const int32_t* __restrict__ row_of_cell, const float* __restrict__ scal,
                                    const float* __restrict__ ga, const float* __restrict__ gbm1, int64_t N,
-                                   int64_t rows, int64_t* __restrict__ flagp)
+                                   int64_t rows, int64_t* __restrict__ flagp, uint32_t parity)
 {
-    if (flagp[2] == 0 || flagp[1] != 0) return;     // [1]: a row index outside the tensor was found (reported as EINVAL)
+    if (flagp[kFullReq + parity] == 0 || flagp[kStickyRow] != 0) return;     // (a row index outside the tensor is reported as EINVAL)
     const int64_t total = N * (int64_t)G;
     bool bad = false;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -388,7 +406,7 @@ __global__ void domain_full_kernel(const float* __restrict__ means, int32_t G,
         const float m = means[(int64_t)row_of_cell[n] * G + g] * scal[n];
         bad = bad || !(m > 0.0f) || (__builtin_fmaf(ga[g], m, gbm1[g]) < 0.0f);
     }
-    if (bad) flagp[0] = 1;
+    if (bad) flagp[kStickyDomain] = 1;
 }
 
 // ------------------------------------------------------------------ ABI
@@ -431,6 +449,10 @@ PA_EXPORT int prosstt_amd_ctx_create(int device, void* stream, prosstt_amd_ctx**
         prosstt_amd_ctx_destroy(c);
         return fail(PROSSTT_AMD_EHIP, "ctx allocation failed");
     }
+    if (hipMemset(c->scratch, 0, kScratchWords * 8) != hipSuccess) {
+        prosstt_amd_ctx_destroy(c);
+        return fail(PROSSTT_AMD_EHIP, "ctx initialisation failed");
+    }
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k3::sample_counts_heavy_kernel, k3::kHeavyBlock, 0) == hipSuccess &&
         per_cu > 0 && prop.multiProcessorCount > 0)
@@ -446,6 +468,7 @@ PA_EXPORT int prosstt_amd_ctx_destroy(prosstt_amd_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     if (c->ws) (void)hipFree(c->ws);
     if (c->scratch) (void)hipFree(c->scratch);
+    if (c->row_bad) (void)hipFree(c->row_bad);
     if (c->h_scratch) (void)hipHostFree(c->h_scratch);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     delete c;
@@ -509,7 +532,7 @@ static StreamGeometry stream_geometry(int64_t N, int32_t G, int64_t rows)
     g.region_cap = (uint32_t)g.strip_cells * (kTileG / 16);
     g.list_bytes = ((g.regions * (size_t)g.region_cap * 4u) + 255) & ~(size_t)255;
     g.count_bytes = ((g.regions * 4u) + 255) & ~(size_t)255;
-    g.rows_bytes = (((size_t)(rows > 0 ? rows : 0)) + 255) & ~(size_t)255;
+    g.rows_bytes = 0;
     g.info_bytes = ((size_t)n + 4) * sizeof(k3::CellInfo);
     return g;
 }
@@ -564,12 +587,67 @@ static int sampler_setup(prosstt_amd_ctx* c, Staging& st, const float* means, in
     A->extra = (char*)c->ws + vec_bytes;
     k3::CellInfo* info = nullptr;
     if (geo) info = (k3::CellInfo*)((char*)A->extra + geo->list_bytes + geo->count_bytes + geo->rows_bytes);
+    // a checked call needs the per-row flags of THIS mean tensor: scanned now unless the caller vouches that the tensor
+    // the ctx last scanned (same pointer, same shape) has not changed since
+    const uint8_t* row_bad = nullptr;
+    if (geo && (flags & (PROSSTT_AMD_CHECK_DOMAIN | PROSSTT_AMD_CHECK_DEFERRED))) {
+        const bool cached = (flags & PROSSTT_AMD_MEANS_CACHED) && !(flags & PROSSTT_AMD_HOST_INPUTS) && c->row_bad &&
+                            c->row_bad_means == means && c->row_bad_rows == rows && c->row_bad_G == G;
+        if (!cached) {
+            if ((size_t)rows > c->row_bad_cap) {
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                if (c->row_bad) HIP_TRY(hipFree(c->row_bad));
+                c->row_bad = nullptr;
+                c->row_bad_cap = 0;
+                c->row_bad_means = nullptr;
+                HIP_TRY(hipMalloc((void**)&c->row_bad, ((size_t)rows + 4095) & ~(size_t)4095));
+                c->row_bad_cap = ((size_t)rows + 4095) & ~(size_t)4095;
+            }
+            row_flags_kernel<<<dim3((unsigned)(rows < 65536 ? rows : 65536)), dim3(256), 0, c->stream>>>(means, rows, G, c->row_bad);
+            HIP_TRY(hipGetLastError());
+            // (a staged copy of host inputs dies with the call: its flags are never reused)
+            c->row_bad_means = (flags & PROSSTT_AMD_HOST_INPUTS) ? nullptr : means;
+            c->row_bad_rows = rows;
+            c->row_bad_G = G;
+        }
+        row_bad = c->row_bad;
+    }
     const int64_t span = (N + 4 > G ? N + 4 : G);
     prep_kernel<<<dim3((unsigned)((span + 255) / 256)), dim3(256), 0, c->stream>>>(
         scaling, N, alpha, beta, G, A->scal, A->ga, A->gbm1, A->gphi, row_of_cell, rows, cell_offset, cell_index,
-        geo ? (int32_t)geo->strip_cells : 1, (uint32_t)seed, (uint32_t)(seed >> 32), info, geo ? c->scratch : nullptr);
+        geo ? (int32_t)geo->strip_cells : 1, (uint32_t)seed, (uint32_t)(seed >> 32), info, geo ? c->scratch : nullptr,
+        row_bad, c->call_parity);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+// Reads and clears the sticky verdict of the checked calls since the last time (synchronises the stream).
+static int domain_verdict(prosstt_amd_ctx* c, int64_t rows, int* verdict)
+{
+    HIP_TRY(hipMemcpyAsync(c->h_scratch + kStickyDomain, c->scratch + kStickyDomain, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemsetAsync(c->scratch + kStickyDomain, 0, 16, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *verdict = 0;
+    if (c->h_scratch[kStickyRow]) {
+        *verdict = PROSSTT_AMD_EINVAL;
+        if (rows >= 0) return fail(PROSSTT_AMD_EINVAL, "row_of_cell holds an index outside [0,%lld)", (long long)rows);
+        return fail(PROSSTT_AMD_EINVAL, "row_of_cell of a checked call held an index outside the mean tensor");
+    }
+    if (c->h_scratch[kStickyDomain]) {
+        *verdict = PROSSTT_AMD_EDOMAIN;
+        return fail(PROSSTT_AMD_EDOMAIN, "Domain error in arguments: a mean <= 0 or alpha*m + beta < 1");
+    }
+    return 0;
+}
+
+PA_EXPORT int prosstt_amd_domain_status(prosstt_amd_ctx* c, int32_t* status)
+{
+    if (!c) return fail(PROSSTT_AMD_EINVAL, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    int verdict = 0;
+    const int rc = domain_verdict(c, -1, &verdict);
+    if (status) *status = verdict;
+    return (rc == PROSSTT_AMD_EHIP) ? rc : 0;     // the verdict travels in *status; the message is in last_error
 }
 
 PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, int64_t rows, int32_t G,
@@ -600,8 +678,7 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
     heavy.count = (uint32_t*)((char*)A.extra + geo.list_bytes);
     heavy.overflow = (uint32_t*)(c->scratch + 3);           // zeroed by the preparation kernel
     heavy.cap = geo.region_cap;
-    uint8_t* rows_used = (uint8_t*)A.extra + geo.list_bytes + geo.count_bytes;
-    k3::CellInfo* cellinfo = (k3::CellInfo*)(rows_used + geo.rows_bytes);
+    k3::CellInfo* cellinfo = (k3::CellInfo*)((char*)A.extra + geo.list_bytes + geo.count_bytes + geo.rows_bytes);
     const int64_t* d_cell_index = A.cell_index;
     int32_t* d_out = out;
     if (flags & PROSSTT_AMD_HOST_OUTPUT) {
@@ -641,26 +718,21 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
     c->list_cap = heavy.cap;
     c->list_groups = geo.groups;
     c->list_strip_cells = geo.strip_cells;
-    if (flags & PROSSTT_AMD_CHECK_DOMAIN) {
-        HIP_TRY(hipMemsetAsync(rows_used, 0, (size_t)rows, c->stream));
-        const int64_t span = N > G ? N : G;
-        domain_rows_kernel<<<dim3((unsigned)((span + 255) / 256)), dim3(256), 0, c->stream>>>(
-            A.row_of_cell, A.scal, N, A.ga, A.gbm1, G, rows, rows_used, c->scratch);
-        domain_means_kernel<<<dim3(2048), dim3(256), 0, c->stream>>>(A.means, rows, G, rows_used, c->scratch);
+    const bool checked = (flags & (PROSSTT_AMD_CHECK_DOMAIN | PROSSTT_AMD_CHECK_DEFERRED)) != 0;
+    if (checked) {
+        // (leaves at once unless a gene has alpha < 0 or beta < 1: prep_kernel's request word)
         domain_full_kernel<<<dim3(8192), dim3(256), 0, c->stream>>>(A.means, G, A.row_of_cell, A.scal, A.ga,
-                                                                  A.gbm1, N, rows, c->scratch);
+                                                                  A.gbm1, N, rows, c->scratch, c->call_parity);
         HIP_TRY(hipGetLastError());
     }
+    c->call_parity ^= 1u;
     if (flags & PROSSTT_AMD_HOST_OUTPUT)   // G columns of every row; the caller's padding beyond G is left alone
         HIP_TRY(hipMemcpy2DAsync(out, (size_t)ld_out * 4, d_out, (size_t)ld_out * 4, (size_t)G * 4, (size_t)N,
                                  hipMemcpyDeviceToHost, c->stream));
     if (flags & PROSSTT_AMD_CHECK_DOMAIN) {
-        HIP_TRY(hipMemcpyAsync(c->h_scratch, c->scratch, 16, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        if (c->h_scratch[1])
-            return fail(PROSSTT_AMD_EINVAL, "row_of_cell holds an index outside [0,%lld)", (long long)rows);
-        if (c->h_scratch[0])
-            return fail(PROSSTT_AMD_EDOMAIN, "Domain error in arguments: a mean <= 0 or alpha*m + beta < 1");
+        int verdict = 0;
+        rc = domain_verdict(c, rows, &verdict);
+        if (rc) return rc;
     } else if (flags & (PROSSTT_AMD_HOST_OUTPUT | PROSSTT_AMD_HOST_INPUTS)) {
         HIP_TRY(hipStreamSynchronize(c->stream));   // staging buffers die with `st`
     }

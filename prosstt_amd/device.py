@@ -43,6 +43,7 @@ class Context:
         _native.check(self._lib.prosstt_amd_ctx_create(
             self.device, ctypes.c_void_p(self.stream.cuda_stream), ctypes.byref(handle)))
         self._h = handle
+        self._checked_means = None      # (pointer, rows, G, token) of the mean tensor whose row flags the ctx holds
 
     def close(self):
         if getattr(self, "_h", None):
@@ -76,8 +77,16 @@ class Context:
 
     # ---- K3: fused count sampler -------------------------------------------
     def sample_counts(self, means, row_of_cell, scaling, alpha, beta, seed, cell_offset=0,
-                      out=None, check_domain=True, time_kernel=False, cell_index=None):
-        """int32 device tensor (N, G) of counts; see prosstt_amd_sample_counts."""
+                      out=None, check_domain=True, time_kernel=False, cell_index=None, means_token=None):
+        """int32 device tensor (N, G) of counts; see prosstt_amd_sample_counts.
+
+        check_domain  True: the reference's argument check, raised here (ValueError; synchronises);
+                      "deferred": the same check, enqueued with the call and not waited for -- the verdict is
+                      raised by the next ``domain_status()`` (the host-returning entry points call it behind the
+                      copy that synchronises anyway); False: no check.
+        means_token   any hashable that changes whenever the content of ``means`` does (the host layer passes the
+                      tree's fingerprint): with the same tensor and token as the previous checked call the per-row
+                      flags of the mean tensor are reused instead of rescanned."""
         torch = _torch()
         means = self.tensor(means, torch.float32)
         rows, G = means.shape
@@ -99,12 +108,27 @@ class Context:
         # (row_of_cell indexes the mean tensor unchecked in the kernels -- device pointers are the caller's
         # contract in the C ABI; with check_domain the library's domain pass also reports an index outside
         # the tensor, as PROSSTT_AMD_EINVAL)
-        flags = (_native.CHECK_DOMAIN if check_domain else 0) | (_native.TIME_KERNEL if time_kernel else 0)
+        if check_domain not in (True, False, "deferred"):
+            raise ValueError("check_domain must be True, False or 'deferred'")
+        flags = _native.TIME_KERNEL if time_kernel else 0
+        if check_domain:
+            flags |= _native.CHECK_DEFERRED if check_domain == "deferred" else _native.CHECK_DOMAIN
+            key = (means.data_ptr(), rows, G, means_token)
+            if means_token is not None and key == self._checked_means:
+                flags |= _native.MEANS_CACHED
+            self._checked_means = key if N and G else None
         _native.check(self._lib.prosstt_amd_sample_counts(
             self._h, _ptr(means), rows, G, _ptr(row_of_cell), _ptr(scaling), _ptr(alpha), _ptr(beta),
             N, ctypes.c_uint64(seed & (2 ** 64 - 1)), ctypes.c_uint64(cell_offset), _ptr(cell_index),
             _ptr(out), out.stride(0) if N else G, flags))
         return out
+
+    def domain_status(self):
+        """Raise what the ``check_domain="deferred"`` calls since the last time found (ValueError where the
+        reference's scipy call raises, NativeError for a row index outside the tensor); synchronises."""
+        status = ctypes.c_int32(0)
+        _native.check(self._lib.prosstt_amd_domain_status(self._h, ctypes.byref(status)))
+        _native.check(status.value)
 
     def last_list(self, cap=1 << 22):
         """(cells, genes, total, overflowed): the samples the streaming kernel of the last

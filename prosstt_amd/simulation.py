@@ -418,7 +418,7 @@ def draw_counts(tree, pseudotime, branches, scalings, alpha, beta, *, seed=None,
     One launch of the fused HIP sampler: gather the cell's row of the mean tensor,
     scale it, form the negative-binomial parameters of ``count_model.get_pr_umi`` and
     draw.  Counts follow the reference's law, NB(n = r, p = 1 - p); the random
-    stream is the counter-based PRNB-4, not numpy's MT19937,
+    stream is the counter-based PRNB-5, not numpy's MT19937,
     so individual values differ from the reference at equal numpy seed.
 
     New keyword-only options
@@ -427,7 +427,9 @@ def draw_counts(tree, pseudotime, branches, scalings, alpha, beta, *, seed=None,
       out     "numpy" (default): int64 ndarray like the reference; "torch": the
               int32 device tensor, no host copy.
       strict  raise ``ValueError`` where scipy's argument check would (an exact-zero
-              mean, or alpha*m + beta < 1); False skips the check (no device sync).
+              mean, or alpha*m + beta < 1); the test rides in the call's own kernels (the per-row flags of
+              the mean tensor are kept until the tensor changes) and costs no launch and no extra
+              synchronisation.  False skips it.
     """
     no_cells = len(branches)
     if len(pseudotime) != no_cells or len(scalings) != no_cells:
@@ -437,14 +439,22 @@ def draw_counts(tree, pseudotime, branches, scalings, alpha, beta, *, seed=None,
         seed = int(lo) | (int(hi) << 32)
     ctx = _device.get_context()
     rows = cell_rows(tree, pseudotime, branches)
+    if out not in ("numpy", "torch"):
+        raise ValueError("out must be 'numpy' or 'torch'")
+    # the domain check rides in the call's own kernels and is not waited for; its verdict is read behind the copy to the
+    # host (which synchronises anyway), or at once when the device tensor itself is returned
+    token = tree.means_token()
     counts = ctx.sample_counts(tree.device_means(), rows, np.asarray(scalings, dtype=np.float64),
                                np.asarray(alpha, dtype=np.float64), np.asarray(beta, dtype=np.float64),
-                               seed=seed, check_domain=strict)
+                               seed=seed, check_domain="deferred" if strict else False, means_token=token)
     if out == "torch":
+        if strict:
+            ctx.domain_status()
         return counts
-    if out != "numpy":
-        raise ValueError("out must be 'numpy' or 'torch'")
-    return _to_host_int64(counts)
+    host = _to_host_int64(counts)
+    if strict:
+        ctx.domain_status()
+    return host
 
 
 def add_non_diff_genes(inform_expr_matrix, genes, gene_params, cell_scalings, *, seed=None):

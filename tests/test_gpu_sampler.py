@@ -1,7 +1,7 @@
 """
 -m gpu: the HIP count sampler (K3) against the oracle, through the C ABI.
 
- * counts: BIT-EXACT against oracle/nb_model.c (the scalar C model of PRNB-4) on the
+ * counts: BIT-EXACT against oracle/nb_model.c (the scalar C model of PRNB-5, reading the device's own tables of v_rcp/v_log/v_exp) on the
    same seeded inputs -- integer work, no tolerance;
  * (mu, p, r): bit-exact against the model AND within rtol 1e-6 of the reference's
    float64 get_pr_umi (count_model.py:156-158) -- the stated fp32 tolerance;
@@ -185,6 +185,48 @@ def test_domain_errors_like_scipy(ctx):
     # unchecked mode never raises and writes 0 for the offending entries
     u = ctx.sample_counts(means, roc, sc, np.full(8, 0.2), np.full(8, 2.0), seed=1, check_domain=False)
     assert int(u[1, 3]) == 0
+
+
+def test_deferred_domain_check_and_cached_row_flags(ctx):
+    """check_domain="deferred": the same verdict as the synchronous check, but the call does not wait for it --
+    ``domain_status()`` raises it (once) later.  With a ``means_token`` the per-row flags of the mean tensor are
+    kept between calls: the same token vouches that the tensor is unchanged, a new token makes the next call rescan."""
+    import torch
+    from prosstt_amd import _native
+    means = torch.ones((3, 8), dtype=torch.float32, device=ctx.torch_device)
+    roc = np.array([0, 1, 2], np.int32)
+    sc = np.ones(3)
+    al, be = np.full(8, 0.2), np.full(8, 2.0)
+    ctx.sample_counts(means, roc, sc, al, be, seed=1, check_domain="deferred", means_token="v1")
+    ctx.domain_status()                                    # nothing to report
+    means[2, 5] = 0.0                                      # edited in place ...
+    ctx.sample_counts(means, roc, sc, al, be, seed=1, check_domain="deferred", means_token="v2")     # ... and announced
+    ctx.sample_counts(means, roc[:2], sc[:2], al, be, seed=2, check_domain="deferred", means_token="v2")
+    with pytest.raises(ValueError):
+        ctx.domain_status()
+    ctx.domain_status()                                    # the verdict was cleared when it was read
+    # only the rows a call uses count
+    ctx.sample_counts(means, roc[:2], sc[:2], al, be, seed=2, check_domain="deferred", means_token="v2")
+    ctx.domain_status()
+    # a scaling that is not > 0, a gene with beta < 1 (full per-sample pass), a row index outside the tensor
+    ctx.sample_counts(means, roc[:2], np.array([1.0, 0.0]), al, be, seed=2, check_domain="deferred", means_token="v2")
+    with pytest.raises(ValueError):
+        ctx.domain_status()
+    bad_beta = be.copy(); bad_beta[3] = 0.5
+    ctx.sample_counts(means, roc[:2], sc[:2], np.zeros(8), bad_beta, seed=2, check_domain="deferred", means_token="v2")
+    with pytest.raises(ValueError):
+        ctx.domain_status()
+    ctx.sample_counts(means, roc[:2], sc[:2], al, be, seed=2, check_domain="deferred", means_token="v2")
+    ctx.domain_status()                                    # the request for the full pass does not outlive its call
+    ctx.sample_counts(means, np.array([0, 7], np.int32), sc[:2], al, be, seed=2, check_domain="deferred", means_token="v2")
+    with pytest.raises(_native.NativeError):
+        ctx.domain_status()
+    # without a token nothing is reused: an in-place edit is seen by the next checked call
+    means[2, 5] = 1.0
+    ctx.sample_counts(means, roc, sc, al, be, seed=3, check_domain=True)
+    means[0, 0] = float("nan")
+    with pytest.raises(ValueError):
+        ctx.sample_counts(means, roc, sc, al, be, seed=3, check_domain=True)
 
 
 def test_empty_inputs(ctx):

@@ -1,5 +1,5 @@
 """
-CPU tests of oracle/nb_model.c, the scalar C model of the device count sampler (PRNB-4):
+CPU tests of oracle/nb_model.c, the scalar C model of the device count sampler (PRNB-5; here on its libm stand-ins for the three hardware functions unless a GPU is present):
 known-answer vectors of Philox4x32-10 and -7, accuracy of the deterministic binary32 math, and the
 LAW of the sampler against the reference's distribution (scipy.stats.nbinom tables of fixture
 g7 and the oracle's numpy path).  The HIP kernel is then held bit-exact to this model (-m gpu).
@@ -161,7 +161,7 @@ def test_degenerate_parameters():
 
 
 def test_inversion_class_rule():
-    """PRNB-4: inversion iff theta = a*m + b - 1 <= 16 and t = -log P(X=0) = m*log1p(theta)/theta <= 19
+    """PRNB-5: inversion iff theta = a*m + b - 1 <= 16 and t2 = -log2 P(X=0) = m*log2(1+theta)/theta < 27.4112 (t < 19)
     (P0 * 2^32 >= 24, tail ratio <= 16/17); m <= 0 or theta <= 0 is the degenerate path.  Both classes
     follow the same law, so the split must not show in the moments."""
     means = np.array([[0.5, 18.9, 30.0, 60.0, 6.0, 8.0, 3.0, 3.0, 25.0, 2.0, 2.0, 0.0, 75.0, 80.0, 25.0, 19.5]], np.float32)

@@ -19,8 +19,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "prosstt_amd", "csrc")
 OUT = os.path.join(ROOT, "build", "ab")
 
-RUN_23 = """        while (s1_top >= 64) {
-            stage2_pass();
+RUN_23 = """        while (s1_at - s1_lds >= 64u * 16u) {
+            stage2_pass(std::true_type{});
             while (s2_top >= kS2Run) stage3_pass();
         }
         cur = nxt;"""
@@ -28,7 +28,8 @@ RUN_23 = """        while (s1_top >= 64) {
 PHILOX_OFF = ("        const prnb::Words W = philox_count_row(ph, quad_hi, quad_lo, k0, k1);",
               "        prnb::Words W; W.w[0] = (ph[0] * 2654435761u) ^ ((uint32_t)g0 * 40503u); W.w[1] = W.w[0] * 3u + k0;\n"
               "        W.w[2] = W.w[1] ^ 0x9E3779B9u; W.w[3] = W.w[2] + W.w[0];")
-STORE_OFF = ("        if (g0 < G) {\n            if (VEC) {", "        if (g0 < G && v[0] == 12345) {\n            if (VEC) {")
+STORE_OFF = ("__builtin_amdgcn_raw_buffer_store_b128(row4, out_rsrc, store_voff, flush_off, 2 /* nt */);",
+             "__builtin_amdgcn_raw_buffer_store_b128(row4, out_rsrc, 0x80000000u, flush_off, 2 /* nt */);")   # every lane out of range: dropped
 
 K3H_LAUNCH = """    k3::sample_counts_heavy_kernel<<<dim3((unsigned)c->heavy_grid), dim3(k3::kHeavyBlock), 0, c->stream>>>(
         heavy, (uint32_t)geo.regions, (int32_t)geo.strips, (int32_t)geo.strip_cells, A.means, rows, G, A.row_of_cell,
@@ -38,19 +39,14 @@ K3H_LAUNCH = """    k3::sample_counts_heavy_kernel<<<dim3((unsigned)c->heavy_gri
 VARIANTS = {
     "base": [],
     # stage 1 only: survivors are pushed, then dropped
-    "s1": [(RUN_23, "        s1_top = 0;\n        cur = nxt;")],
+    "s1": [(RUN_23, "        s1_at = s1_lds;\n        cur = nxt;")],
     # stages 1 + 2: what stage 2 pushes on S2 is dropped
-    "s12": [(RUN_23, "        while (s1_top >= 64) { stage2_pass(); s2_top = 0; }\n        cur = nxt;")],
+    "s12": [(RUN_23, "        while (s1_at - s1_lds >= 64u * 16u) { stage2_pass(std::true_type{}); s2_top = 0; }\n        cur = nxt;")],
     # stage 1 without the Philox call (a 2-instruction hash stands in)
-    "s1_nophilox": [(RUN_23, "        s1_top = 0;\n        cur = nxt;"), PHILOX_OFF],
+    "s1_nophilox": [(RUN_23, "        s1_at = s1_lds;\n        cur = nxt;"), PHILOX_OFF],
     # stage 1 only, rows not stored (pure issue time of stage 1)
-    "s1_nostore": [(RUN_23, "        s1_top = 0;\n        cur = nxt;"), STORE_OFF],
-    "s1_nostore_nophilox": [(RUN_23, "        s1_top = 0;\n        cur = nxt;"), STORE_OFF, PHILOX_OFF],
-    # stage 1 only, nothing pushed (the compare stays)
-    "s1_nopush": [(RUN_23, "        s1_top = 0;\n        cur = nxt;"),
-                  ('            asm volatile("s_mov_b64 exec, %0\\n\\tds_write_b128 %1, %2\\n\\ts_mov_b64 exec, -1"\n'
-                   '                         :: "s"(push_m), "v"(slot), "v"(e) : "memory");',
-                   '            asm volatile("" :: "s"(push_m), "v"(slot), "v"(e));')],
+    "s1_nostore": [(RUN_23, "        s1_at = s1_lds;\n        cur = nxt;"), STORE_OFF],
+    "s1_nostore_nophilox": [(RUN_23, "        s1_at = s1_lds;\n        cur = nxt;"), STORE_OFF, PHILOX_OFF],
     # everything, mean segments not loaded (constant means)
     "noload": [("            const float4 v = *reinterpret_cast<const float4*>(rowp + gload);",
                 "            const float4 v = make_float4(0.4f, 1.1f, 0.05f, 2.5f); asm volatile(\"\" :: \"v\"(rowp + gload));")],
@@ -63,25 +59,11 @@ VARIANTS = {
     "k3h_grid2048": [("k3::sample_counts_heavy_kernel<<<dim3((unsigned)c->heavy_grid),", "k3::sample_counts_heavy_kernel<<<dim3(2048),")],
     "k3h_grid3072": [("k3::sample_counts_heavy_kernel<<<dim3((unsigned)c->heavy_grid),", "k3::sample_counts_heavy_kernel<<<dim3(3072),")],
     "k3h_none": [("            light = P.valid && P.light;\n", "            light = false;\n"), ("            heavy = P.valid && !P.light;\n", "            heavy = false;\n")],
-    # K3h diagnosis (timing only): redo walks cut at 35 / 131 terms; every gamma / Poisson attempt accepted
-    "k3h_walk35": [("    for (int k = 3;; k += 4) {\n        const float4 inv", "    for (int k = 3;; k += 4) {\n        if (k >= 35) return k;\n        const float4 inv")],
-    "k3h_walk131": [("    for (int k = 3;; k += 4) {\n        const float4 inv", "    for (int k = 3;; k += 4) {\n        if (k >= 131) return k;\n        const float4 inv")],
     "k3h_gamma1": [("                    ok = last;\n                    if (!ok) {", "                    ok = true;\n                    if (!ok) {")],
     "k3h_pois1": [("                    again = j + 1 < 2 * prnb::kMaxTries;", "                    again = false;")],
     # K3h launched twice / three times (idempotent): what a launch costs when its code and data are warm
     "k3h_twice": [(K3H_LAUNCH, K3H_LAUNCH * 2)],
     "k3h_thrice": [(K3H_LAUNCH, K3H_LAUNCH * 3)],
-    # K3h without its scattered 4-byte stores
-    "k3h_noout": [("            if (x != 0) out[(int64_t)e.n * ld + e.g] = x;", "            if (x == 0x7fffffff) out[(int64_t)e.n * ld + e.g] = x;"),
-                  ("            if (!again && x != 0) out[(int64_t)e.n * ld + e.g] = x;", "            if (!again && x == 0x7fffffff) out[(int64_t)e.n * ld + e.g] = x;")],
-    # K3h: the list is read and sorted onto the stacks, no pass runs
-    "k3h_feedonly": [("        while (hg_top >= 64) gamma_pass();\n        while (hl_top >= 64) light_pass();",
-                      "        if (hg_top >= 64) { asm volatile(\"\" :: \"v\"(L.hg[lane].m)); hg_top = 0; }\n"
-                      "        if (hl_top >= 64) { asm volatile(\"\" :: \"v\"(L.hl[lane].m)); hl_top = 0; }"),
-                     ("    light_service(true);\n    while (hg_top > 0) gamma_pass();\n    while (hp_top > 0) poisson_pass();",
-                      "    asm volatile(\"\" :: \"v\"(L.hl[lane].m), \"v\"(L.hg[lane].m));")],
-    # K3h: redo walks replaced by one compare (parameters, Philox call and store stay)
-    "k3h_nowalk": [("            const int32_t x = prnb::light_draw(P, w.w[e.g & 3], inv_k);", "            const int32_t x = (float)w.w[e.g & 3] < P.t * P.inv_u1;")],
     # K3h: gamma-Poisson entries dropped after the gamma pass
     "k3h_nopois": [("        while (hp_top >= 64) poisson_pass();", "        hp_top = 0;")],
     # K3h with a device printf of per-phase cycle counts of a few waves (diagnosis; printf costs registers and time)
@@ -112,27 +94,12 @@ VARIANTS = {
     "strip128": [("    g.strip_cells = k3::kStripCells / 2;", "    g.strip_cells = k3::kStripCells;")],
     "strip32": [("    g.strip_cells = k3::kStripCells / 2;", "    g.strip_cells = k3::kStripCells / 4;")],
     # plain instead of non-temporal row stores
-    "plainstore": [("                __builtin_nontemporal_store(row4, reinterpret_cast<i32x4*>(dst));", "                *reinterpret_cast<i32x4*>(dst) = row4;")],
+    "plainstore": [("store_voff, flush_off, 2 /* nt */);", "store_voff, flush_off, 0);")],
     # stage 3 waits for 48 entries (the late list shrinks to pay for the deeper S2)
     "run48": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 48;"), ("constexpr int kS2Cap = 96;", "constexpr int kS2Cap = 112;"),
               ("constexpr int kLateCap = 128;", "constexpr int kLateCap = 64;")],
     "run40": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 40;"), ("constexpr int kS2Cap = 96;", "constexpr int kS2Cap = 104;"),
               ("constexpr int kLateCap = 128;", "constexpr int kLateCap = 64;")],
-    # round 4: what the margin protocol costs (timing only): no near/dl/tail-band/close_m, v_rcp_f32 for det_rcp, no margin word
-    "nomargin": [
-        ("        const float near = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fabsf(r1), __builtin_fabsf(r2)),\n"
-         "                                                           __builtin_fabsf(r3)), __builtin_fabsf(r4));\n"
-         "        const unsigned long long close_m = K3_MASK(near < dl) | K3_MASK(__builtin_fabsf(ps3 - 1.0f) < kTailBand);",
-         "        const unsigned long long close_m = 0ull;"),
-        ("        dl = dl + 4.0f * kMarginPerTerm;\n", ""),
-        ("        const float inv_u1 = prnb::det_rcp(theta * u1) * theta;", "        const float inv_u1 = __builtin_amdgcn_rcpf(u1);"),
-        ("        const float near = __builtin_fminf(__builtin_fminf(__builtin_fabsf(r0), __builtin_fabsf(r1)), __builtin_fabsf(r2));\n"
-         "        const unsigned long long close_m = K3_MASK(near < d2) | K3_MASK(__builtin_fabsf(ps2 - 1.0f) < kTailBand);",
-         "        const unsigned long long close_m = 0ull;"),
-        ("            const uint32_t m2 = ((prnb::f2u(d2 + 4.0f * kMarginPerTerm) + 0xffffu) & 0xffff0000u) | p2;", "            const uint32_t m2 = p2;"),
-        ("        const unsigned long long light_m = K3_MASK(theta <= prnb::kLightTheta) & K3_MASK(t2 < kT2Sure);",
-         "        const unsigned long long light_m = K3_MASK(theta <= prnb::kLightTheta) & K3_MASK(t2 < 27.4112f);"),
-    ],
     # round 4: K3h on a second stream with no dependency on the stream kernel (it reads the PREVIOUS call's list: timing only) --
     # the upper bound of what overlapping the two kernels can give
     "k3h_overlap": [
