@@ -52,13 +52,13 @@ namespace k3 {
 constexpr int kBlock = 256;        // 4 waves
 constexpr int kTileG = 256;        // genes per wave pass: 64 lanes x 4
 constexpr int kStripCells = 128;   // most cells per wave (pos keeps the cell in 7 bits); the host launches 64
-constexpr int kS1Cap = 320;        // < 64 left over + 256 pushed by one pass
+constexpr int kS1Cap = 192;        // < 64 left over + 128 pushed by half a pass (two samples per lane)
 constexpr int kS2Cap = 96;         // < 32 left over + 64 pushed by one stage-2 pass
 constexpr int kS2Run = 32;         // stage 3 runs while S2 holds at least this many entries (8, 16: 3-5 % slower)
-static_assert(kS2Cap >= kS2Run - 1 + 64 && kS1Cap >= 63 + 256, "a stack must take one more pass of pushes");
+static_assert(kS2Cap >= kS2Run - 1 + 64 && kS1Cap >= 63 + 128, "a stack must take one more round of pushes");
 constexpr int kRing = 8;           // rows of the strip kept in LDS (8 bits per count) before they are stored; a power of 2
 constexpr int kBail = 6;           // walks left to K3h when a strip has nothing else to do (see the drain)
-constexpr int kLateCap = 128;      // results that missed their row wait here for one burst of stores (< 64 left + 64)
+constexpr int kLateCap = 64;       // results that missed their row wait here for one burst of stores (a pass delivers at most 64)
 constexpr int kRingMaxK3 = 254;    // a walk whose group k3-3..k3 with k3 = 254 ends undecided goes to K3h: counts fit the ring's 8 bits
 constexpr int kInvTab = 260;       // 1/k for k < 260: the reciprocals a pass at k3 <= 254 reads ahead (k3 + 5)
 
@@ -132,7 +132,7 @@ __device__ __forceinline__ int lane_rank(unsigned long long mask)
 }
 
 template <bool VEC>
-__global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
+__global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
     const float* __restrict__ means, int32_t G, const CellInfo* __restrict__ cellinfo,
     const float* __restrict__ ga, const float* __restrict__ gbm1, const float* __restrict__ gphi,
     int64_t N, uint32_t k0, uint32_t k1, int32_t* __restrict__ out, int64_t ld, int32_t strips,
@@ -485,11 +485,13 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
             e[j].z = __float_as_uint(wf);
             e[j].w = pos4 | (uint32_t)j;
         }
-        // The four pushes: one LDS store each under exec = its mask, at the stack's top + 16 * (rank among the pushing
-        // lanes) -- no branch, no exec save, exec restored once.  (v_mbcnt counts the bits of the mask it is GIVEN below
-        // the lane, so it runs under the mask as well.)
-        {
-            uint32_t t0, t1, t2, t3, c_;
+        // The pushes: one LDS store each under exec = its mask, at the stack's top + 16 * (rank among the pushing
+        // lanes) -- no branch, no exec save, exec restored once per pair.  (v_mbcnt counts the bits of the mask it is GIVEN
+        // below the lane, so it runs under the mask as well.)  Two samples of the quad, then the stages behind, then the
+        // other two: S1 never holds more than 63 + 128 entries, which is what lets five blocks share a CU's LDS.
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint32_t t0, t1, c_;
             asm volatile(
                 "s_mov_b64 exec, %[m0]\n\t"
                 "v_mbcnt_lo_u32_b32 %[t0], exec_lo, 0\n\t"
@@ -505,29 +507,14 @@ __global__ __launch_bounds__(kBlock, 4) void sample_counts_stream_kernel(
                 "ds_write_b128 %[t1], %[e1]\n\t"
                 "s_bcnt1_i32_b64 %[c], exec\n\t"
                 "s_lshl4_add_u32 %[at], %[c], %[at]\n\t"
-                "s_mov_b64 exec, %[m2]\n\t"
-                "v_mbcnt_lo_u32_b32 %[t2], exec_lo, 0\n\t"
-                "v_mbcnt_hi_u32_b32 %[t2], exec_hi, %[t2]\n\t"
-                "v_lshl_add_u32 %[t2], %[t2], 4, %[at]\n\t"
-                "ds_write_b128 %[t2], %[e2]\n\t"
-                "s_bcnt1_i32_b64 %[c], exec\n\t"
-                "s_lshl4_add_u32 %[at], %[c], %[at]\n\t"
-                "s_mov_b64 exec, %[m3]\n\t"
-                "v_mbcnt_lo_u32_b32 %[t3], exec_lo, 0\n\t"
-                "v_mbcnt_hi_u32_b32 %[t3], exec_hi, %[t3]\n\t"
-                "v_lshl_add_u32 %[t3], %[t3], 4, %[at]\n\t"
-                "ds_write_b128 %[t3], %[e3]\n\t"
-                "s_bcnt1_i32_b64 %[c], exec\n\t"
-                "s_lshl4_add_u32 %[at], %[c], %[at]\n\t"
                 "s_mov_b64 exec, -1"
-                : [at] "+s"(s1_at), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [c] "=&s"(c_)
-                : [m0] "s"(push_m[0]), [m1] "s"(push_m[1]), [m2] "s"(push_m[2]), [m3] "s"(push_m[3]),
-                  [e0] "v"(e[0]), [e1] "v"(e[1]), [e2] "v"(e[2]), [e3] "v"(e[3])
+                : [at] "+s"(s1_at), [t0] "=&v"(t0), [t1] "=&v"(t1), [c] "=&s"(c_)
+                : [m0] "s"(push_m[2 * h]), [m1] "s"(push_m[2 * h + 1]), [e0] "v"(e[2 * h]), [e1] "v"(e[2 * h + 1])
                 : "memory", "scc");
-        }
-        while (s1_at - s1_lds >= 64u * 16u) {
-            stage2_pass(std::true_type{});
-            while (s2_top >= kS2Run) stage3_pass();
+            while (s1_at - s1_lds >= 64u * 16u) {
+                stage2_pass(std::true_type{});
+                while (s2_top >= kS2Run) stage3_pass();
+            }
         }
         cur = nxt;
         nxt = nn;
