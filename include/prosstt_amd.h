@@ -128,7 +128,7 @@ int prosstt_amd_nb_params(prosstt_amd_ctx* ctx, const float* means, int64_t rows
  * The three hardware functions that the sampler's definition (PRNB-5) takes from gfx950,
  * tabulated by the device itself over a range of binary32 bit patterns:
  *   out[i] = f(as_float(first_bits + i)),  i < count;   op 0: f = v_rcp_f32(x), 1: v_log_f32(x), 2: v_exp_f32(-x)
- * -- the side input of the scalar model that checks the sampler bit for bit (oracle/nb_model.c reads these values
+ * -- the side input of the scalar model that checks the sampler bit for bit (the test-side model reads these values
  * instead of re-implementing the hardware).  Replaces nothing of the reference: its scipy.stats.nbinom draws
  * (simulation.py:647-648) evaluate log/exp in libm.  `out`: DEVICE, or HOST with PROSSTT_AMD_HOST_OUTPUT.
  */

@@ -9,7 +9,7 @@
 // unit is compiled with -ffp-contract=off and every fused multiply-add below is spelled out), plus --
 // for the inversion class only -- three functions of the gfx950 hardware, HW_RCP = v_rcp_f32,
 // HW_LOG2 = v_log_f32, HW_EXP2 = v_exp_f32 (hw_rcp / hw_log2 / hw_exp2 below: one instruction each,
-// deterministic on the chip).  The scalar model (oracle/nb_model.c) takes the values of those three
+// deterministic on the chip).  The scalar model that checks the kernels (a test-side C file) takes the values of those three
 // from tables that a three-line probe kernel (hw_math_kernel, prosstt_amd.hip) writes on the device
 // under test; everything else of the model is its own C.  So counts still compare bit for bit.
 // (PRNB-4 defined P(X = 0) by polynomial log/exp and a Newton reciprocal and let the streaming kernel

@@ -97,19 +97,19 @@ def calc_relat_means(tree, programs, coefficients):
 
 
 def diverging_parallel(branches, programs, genes, tol=0.5):
-    """Whether every pair of parallel branches has more than ``tol`` of its genes
-    anticorrelated (sim_utils.py:216-252).  ``programs`` holds (T, genes) relative
-    means; Pearson signs are evaluated by ``pearson_between_programs``."""
-    branches = [b for b in branches if b is not None]
-    if len(branches) == 1:
+    """For every pair of parallel branches: do more than ``tol`` of the genes run in opposite
+    directions, i.e. have a negative Pearson coefficient between the two branches' (T, genes)
+    relative means (sim_utils.py:216-252)?  One answer per pair, in ``flat_order``'s order; a
+    lone branch has nothing to diverge from."""
+    present = [b for b in branches if b is not None]
+    if len(present) == 1:
         return [True]
-    pairs = flat_order(len(branches))
-    diverging = np.zeros(len(pairs), dtype=bool)
-    for index, i, j in pairs:
-        pearson = pearson_between_programs(genes, programs[branches[i]], programs[branches[j]])
+    verdict = []
+    for _, i, j in flat_order(len(present)):
+        signs = pearson_between_programs(genes, programs[present[i]], programs[present[j]])
         with np.errstate(invalid="ignore"):
-            diverging[index] = np.sum(pearson < 0) / (genes * 1.0) > tol
-    return diverging
+            verdict.append(np.count_nonzero(signs < 0) / float(genes) > tol)
+    return np.array(verdict, dtype=bool)
 
 
 def commited_branches(tree, branches, rel_means):

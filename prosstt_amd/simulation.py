@@ -338,14 +338,18 @@ def draw_times(timepoint, no_cells, max_time, var=4):
 
 
 def _density_plan(tree, no_cells):
-    """(pseudotime, branch) of ``no_cells`` cells drawn from ``tree.density``
-    (simulation.py:452-467): one ``np.random.choice`` over all sum(T_b) positions."""
-    bt = tree.branch_times()
-    possible_pt = np.concatenate([np.arange(bt[b][0], bt[b][1] + 1) for b in tree.branches])
-    possible_branches = np.concatenate([[b] * tree.time[b] for b in tree.branches])
-    probabilities = np.concatenate([tree.density[b] for b in tree.branches])
-    sample = random.choice(np.arange(len(probabilities)), size=no_cells, p=probabilities)
-    return possible_pt[sample], possible_branches[sample]
+    """(pseudotime, branch) of ``no_cells`` cells drawn from ``tree.density``: one
+    ``np.random.choice`` over all sum(T_b) positions of the tree, weighted by the density
+    (simulation.py:452-467 -- the same single draw, so the same cells at equal numpy seed)."""
+    spans = tree.branch_times()
+    weights = np.concatenate([tree.density[b] for b in tree.branches])
+    picked = random.choice(np.arange(weights.size), size=no_cells, p=weights)
+    # position i of the concatenation belongs to branch owner[i] at pseudotime first[owner] + offset
+    lengths = np.array([tree.time[b] for b in tree.branches], dtype=np.int64)
+    owner = np.repeat(np.arange(len(tree.branches)), lengths)[picked]
+    first = np.array([spans[b][0] for b in tree.branches], dtype=np.int64)
+    offset = picked - (np.cumsum(lengths) - lengths)[owner]
+    return first[owner] + offset, np.asarray(tree.branches)[owner]
 
 
 def sample_density(tree, no_cells, alpha=0.3, beta=2, scale=True, scale_v=0.7, scale_mean=0.,

@@ -105,21 +105,12 @@ def sanitize_velocity(velocity, minimum_velocity=0.1):
 
 
 def _density_from_velocity(velocity):
-    """Density inversely related to velocity (tree_utils.py:207-242; the reference's
-    ``np.Inf`` no longer exists in numpy 2 -- ``np.inf`` here)."""
-    total_velocity = 0
-    global_min, global_max = np.inf, -np.inf
-    for b in velocity:
-        total_velocity += np.sum(velocity[b])
-        global_max = max(global_max, np.max(velocity[b]))
-        global_min = min(global_min, np.min(velocity[b]))
-    global_min /= total_velocity
-    global_max /= total_velocity
-    density, total_density = {}, 0
-    for b in velocity:
-        velocity[b] = velocity[b] / total_velocity
-        density[b] = - velocity[b] + global_max + global_min
-        total_density += np.sum(density[b])
-    for b in velocity:
-        density[b] /= total_density
-    return density
+    """Cell density along the tree from pseudotime velocities: where cells move fast, few are
+    seen (tree_utils.py:207-242).  Over all branches together the density is the velocity
+    mirrored inside its own range, ``vmax + vmin - v``, normalised to sum to one over the tree."""
+    keys = list(velocity)
+    flat = np.concatenate([np.asarray(velocity[k], dtype=float) for k in keys])
+    mirrored = (flat.max() + flat.min()) - flat
+    mirrored = mirrored / mirrored.sum()
+    cuts = np.cumsum([len(velocity[k]) for k in keys])[:-1]
+    return dict(zip(keys, np.split(mirrored, cuts)))

@@ -45,8 +45,8 @@ def _meta(text, mangled_part, key):
 
 @pytest.mark.parametrize("kernel", ["sample_counts_stream_kernelILb1", "sample_counts_stream_kernelILb0"])
 def test_stream_kernel_memory_operations_are_global(isa, kernel):
-    # a late 4-byte store must land after its row's 16-byte store: global_* operations of a wave are performed
-    # in issue order, flat_* are not (k3_stream.h, flush_late)
+    # a late 4-byte store must land after its row's 16-byte store: global_* and buffer_* operations of a wave are
+    # performed in issue order, flat_* are not (k3_stream.h, flush_late)
     body = _body(isa, kernel)
     assert "flat_" not in body
     assert re.search(r"global_store_dword\b", body)
@@ -54,12 +54,15 @@ def test_stream_kernel_memory_operations_are_global(isa, kernel):
 
 def test_stream_kernel_rows_are_stored_non_temporally_and_nothing_spills(isa):
     body = _body(isa, "sample_counts_stream_kernelILb1")
-    assert re.search(r"global_store_dwordx4 .* nt\b", body)
+    assert re.search(r"buffer_store_dwordx4 .* offen nt\b", body)       # rows: the row in soffset, the lane's 16 bytes in voffset
     assert _meta(isa, "sample_counts_stream_kernelILb1", "private_segment_fixed_size") == 0
     assert _meta(isa, "sample_counts_stream_kernelILb1", "vgpr_spill_count") == 0
-    # four blocks of 256 threads per CU: 128 VGPRs and 40 KB of LDS each at most
-    assert _meta(isa, "sample_counts_stream_kernelILb1", "vgpr_count") <= 128
-    assert _meta(isa, "sample_counts_stream_kernelILb1", "group_segment_fixed_size") <= 40 * 1024
+    # five blocks of 256 threads per CU (the fifth is worth 11 %: profiles/r04_ablation.txt): 96 VGPRs and
+    # 32 KB of LDS each at most
+    assert _meta(isa, "sample_counts_stream_kernelILb1", "vgpr_count") <= 96
+    assert _meta(isa, "sample_counts_stream_kernelILb1", "group_segment_fixed_size") <= 32 * 1024
+    # packed binary32 instructions take two issue slots and cost moves to pair their operands (-fno-slp-vectorize)
+    assert "v_pk_mul_f32" not in body and "v_pk_add_f32" not in body and "v_pk_fma_f32" not in body
 
 
 def test_second_kernel_has_no_scratch(isa):

@@ -132,6 +132,22 @@ VARIANTS = {
         posbase = posbase_next;
 """, ""),
     ],
+    # round 4: the shipped kernel held at four / three blocks per CU by LDS padding (what the fifth block is worth)
+    "occ4": [("    __shared__ WaveLds lds_all[kBlock / 64];\n\n    const int tid = threadIdx.x;",
+              "    __shared__ WaveLds lds_all[kBlock / 64];\n    __shared__ uint32_t occ_pad[2400];\n    if (N < 0) occ_pad[threadIdx.x] = 1u;\n    asm volatile(\"\" :: \"v\"((uint32_t)(uintptr_t)&occ_pad[0]));\n\n    const int tid = threadIdx.x;")],
+    "occ3": [("    __shared__ WaveLds lds_all[kBlock / 64];\n\n    const int tid = threadIdx.x;",
+              "    __shared__ WaveLds lds_all[kBlock / 64];\n    __shared__ uint32_t occ_pad[5600];\n    if (N < 0) occ_pad[threadIdx.x] = 1u;\n    asm volatile(\"\" :: \"v\"((uint32_t)(uintptr_t)&occ_pad[0]));\n\n    const int tid = threadIdx.x;")],
+    # round 4: four rows in the ring instead of eight, at the shipped five blocks per CU (padding keeps the block's LDS)
+    "ring4": [("constexpr int kRing = 8; ", "constexpr int kRing = 4; "),
+              ("    __shared__ WaveLds lds_all[kBlock / 64];\n\n    const int tid = threadIdx.x;",
+               "    __shared__ WaveLds lds_all[kBlock / 64];\n    __shared__ uint32_t occ_pad[1000];\n    if (N < 0) occ_pad[threadIdx.x] = 1u;\n    asm volatile(\"\" :: \"v\"((uint32_t)(uintptr_t)&occ_pad[0]));\n\n    const int tid = threadIdx.x;")],
+    # round 4 (diagnosis): how many counts miss their row in the ring (printf of a few waves: late deliveries, nonzero deliveries)
+    "latecount": [("    int late_top = 0;                                // wave-uniform",
+                   "    int late_top = 0;                                // wave-uniform\n    int late_total = 0, deliv_total = 0;"),
+                  ("                late_top += cnt;\n", "                late_top += cnt;\n                late_total += cnt;\n"),
+                  ("        const unsigned long long ml = ok_m & late_m;\n", "        const unsigned long long ml = ok_m & late_m;\n        deliv_total += __popcll(ok_m);\n"),
+                  ("    flush_late();\n    if (__builtin_amdgcn_ballot_w64(hpend != kNoHeavy) != 0ull) flush_heavy();",
+                   "    flush_late();\n    if (lane == 0 && (region % 4093u) == 7u) printf(\"LATE region %u cells %d delivered %d late %d listed %u\\n\", region, cells, deliv_total, late_total, h_cnt);\n    if (__builtin_amdgcn_ballot_w64(hpend != kNoHeavy) != 0ull) flush_heavy();")],
     # mean segments one cell ahead, requested at the END of a pass (one register rotation; the row store gets a whole pass before anything waits behind it)
     "pf1": [("        const Seg nn = load_seg(row2);\n        const uint64_t row3 = cinfo[3].row_bytes;",
              "        const uint64_t row3 = cinfo[3].row_bytes;"),
