@@ -202,6 +202,7 @@ def launch_ranks(gpus, argv, script=None):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this pool
     env.setdefault("OMP_NUM_THREADS", "1")
+    env.setdefault("NCCL_DEBUG", "WARN")                   # an RCCL failure says why on the ranks' stderr
     return subprocess.run(cmd, env=env).returncode
 
 
@@ -223,6 +224,8 @@ class Job:
         self.use_dist = self.world > 1 or os.environ.get("PROSSTT_BENCH_FORCE_DIST") == "1"   # the latter: RCCL path on 1 GPU
         if self.use_dist:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("NCCL_DEBUG", "WARN")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             if self.backend == "nccl":
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local))
             else:
@@ -387,6 +390,9 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="do not time the row gather to rank 0 (N > 1)")
     ap.add_argument("--ramp-ms", type=float, default=400.0,
                     help="untimed passes of the step for this long before the W warmup steps (device clock ramp; 0 = none)")
+    ap.add_argument("--fail-on-extras-error", action="store_true",
+                    help="N > 1: exit with code 3 when the gather or a strong-scaling case failed or stalled "
+                         "(the line still goes out with 'extras_error'; default: exit code 0)")
     ap.add_argument("--no-end-to-end", action="store_true",
                     help="skip the end-to-end time of the drop-in sample_density call (N = 1)")
     args = ap.parse_args()
@@ -408,7 +414,7 @@ def main():
     if world == 1:
         main_case.pop("shard", None)
     if world == 1 and not args.no_end_to_end and rank == 0:
-        end_to_end = end_to_end_ms(main_case["tree"], work, n_total)
+        end_to_end = (end_to_end_ms(main_case["tree"], work, n_total), end_to_end_ms(main_case["tree"], work, n_total, "numpy32"))
 
     # With N > 1 the measurements beyond the contract's line (the row gather, the strong-scaling configurations)
     # run under a watchdog: if one of them raises or stalls, rank 0 still prints the line -- with what was
@@ -422,7 +428,8 @@ def main():
         line = assemble_line(args, job, main_case, strong, end_to_end, why or extras_error)
         print(json.dumps(line), flush=True)
 
-    guard = ExtrasGuard(rank, float(os.environ.get("PROSSTT_BENCH_EXTRAS_TIMEOUT_S", "600")))
+    guard = ExtrasGuard(rank, float(os.environ.get("PROSSTT_BENCH_EXTRAS_TIMEOUT_S", "600")),
+                        exit_code=3 if args.fail_on_extras_error else 0)
     if world > 1:
         guard.arm(lambda why: emit(why))
         try:
@@ -455,18 +462,21 @@ def main():
         threading.Event().wait()    # the watchdog is printing and will end the process
     emit()
     if extras_error is not None:
-        # the other ranks may be waiting in a collective this rank left: no orderly shutdown is possible
+        # the other ranks may be waiting in a collective this rank left: no orderly shutdown is possible.  The line has
+        # gone out with the reason; --fail-on-extras-error turns the reason into exit code 3 for callers that go by the
+        # exit status (the default keeps 0: the contract's line itself was measured)
         sys.stdout.flush()
-        os._exit(0)
+        os._exit(3 if args.fail_on_extras_error else 0)
     job.close()
 
 
 class ExtrasGuard:
     """Deadline for the measurements that are not part of the contract's line (N > 1)."""
 
-    def __init__(self, rank, seconds):
+    def __init__(self, rank, seconds, exit_code=0):
         import threading
         self.rank, self.seconds, self.lock, self.state, self.timer = rank, seconds, threading.Lock(), "idle", None
+        self.exit_code = exit_code
 
     def arm(self, emit):
         import threading
@@ -480,7 +490,7 @@ class ExtrasGuard:
                 emit("extras timed out after %.0f s (PROSSTT_BENCH_EXTRAS_TIMEOUT_S); what was measured until then is reported" % self.seconds)
             finally:
                 sys.stdout.flush()
-                os._exit(0)
+                os._exit(self.exit_code)
 
         self.state = "armed"
         self.timer = threading.Timer(self.seconds, fire)
@@ -542,7 +552,7 @@ def assemble_line(args, job, main_case, strong, end_to_end, extras_error):
     if strong:
         line["strong_scaling"] = strong
     if end_to_end is not None:
-        line["end_to_end_ms"] = end_to_end
+        line["end_to_end_ms"], line["end_to_end_ms_int32"] = end_to_end
     if world == 1 and args.cpu_cells > 0:
         line["cpu_baseline"] = cpu_baseline(work, pt, br, sc, min(args.cpu_cells, n_total))
         line["speedup_vs_cpu_1core"] = main_case["value"] / line["cpu_baseline"]["value"]
@@ -555,19 +565,19 @@ def assemble_line(args, job, main_case, strong, end_to_end, extras_error):
     return line
 
 
-def end_to_end_ms(tree, work, n_cells):
+def end_to_end_ms(tree, work, n_cells, out="numpy"):
     """Wall time of the drop-in call a reference user makes -- ``simulation.sample_density`` returning the
-    reference's (N, G) int64 ndarray: host plan, kernels, domain check, and the device-to-host copy of the
-    widened matrix (PCIe-inclusive; never ``value``).  Second of two calls (the first sizes the pinned
-    staging buffers)."""
+    (N, G) matrix on the host: host plan, kernels, domain check, and the device-to-host copy (PCIe-inclusive;
+    never ``value``).  out="numpy": the reference's int64 ndarray (widened on the device, 8 bytes per count over
+    PCIe); "numpy32": int32 as the device holds it.  Second of two calls (the first sizes the pinned buffers)."""
     from prosstt_amd import simulation as sim
     best = None
     for _ in range(2):
         np.random.seed(work.cfg["seed"] + 1)
         t0 = time.perf_counter()
-        x = sim.sample_density(tree, n_cells, alpha=work.alpha, beta=work.beta)[0]
+        x = sim.sample_density(tree, n_cells, alpha=work.alpha, beta=work.beta, out=out)[0]
         dt = (time.perf_counter() - t0) * 1e3
-        assert x.shape == (n_cells, tree.G) and x.dtype == np.int64
+        assert x.shape == (n_cells, tree.G) and x.dtype == (np.int64 if out == "numpy" else np.int32)
         del x
         best = dt
     return best

@@ -46,6 +46,8 @@ enum {
 #define PROSSTT_AMD_CHECK_DEFERRED 16u /* the same check without synchronising: the verdict stays in the ctx until
                                           prosstt_amd_domain_status reads it (no kernel is added to the call: the per-cell and
                                           per-gene tests ride in the preparation kernel) */
+#define PROSSTT_AMD_PARAMS_NONNEG 64u /* with a checked call: the caller has verified alpha >= 0 and beta >= 1 for every gene, so
+                                        alpha*m + beta < 1 cannot happen and the per-sample pass for it is not enqueued */
 #define PROSSTT_AMD_MEANS_CACHED 32u /* with a checked call: the mean tensor (same pointer, rows, G) has not changed since the
                                         previous checked call on this ctx -- its per-row flags are reused, not rescanned */
 
@@ -136,6 +138,23 @@ int prosstt_amd_hw_math(prosstt_amd_ctx* ctx, int32_t op, uint32_t first_bits, u
                         uint32_t flags);
 
 /*
+ * Host only (no device, no ctx): the variates of `attempts` consecutive simulation.sim_expr_branch(T, K) calls
+ * (simulation.py:21-86; per walk, simulation.diffusion's draws, simulation.py:104-113: uniform(0, 1.5),
+ * normal(0, 0.2), uniform(0, 1), normal(0, 2/T) x (T-1)) taken from numpy's legacy global stream (MT19937,
+ * 53-bit doubles, polar normals with the cached second value) exactly as those calls take them.
+ *   mt_words[624], *mt_next, *has_gauss, *gauss   in: the fields of np.random.get_state(); out: the state behind
+ *                                                 the last attempt
+ *   start, vel0, eta   [attempts][K];   noise  [attempts][K][T-1]
+ *   after_words [attempts][624], after_next, after_has_gauss, after_gauss [attempts]: the state behind EVERY attempt
+ *                                                 (the caller rewinds numpy to the attempt it accepts)
+ * Replaces the Python-level loop of 4 numpy calls per walk that bounds the lineage stage on large trees.
+ */
+int prosstt_amd_numpy_programs(uint32_t* mt_words, int32_t* mt_next, int32_t* has_gauss, double* gauss,
+                               int32_t attempts, int32_t T, int32_t K, double* start, double* vel0, double* eta,
+                               double* noise, uint32_t* after_words, int32_t* after_next, int32_t* after_has_gauss,
+                               double* after_gauss);
+
+/*
  * One attempt of the accept/reject loop of simulation.simulate_lineage
  * (simulation.py:264-282) for one branch, without materialising (T,G):
  *   rel = programs @ H                                   simulation.py:269
@@ -174,6 +193,10 @@ int prosstt_amd_lineage_attempt_batch(prosstt_amd_ctx* ctx, const double* progra
  */
 int prosstt_amd_lineage_walk(prosstt_amd_ctx* ctx, uint64_t seed, uint64_t stream_id, int32_t T,
                              int32_t K, double* programs_out);
+/* B attempts in one launch and one copy back: walk streams first_stream_id .. first_stream_id + B - 1;
+ * programs_out: HOST [B][T][K]. */
+int prosstt_amd_lineage_walk_batch(prosstt_amd_ctx* ctx, uint64_t seed, uint64_t first_stream_id, int32_t B,
+                                   int32_t T, int32_t K, double* programs_out);
 
 /*
  * Materialise an accepted branch: rel_out[t][g] = sum_k programs[t][k]*H[k][g]

@@ -13,15 +13,16 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PROSSTT_AMD_LIB") or os.path.join(_HERE, "lib", "libprosstt_amd.so")
 
 OK, EINVAL, EDOMAIN, EHIP, ENOMEM, ENODEV = 0, -1, -2, -3, -4, -5
-HOST_INPUTS, HOST_OUTPUT, CHECK_DOMAIN, TIME_KERNEL, CHECK_DEFERRED, MEANS_CACHED = 1, 2, 4, 8, 16, 32
+HOST_INPUTS, HOST_OUTPUT, CHECK_DOMAIN, TIME_KERNEL, CHECK_DEFERRED, MEANS_CACHED, PARAMS_NONNEG = 1, 2, 4, 8, 16, 32, 64
 
 # every symbol include/prosstt_amd.h declares
 SYMBOLS = [
     "prosstt_amd_version", "prosstt_amd_last_error", "prosstt_amd_device_count",
     "prosstt_amd_ctx_create", "prosstt_amd_ctx_destroy", "prosstt_amd_ctx_synchronize",
     "prosstt_amd_last_kernel_ms", "prosstt_amd_sample_counts", "prosstt_amd_last_list", "prosstt_amd_nb_params",
-    "prosstt_amd_hw_math", "prosstt_amd_domain_status",
+    "prosstt_amd_hw_math", "prosstt_amd_domain_status", "prosstt_amd_numpy_programs",
     "prosstt_amd_lineage_attempt", "prosstt_amd_lineage_attempt_batch", "prosstt_amd_lineage_walk",
+    "prosstt_amd_lineage_walk_batch",
     "prosstt_amd_lineage_commit",
     "prosstt_amd_gene_max",
     "prosstt_amd_means_from_rel",
@@ -70,9 +71,11 @@ def load():
         L.prosstt_amd_nb_params.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp, u32]
         L.prosstt_amd_hw_math.argtypes = [vp, i32, u32, u64, vp, u32]
         L.prosstt_amd_domain_status.argtypes = [vp, ctypes.POINTER(i32)]
+        L.prosstt_amd_numpy_programs.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
         L.prosstt_amd_lineage_attempt.argtypes = [vp, vp, i32, i32, vp, i64, i32, vp, vp, vp, vp]
         L.prosstt_amd_lineage_attempt_batch.argtypes = [vp, vp, i32, i32, i32, vp, i64, i32, vp, vp, vp, vp]
         L.prosstt_amd_lineage_walk.argtypes = [vp, u64, u64, i32, i32, vp]
+        L.prosstt_amd_lineage_walk_batch.argtypes = [vp, u64, u64, i32, i32, i32, vp]
         L.prosstt_amd_lineage_commit.argtypes = [vp, vp, i32, i32, vp, i64, vp, vp]
         L.prosstt_amd_gene_max.argtypes = [vp, vp, i64, i64, vp]
         L.prosstt_amd_means_from_rel.argtypes = [vp, vp, vp, i64, i64, vp]

@@ -25,6 +25,7 @@
 #include "prnb_device.h"
 #include "k3_stream.h"
 #include "k3_heavy.h"
+#include "numpy_stream.h"
 
 #define PA_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -312,10 +313,15 @@ __global__ __launch_bounds__(256) void lineage_attempt_kernel(
 
 // K1: one lane per expression program, T sequential steps (walk definition PRLW-1)
 __global__ void lineage_walk_kernel(uint32_t k0, uint32_t k1, uint32_t sid_lo, uint32_t sid_hi, int32_t T,
-                                    int32_t K, double* __restrict__ out)
+                                    int32_t K, double* out)
 {
     const int32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
+    // walk stream blockIdx.y of a batch: consecutive stream ids, consecutive (T, K) blocks of the output
+    const uint64_t sid = (((uint64_t)sid_hi << 32) | sid_lo) + blockIdx.y;
+    sid_lo = (uint32_t)sid;
+    sid_hi = (uint32_t)(sid >> 32);
+    out += (int64_t)blockIdx.y * T * K;
     prnb::Words w = prnb::philox4x32_10((uint32_t)k, 0u, sid_lo, sid_hi, k0, k1);
     double walk = (double)prnb::det_log(1.5f * prnb::unif(w.w[0]));
     double vel = 0.2 * (double)(prnb::det_sqrt(-2.0f * prnb::det_log(prnb::unif(w.w[1]))) * prnb::det_cos2pi(w.w[2]));
@@ -332,33 +338,79 @@ __global__ void lineage_walk_kernel(uint32_t k0, uint32_t k1, uint32_t sid_lo, u
     }
 }
 
+// max into a binary64 cell shared by a few blocks (compare-and-swap on the bits; NaN never wins)
+__device__ __forceinline__ void atomic_max_f64(double* cell, double v)
+{
+    unsigned long long* bits = reinterpret_cast<unsigned long long*>(cell);
+    unsigned long long seen = *bits;
+    while (v > __longlong_as_double((long long)seen)) {
+        const unsigned long long was = atomicCAS(bits, seen, (unsigned long long)__double_as_longlong(v));
+        if (was == seen) break;
+        seen = was;
+    }
+}
+
+// K2b: rel[t][g] = sum_k progs[t][k] * H[k][g] for an accepted branch, and its per-gene maximum folded into gene_max.
+// Block = 64 genes x 4 groups of time steps, blockIdx.y = one of gridDim.y ranges of the T steps (the host picks them
+// so that the launch has >= 1024 blocks); the range's programs sit in LDS (wave-uniform reads), a gene's H column in
+// registers when K <= 32.  The dot product runs over k in ascending order by fma, as the attempt kernel's does.
+constexpr int kCommitLdsDoubles = 2048;     // programs of one block's time range: steps * K <= this (the host sizes gridDim.y)
+
+template <bool HREG>
 __global__ __launch_bounds__(256) void lineage_commit_kernel(const double* __restrict__ progs,
                                                              int32_t T, int32_t K,
                                                              const double* __restrict__ H, int64_t G,
                                                              double* __restrict__ rel_out,
                                                              double* __restrict__ gene_max)
 {
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= G) return;
-    const double* h = H + g;
-    double mx = gene_max ? gene_max[g] : 0.0;
-    for (int t = 0; t < T; ++t) {
+    __shared__ double pl[kCommitLdsDoubles];
+    __shared__ double part[4][64];
+    const int gl = threadIdx.x & 63, c = threadIdx.x >> 6;
+    const int64_t g = (int64_t)blockIdx.x * 64 + gl;
+    const bool live = g < G;
+    const int t0 = (int)(((int64_t)blockIdx.y * T) / gridDim.y), t1 = (int)(((int64_t)(blockIdx.y + 1) * T) / gridDim.y);
+    for (int i = threadIdx.x; i < (t1 - t0) * K; i += 256) pl[i] = progs[(int64_t)t0 * K + i];
+    const double* h = H + (live ? g : 0);
+    double hreg[HREG ? 32 : 1];
+    if (HREG) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) hreg[k] = k < K ? h[(int64_t)k * G] : 0.0;
+    }
+    __syncthreads();
+    double mx = -std::numeric_limits<double>::infinity();
+    for (int t = t0 + c; t < t1; t += 4) {
+        const double* row = pl + (t - t0) * K;
         double acc = 0.0;
-        for (int k = 0; k < K; ++k) acc = fma(progs[t * K + k], h[(int64_t)k * G], acc);
-        if (rel_out) rel_out[(int64_t)t * G + g] = acc;
+        if (HREG) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k)
+                if (k < K) acc = fma(row[k], hreg[k], acc);
+        } else {
+            for (int k = 0; k < K; ++k) acc = fma(row[k], h[(int64_t)k * G], acc);
+        }
+        if (live && rel_out) rel_out[(int64_t)t * G + g] = acc;
         mx = fmax(mx, acc);
     }
-    if (gene_max) gene_max[g] = mx;
+    if (!gene_max) return;
+    part[c][gl] = mx;
+    __syncthreads();
+    if (c == 0 && live) atomic_max_f64(&gene_max[g], fmax(fmax(part[0][gl], part[1][gl]), fmax(part[2][gl], part[3][gl])));
 }
 
+// gene_max[g] = max(gene_max[g], max over rows of rel[row][g]): block = 64 genes x 4 groups of rows, blockIdx.y = a range of rows
 __global__ __launch_bounds__(256) void gene_max_kernel(const double* __restrict__ rel, int64_t rows,
                                                        int64_t G, double* __restrict__ gene_max)
 {
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= G) return;
-    double mx = gene_max[g];
-    for (int64_t t = 0; t < rows; ++t) mx = fmax(mx, rel[t * G + g]);
-    gene_max[g] = mx;
+    __shared__ double part[4][64];
+    const int gl = threadIdx.x & 63, c = threadIdx.x >> 6;
+    const int64_t g = (int64_t)blockIdx.x * 64 + gl;
+    const int64_t r0 = ((int64_t)blockIdx.y * rows) / gridDim.y, r1 = ((int64_t)(blockIdx.y + 1) * rows) / gridDim.y;
+    double mx = -std::numeric_limits<double>::infinity();
+    if (g < G)
+        for (int64_t t = r0 + c; t < r1; t += 4) mx = fmax(mx, rel[t * G + g]);
+    part[c][gl] = mx;
+    __syncthreads();
+    if (c == 0 && g < G) atomic_max_f64(&gene_max[g], fmax(fmax(part[0][gl], part[1][gl]), fmax(part[2][gl], part[3][gl])));
 }
 
 __global__ __launch_bounds__(256) void means_from_rel_kernel(const double* __restrict__ rel,
@@ -719,7 +771,7 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
     c->list_groups = geo.groups;
     c->list_strip_cells = geo.strip_cells;
     const bool checked = (flags & (PROSSTT_AMD_CHECK_DOMAIN | PROSSTT_AMD_CHECK_DEFERRED)) != 0;
-    if (checked) {
+    if (checked && !(flags & PROSSTT_AMD_PARAMS_NONNEG)) {
         // (leaves at once unless a gene has alpha < 0 or beta < 1: prep_kernel's request word)
         domain_full_kernel<<<dim3(8192), dim3(256), 0, c->stream>>>(A.means, G, A.row_of_cell, A.scal, A.ga,
                                                                   A.gbm1, N, rows, c->scratch, c->call_parity);
@@ -830,6 +882,29 @@ PA_EXPORT int prosstt_amd_hw_math(prosstt_amd_ctx* c, int32_t op, uint32_t first
     return 0;
 }
 
+PA_EXPORT int prosstt_amd_numpy_programs(uint32_t* mt_words, int32_t* mt_next, int32_t* has_gauss, double* gauss,
+                                         int32_t attempts, int32_t T, int32_t K, double* start, double* vel0, double* eta,
+                                         double* noise, uint32_t* after_words, int32_t* after_next,
+                                         int32_t* after_has_gauss, double* after_gauss)
+{
+    if (!mt_words || !mt_next || !has_gauss || !gauss || !start || !vel0 || !eta || !after_words || !after_next ||
+        !after_has_gauss || !after_gauss || (T > 1 && !noise))
+        return fail(PROSSTT_AMD_EINVAL, "NULL argument");
+    if (attempts <= 0 || T <= 0 || K <= 0) return fail(PROSSTT_AMD_EINVAL, "bad size");
+    if (*mt_next < 0 || *mt_next > npstream::kWords) return fail(PROSSTT_AMD_EINVAL, "generator position %d outside [0,624]", *mt_next);
+    npstream::Generator g;
+    memcpy(g.word, mt_words, sizeof(g.word));
+    g.next = *mt_next;
+    g.has_spare = *has_gauss != 0;
+    g.spare = *gauss;
+    npstream::draw_programs(g, attempts, T, K, start, vel0, eta, noise, after_words, after_next, after_has_gauss, after_gauss);
+    memcpy(mt_words, g.word, sizeof(g.word));
+    *mt_next = g.next;
+    *has_gauss = g.has_spare;
+    *gauss = g.spare;
+    return 0;
+}
+
 // centre the first `steps` rows of a [*][K] program matrix over time (scipy.stats.pearsonr's xm = x - mean)
 static void centred(const double* src, int steps, int K, double* dst)
 {
@@ -916,22 +991,28 @@ PA_EXPORT int prosstt_amd_lineage_attempt(prosstt_amd_ctx* c, const double* prog
                                              out_anticorr);
 }
 
-PA_EXPORT int prosstt_amd_lineage_walk(prosstt_amd_ctx* c, uint64_t seed, uint64_t stream_id, int32_t T,
-                                       int32_t K, double* programs_out)
+PA_EXPORT int prosstt_amd_lineage_walk_batch(prosstt_amd_ctx* c, uint64_t seed, uint64_t first_stream_id, int32_t B,
+                                             int32_t T, int32_t K, double* programs_out)
 {
     if (!c || !programs_out) return fail(PROSSTT_AMD_EINVAL, "NULL argument");
-    if (T <= 0 || K <= 0) return fail(PROSSTT_AMD_EINVAL, "bad size");
+    if (B <= 0 || B > 65535 || T <= 0 || K <= 0) return fail(PROSSTT_AMD_EINVAL, "bad size");
     HIP_TRY(hipSetDevice(c->device));
-    const size_t bytes = (size_t)T * K * 8;
+    const size_t bytes = (size_t)B * T * K * 8;
     int rc = ws_reserve(c, bytes);
     if (rc) return rc;
-    lineage_walk_kernel<<<dim3((unsigned)((K + 63) / 64)), dim3(64), 0, c->stream>>>(
-        (uint32_t)seed ^ 0x57414C4Bu, (uint32_t)(seed >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32), T, K,
+    lineage_walk_kernel<<<dim3((unsigned)((K + 63) / 64), (unsigned)B), dim3(64), 0, c->stream>>>(
+        (uint32_t)seed ^ 0x57414C4Bu, (uint32_t)(seed >> 32), (uint32_t)first_stream_id, (uint32_t)(first_stream_id >> 32), T, K,
         (double*)c->ws);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(programs_out, c->ws, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
+}
+
+PA_EXPORT int prosstt_amd_lineage_walk(prosstt_amd_ctx* c, uint64_t seed, uint64_t stream_id, int32_t T,
+                                       int32_t K, double* programs_out)
+{
+    return prosstt_amd_lineage_walk_batch(c, seed, stream_id, 1, T, K, programs_out);
 }
 
 PA_EXPORT int prosstt_amd_lineage_commit(prosstt_amd_ctx* c, const double* programs, int32_t T, int32_t K,
@@ -944,8 +1025,17 @@ PA_EXPORT int prosstt_amd_lineage_commit(prosstt_amd_ctx* c, const double* progr
     int rc = ws_reserve(c, bytes);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(c->ws, programs, bytes, hipMemcpyHostToDevice, c->stream));
-    lineage_commit_kernel<<<dim3((unsigned)((G + 255) / 256)), dim3(256), 0, c->stream>>>(
-        (const double*)c->ws, T, K, H, G, rel_out, gene_max);
+    // ranges of time steps: enough blocks to fill the chip (>= 1024 when T allows), few enough steps per block for its LDS
+    const int64_t gene_blocks = (G + 63) / 64;
+    if ((int64_t)K * 2 > kCommitLdsDoubles) return fail(PROSSTT_AMD_EINVAL, "more than %d expression programs", kCommitLdsDoubles / 2);
+    int64_t ranges = (1024 + gene_blocks - 1) / gene_blocks;
+    while (ranges < T && (int64_t)((T + ranges - 1) / ranges + 1) * K > kCommitLdsDoubles) ++ranges;
+    if (ranges > T) ranges = T;
+    const dim3 grid((unsigned)gene_blocks, (unsigned)ranges);
+    if (K <= 32)
+        lineage_commit_kernel<true><<<grid, dim3(256), 0, c->stream>>>((const double*)c->ws, T, K, H, G, rel_out, gene_max);
+    else
+        lineage_commit_kernel<false><<<grid, dim3(256), 0, c->stream>>>((const double*)c->ws, T, K, H, G, rel_out, gene_max);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));   // `programs` is a pageable host buffer the caller may reuse
     return 0;
@@ -958,7 +1048,10 @@ PA_EXPORT int prosstt_amd_gene_max(prosstt_amd_ctx* c, const double* rel, int64_
     if (rows < 0 || G < 0) return fail(PROSSTT_AMD_EINVAL, "negative size");
     if (rows == 0 || G == 0) return 0;
     HIP_TRY(hipSetDevice(c->device));
-    gene_max_kernel<<<dim3((unsigned)((G + 255) / 256)), dim3(256), 0, c->stream>>>(rel, rows, G, gene_max);
+    const int64_t gene_blocks = (G + 63) / 64;
+    int64_t ranges = (2048 + gene_blocks - 1) / gene_blocks;
+    if (ranges > (rows + 15) / 16) ranges = (rows + 15) / 16;
+    gene_max_kernel<<<dim3((unsigned)gene_blocks, (unsigned)(ranges > 0 ? ranges : 1)), dim3(256), 0, c->stream>>>(rel, rows, G, gene_max);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -44,6 +44,7 @@ class Context:
             self.device, ctypes.c_void_p(self.stream.cuda_stream), ctypes.byref(handle)))
         self._h = handle
         self._checked_means = None      # (pointer, rows, G, token) of the mean tensor whose row flags the ctx holds
+        self._nonneg_cache = {}         # device alpha / beta tensors already verified (see _params_nonneg)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -93,6 +94,7 @@ class Context:
         row_of_cell = self.tensor(row_of_cell, torch.int32)
         N = row_of_cell.numel()
         scaling = self.tensor(scaling, torch.float64)
+        nonneg = bool(check_domain) and self._params_nonneg(alpha, beta)
         alpha = self.tensor(alpha, torch.float64)
         beta = self.tensor(beta, torch.float64)
         if scaling.numel() != N or alpha.numel() != G or beta.numel() != G:
@@ -113,6 +115,8 @@ class Context:
         flags = _native.TIME_KERNEL if time_kernel else 0
         if check_domain:
             flags |= _native.CHECK_DEFERRED if check_domain == "deferred" else _native.CHECK_DOMAIN
+            if nonneg:
+                flags |= _native.PARAMS_NONNEG
             key = (means.data_ptr(), rows, G, means_token)
             if means_token is not None and key == self._checked_means:
                 flags |= _native.MEANS_CACHED
@@ -122,6 +126,25 @@ class Context:
             N, ctypes.c_uint64(seed & (2 ** 64 - 1)), ctypes.c_uint64(cell_offset), _ptr(cell_index),
             _ptr(out), out.stride(0) if N else G, flags))
         return out
+
+    def _params_nonneg(self, alpha, beta):
+        """alpha >= 0 and beta >= 1 for every gene (then alpha*m + beta < 1 cannot happen and the checked call
+        skips its per-sample pass).  Host arrays are looked at here (O(G)); device tensors once per
+        (storage, version) -- torch counts their in-place edits."""
+        torch = _torch()
+        verdicts = []
+        for arr, floor in ((alpha, 0.0), (beta, 1.0)):
+            if isinstance(arr, torch.Tensor):
+                key = (arr.data_ptr(), arr.numel(), arr._version, floor)
+                if key not in self._nonneg_cache:
+                    if len(self._nonneg_cache) > 64:
+                        self._nonneg_cache.clear()
+                    self._nonneg_cache[key] = bool((arr >= floor).all()) if arr.numel() else True
+                verdicts.append(self._nonneg_cache[key])
+            else:
+                a = np.asarray(arr)
+                verdicts.append(bool(np.all(a >= floor)))
+        return all(verdicts)
 
     def domain_status(self):
         """Raise what the ``check_domain="deferred"`` calls since the last time found (ValueError where the
@@ -209,6 +232,19 @@ class Context:
             out.ctypes.data_as(ctypes.c_void_p)))
         return out
 
+    def lineage_walks(self, seed, stream_ids, T, K):
+        """(B, T, K) programs of the walk streams ``stream_ids`` (consecutive ids: one launch, one copy back)."""
+        ids = [int(i) for i in stream_ids]
+        if not ids:
+            return np.empty((0, T, K), np.float64)
+        if ids != list(range(ids[0], ids[0] + len(ids))):
+            return np.stack([self.lineage_walk(seed, i, T, K) for i in ids])
+        out = np.empty((len(ids), T, K), np.float64)
+        _native.check(self._lib.prosstt_amd_lineage_walk_batch(
+            self._h, ctypes.c_uint64(seed & (2 ** 64 - 1)), ctypes.c_uint64(ids[0]), len(ids), T, K,
+            out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
     def lineage_commit(self, programs, H, rel_out=None, gene_max=None):
         programs = np.ascontiguousarray(programs, np.float64)
         T, K = programs.shape
@@ -238,11 +274,12 @@ def host_fingerprint(arrays):
     One pass at memory speed (64 MB in ~6 ms)."""
     try:
         from xxhash import xxh3_64_intdigest as digest
-    except ImportError:                              # position-blind, still catches any single edit
+    except ImportError:                              # slower (64 MB in ~60 ms), as position-sensitive
+        import zlib
+
         def digest(buf):
-            flat = np.frombuffer(buf, dtype=np.uint8)
-            head = flat[:flat.size // 8 * 8].view(np.uint64)
-            return int(head.sum(dtype=np.uint64)) ^ (int(flat[head.size * 8:].sum()) << 1)
+            view = memoryview(buf).cast("B")
+            return (zlib.crc32(view) << 32) | zlib.adler32(view)
     out = []
     for a in arrays:
         if isinstance(a, np.ndarray):
@@ -256,50 +293,76 @@ def host_fingerprint(arrays):
 PINNED_RETURN_MAX = int(os.environ.get("PROSSTT_AMD_PINNED_MAX_BYTES", str(32 << 30)))
 
 
-def to_host_int64(counts, chunk_bytes=256 << 20):
-    """int32 device counts -> the reference's int64 ndarray (simulation.py:651).
+HOST_DTYPES = {"numpy": np.int64, "numpy32": np.int32, "numpy16": np.uint16}
 
-    The matrix is widened on the device a chunk of rows at a time (two staging buffers) and every
-    chunk travels by an asynchronous copy on a second stream while the next one is widened.  The
-    destination is page-locked host memory from torch's caching host allocator whenever the matrix is
-    at most PROSSTT_AMD_PINNED_MAX_BYTES (default 32 GiB): DMA straight into the array that is
-    returned, no bounce buffers and no first-touch page faults; the block goes back to the allocator's
-    cache when the caller drops the array, so the pinning cost is paid once per size.  Larger results
-    (or a failed page-lock) take the same chunked path into ordinary memory."""
+
+def to_host(counts, dtype=np.int64, chunk_bytes=256 << 20):
+    """int32 device counts -> host ndarray of ``dtype``: int64 (the reference's return type,
+    simulation.py:651), int32 (what the device holds: half the bytes over PCIe) or uint16 (a quarter; raises
+    OverflowError if a count does not fit -- counts of scRNA-seq simulations are far below 65 536).
+
+    The matrix travels a chunk of rows at a time by asynchronous copies on a second stream into page-locked
+    host memory from torch's caching host allocator -- the array that is returned -- whenever it is at most
+    PROSSTT_AMD_PINNED_MAX_BYTES (default 32 GiB): DMA straight into the result, no bounce buffers and no
+    first-touch page faults; the block goes back to the allocator's cache when the caller drops the array, so
+    the pinning cost is paid once per size.  Larger results (or a failed page-lock) take the same chunked path
+    into ordinary memory.  int64 and uint16 are converted on the device, chunk by chunk (two staging buffers),
+    under the transfer of the previous chunk; int32 is copied as it lies."""
     torch = _torch()
+    dtype = np.dtype(dtype)
     n, g = counts.shape
+    if dtype not in (np.dtype(np.int64), np.dtype(np.int32), np.dtype(np.uint16)):
+        raise ValueError("host counts are int64, int32 or uint16")
     if n == 0 or g == 0:
-        return np.zeros((n, g), dtype=np.int64)
+        return np.zeros((n, g), dtype=dtype)
+    # (torch has no arithmetic on uint16: the device narrows to int16 bit patterns, viewed as uint16 on the host)
+    t_dtype = {8: torch.int64, 4: torch.int32, 2: torch.int16}[dtype.itemsize]
     host = None
-    if n * g * 8 <= PINNED_RETURN_MAX:
+    if n * g * dtype.itemsize <= PINNED_RETURN_MAX:
         try:
-            host = torch.empty((n, g), dtype=torch.int64, pin_memory=True)
+            host = torch.empty((n, g), dtype=t_dtype, pin_memory=True)
         except RuntimeError:
             host = None
     if host is None:
-        host = torch.empty((n, g), dtype=torch.int64)
-    rows = max(1, min(n, int(chunk_bytes) // (g * 8)))
+        host = torch.empty((n, g), dtype=t_dtype)
+    rows = max(1, min(n, int(chunk_bytes) // (g * dtype.itemsize)))
     dev = counts.device
     compute = torch.cuda.current_stream(dev)
     copier = torch.cuda.Stream(dev)
-    staging = [torch.empty((rows, g), dtype=torch.int64, device=dev) for _ in range(2 if rows < n else 1)]
+    convert = t_dtype != torch.int32
+    staging = [torch.empty((rows, g), dtype=t_dtype, device=dev) for _ in range(2 if rows < n else 1)] if convert else []
     copied = [None, None]
+    too_big = torch.zeros((), dtype=torch.int32, device=dev) if dtype.itemsize == 2 else None
     for i, lo in enumerate(range(0, n, rows)):
         hi = min(lo + rows, n)
-        slot = i & 1
-        if copied[slot] is not None:
-            compute.wait_event(copied[slot])           # the buffer's previous chunk has left
-        stage = staging[slot][:hi - lo]
-        stage.copy_(counts[lo:hi])                      # int32 -> int64 on the device
-        widened = torch.cuda.Event()
-        widened.record(compute)
-        copier.wait_event(widened)
+        if convert:
+            slot = i & 1
+            if copied[slot] is not None:
+                compute.wait_event(copied[slot])           # the buffer's previous chunk has left
+            stage = staging[slot][:hi - lo]
+            if too_big is not None:
+                too_big = torch.maximum(too_big, counts[lo:hi].max())
+            stage.copy_(counts[lo:hi])                      # int32 -> int64, or the low 16 bits
+        else:
+            stage = counts[lo:hi]
+        ready = torch.cuda.Event()
+        ready.record(compute)
+        copier.wait_event(ready)
         with torch.cuda.stream(copier):
             host[lo:hi].copy_(stage, non_blocking=True)
-            copied[slot] = torch.cuda.Event()
-            copied[slot].record(copier)
+            if convert:
+                copied[slot] = torch.cuda.Event()
+                copied[slot].record(copier)
     copier.synchronize()
-    return host.numpy()
+    if too_big is not None and int(too_big) > 65535:
+        raise OverflowError("a count of %d does not fit uint16: ask for 'numpy32'" % int(too_big))
+    out = host.numpy()
+    return out.view(np.uint16) if dtype.itemsize == 2 else out
+
+
+def to_host_int64(counts, chunk_bytes=256 << 20):
+    """int32 device counts -> the reference's int64 ndarray (simulation.py:651); see ``to_host``."""
+    return to_host(counts, np.int64, chunk_bytes)
 
 
 _contexts = {}

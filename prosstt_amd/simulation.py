@@ -22,7 +22,7 @@ import pandas as pd
 from . import count_model as cm
 from . import device as _device
 from . import sim_utils as sut
-from .device import to_host_int64 as _to_host_int64
+from .device import HOST_DTYPES as _HOST_DTYPES, to_host as _to_host
 
 
 # ----------------------------------------------------------------------------------
@@ -90,6 +90,48 @@ def sim_expr_branch(branch_length, expr_progr, cutoff=0.2, max_loops=100):
     return np.transpose(programs)
 
 
+def sim_expr_branches(attempts, branch_length, expr_progr):
+    """``attempts`` consecutive ``sim_expr_branch(branch_length, expr_progr)`` results in one go:
+    ``(programs (attempts, branch_length, expr_progr), states)`` where ``states[i]`` is what
+    ``np.random.get_state()`` would return behind the i-th call.  The variates come from numpy's own global
+    stream through the library's generator of it (``prosstt_amd_numpy_programs``: one call instead of
+    4 * expr_progr * attempts numpy calls), the walks are the reference's recurrence (simulation.py:114-121)
+    advanced for all of them at once, one time step per numpy operation: the same binary64 operations on the
+    same numbers.  numpy's generator is left behind the LAST attempt; the caller rewinds it with
+    ``np.random.set_state(states[i])``."""
+    import ctypes
+    from . import _native
+    if expr_progr < 2:
+        raise ValueError("at least 2 expression programs are needed (the reference never "
+                         "terminates for 1)")
+    lib = _native.load()
+    kind, words, pos, has_gauss, gauss = random.get_state()
+    if kind != "MT19937":
+        raise RuntimeError("numpy's global generator is not the legacy MT19937")
+    words = np.ascontiguousarray(words, dtype=np.uint32).copy()
+    pos_c, has_c, gauss_c = ctypes.c_int32(int(pos)), ctypes.c_int32(int(has_gauss)), ctypes.c_double(float(gauss))
+    B, T, K = int(attempts), int(branch_length), int(expr_progr)
+    start, vel0, eta = (np.empty((B, K)) for _ in range(3))
+    noise = np.empty((B, K, max(T - 1, 0)))
+    after_words = np.empty((B, 624), np.uint32)
+    after_pos, after_has = np.empty(B, np.int32), np.empty(B, np.int32)
+    after_gauss = np.empty(B)
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    _native.check(lib.prosstt_amd_numpy_programs(
+        ptr(words), ctypes.byref(pos_c), ctypes.byref(has_c), ctypes.byref(gauss_c), B, T, K, ptr(start), ptr(vel0),
+        ptr(eta), ptr(noise), ptr(after_words), ptr(after_pos), ptr(after_has), ptr(after_gauss)))
+    random.set_state(("MT19937", words, pos_c.value, has_c.value, gauss_c.value))
+    states = [("MT19937", after_words[i], int(after_pos[i]), int(after_has[i]), float(after_gauss[i])) for i in range(B)]
+    walks = np.empty((B, T, K))
+    level, velocity = np.log(start), vel0
+    for t in range(T - 1):
+        walks[:, t] = level
+        level = level + velocity
+        velocity = eta * velocity + noise[:, :, t]
+    walks[:, T - 1] = level
+    return walks, states
+
+
 def simulate_coefficients(tree, fallback_a=0.04, **kwargs):
     """(K, G) contribution of every program to every gene (simulation.py:127-161)."""
     if "a" not in kwargs.keys():
@@ -154,6 +196,11 @@ def _device_gene_max(tree, relative_means):
     cache = _lineage_cache(tree, relative_means)
     if cache is not None:
         return cache["gene_max"]
+    if getattr(tree, "_branch_owner", None) is not None:
+        # built sharded over ranks: this process holds only its own branches' rows, so a maximum recomputed here
+        # would differ from rank to rank and the ranks would build mutually inconsistent mean tensors
+        raise ValueError("the relative means of a tree built by simulate_lineage_sharded must be passed on unmodified "
+                         "(the per-gene maximum over the whole tree was reduced across the ranks when it was built)")
     ctx = _device.get_context()
     rel = ctx.tensor(_stack_rows(tree, relative_means), torch.float64)
     gmax = torch.full((rel.shape[1],), -np.inf, dtype=torch.float64, device=ctx.torch_device)
@@ -240,12 +287,12 @@ def _lineage_loop(tree, ctx, evaluate, commit, rel_exp_cutoff, intra_branch_tol,
             candidates, states = [], []
             entry_state = random.get_state() if rng == "numpy" else None
             try:
+                if rng == "device":
+                    drawn = ctx.lineage_walks(seed, [(ordinal << 32) | (tries + i) for i in range(width)], steps, int(tree.modules))
+                else:
+                    drawn, states = sim_expr_branches(width, steps, int(tree.modules))
                 for i in range(width):
-                    if rng == "device":
-                        programs[branch] = ctx.lineage_walk(seed, (ordinal << 32) | (tries + i), steps, int(tree.modules))
-                    else:
-                        programs[branch] = sim_expr_branch(steps, tree.modules, cutoff=intra_branch_tol)
-                        states.append(random.get_state())
+                    programs[branch] = drawn[i]
                     candidates.append(sut.adjust_to_parent(programs, branch, topology))
                 if siblings is None:
                     siblings = [b for b in sut.find_parallel(tree, programs, branch)
@@ -360,6 +407,47 @@ def sample_density(tree, no_cells, alpha=0.3, beta=2, scale=True, scale_v=0.7, s
                                  scale=scale, scale_mean=scale_mean, scale_v=scale_v, **device_opts)
 
 
+def sample_density_chunks(tree, no_cells, chunk_cells, alpha=0.3, beta=2, scale=True, scale_v=0.7, scale_mean=0.,
+                          *, seed=None, out="numpy32", strict=True):
+    """``sample_density`` (simulation.py:416-471) for matrices that should not exist whole on the host -- or
+    not all at once: a generator of ``(counts, pseudotime, branches, scalings)`` for successive ranges of
+    ``chunk_cells`` cells of ONE plan (drawn up front, with the reference's numpy calls).  Chunk i + 1 is
+    sampled on the device while chunk i travels to the host; every count equals the one the single call
+    returns for that cell (the sampler is keyed by the cell's position in the plan), so the chunks
+    concatenate to ``sample_density``'s matrix.  ``out``: as in ``draw_counts`` ("torch" yields device
+    tensors that the consumer must be done with before asking for the next chunk but one)."""
+    if out != "torch" and out not in _HOST_DTYPES:
+        raise ValueError("out must be 'numpy', 'numpy32', 'numpy16' or 'torch'")
+    if chunk_cells <= 0:
+        raise ValueError("chunk_cells must be positive")
+    alpha, beta = (np.full(tree.G, v, dtype=np.float64) if np.ndim(v) == 0 else np.asarray(v, dtype=np.float64)
+                   for v in (alpha, beta))
+    sample_time, sample_branches = _density_plan(tree, no_cells)
+    scalings = sut.calc_scalings(no_cells, scale, scale_mean, scale_v)
+    if seed is None:
+        lo, hi = random.randint(0, 2 ** 32, size=2, dtype=np.uint64)
+        seed = int(lo) | (int(hi) << 32)
+    ctx = _device.get_context()
+    rows = cell_rows(tree, sample_time, sample_branches)
+    token = tree.means_token()
+    means = tree.device_means()
+
+    def launch(lo):
+        hi = min(lo + chunk_cells, no_cells)
+        return ctx.sample_counts(means, rows[lo:hi], scalings[lo:hi], alpha, beta, seed=seed, cell_offset=lo,
+                                 check_domain="deferred" if strict else False, means_token=token)
+
+    pending = launch(0) if no_cells else None
+    for lo in range(0, no_cells, chunk_cells):
+        hi = min(lo + chunk_cells, no_cells)
+        counts = pending
+        pending = launch(hi) if hi < no_cells else None      # enqueued behind `counts`, runs under its copy
+        host = counts if out == "torch" else _to_host(counts, _HOST_DTYPES[out])
+        if strict:
+            ctx.domain_status()
+        yield host, sample_time[lo:hi], sample_branches[lo:hi], scalings[lo:hi]
+
+
 def sample_whole_tree(tree, n_factor, alpha=0.3, beta=2, scale=True, scale_mean=0., scale_v=0.7,
                       **device_opts):
     """Every (pseudotime, branch) position ``n_factor`` times (simulation.py:474-517)."""
@@ -428,8 +516,9 @@ def draw_counts(tree, pseudotime, branches, scalings, alpha, beta, *, seed=None,
     New keyword-only options
       seed    64-bit sampler seed.  Default: two 32-bit draws from numpy's global
               stream, so ``np.random.seed`` still determines the whole simulation.
-      out     "numpy" (default): int64 ndarray like the reference; "torch": the
-              int32 device tensor, no host copy.
+      out     "numpy" (default): int64 ndarray like the reference; "numpy32": int32 (what the
+              device holds -- half the bytes over PCIe); "numpy16": uint16 (a quarter; OverflowError
+              if a count does not fit); "torch": the int32 device tensor, no host copy.
       strict  raise ``ValueError`` where scipy's argument check would (an exact-zero
               mean, or alpha*m + beta < 1); the test rides in the call's own kernels (the per-row flags of
               the mean tensor are kept until the tensor changes) and costs no launch and no extra
@@ -443,8 +532,8 @@ def draw_counts(tree, pseudotime, branches, scalings, alpha, beta, *, seed=None,
         seed = int(lo) | (int(hi) << 32)
     ctx = _device.get_context()
     rows = cell_rows(tree, pseudotime, branches)
-    if out not in ("numpy", "torch"):
-        raise ValueError("out must be 'numpy' or 'torch'")
+    if out != "torch" and out not in _HOST_DTYPES:
+        raise ValueError("out must be 'numpy', 'numpy32', 'numpy16' or 'torch'")
     # the domain check rides in the call's own kernels and is not waited for; its verdict is read behind the copy to the
     # host (which synchronises anyway), or at once when the device tensor itself is returned
     token = tree.means_token()
@@ -455,7 +544,7 @@ def draw_counts(tree, pseudotime, branches, scalings, alpha, beta, *, seed=None,
         if strict:
             ctx.domain_status()
         return counts
-    host = _to_host_int64(counts)
+    host = _to_host(counts, _HOST_DTYPES[out])
     if strict:
         ctx.domain_status()
     return host

@@ -191,6 +191,50 @@ def test_sample_counts_new_name():
     assert X.dtype == np.int64
 
 
+def test_compact_host_returns_and_chunk_generator():
+    """out="numpy32" / "numpy16": the same counts as the reference-typed int64 return in a half / a quarter of the
+    bytes (uint16 refuses a count it cannot hold); sample_density_chunks: the chunks of one plan concatenate to the
+    matrix of the single call, whatever the chunk length, and a zero mean raises from the generator as it does
+    from the call."""
+    from prosstt_amd import count_model as cm, simulation as sim
+    from prosstt_amd import tree as ptree
+    np.random.seed(7)
+    t = ptree.Tree(topology=[["A", "B"], ["A", "C"]], time={"A": 30, "B": 25, "C": 35}, num_branches=3, branch_points=1,
+                   modules=6, G=700)
+    rel, _, _ = sim.simulate_lineage(t, a=0.05, intra_branch_tol=0)
+    from prosstt_amd import sim_utils as sut
+    t.add_genes(rel, sut.simulate_base_gene_exp(t, rel))
+    al, be = np.full(t.G, 0.3), np.full(t.G, 2.0)
+    state = np.random.get_state()
+    X, pt, br, sc = sim.sample_density(t, 1000, alpha=al, beta=be, seed=11)
+    assert X.dtype == np.int64
+    for out, dtype in (("numpy32", np.int32), ("numpy16", np.uint16)):
+        np.random.set_state(state)
+        Y = sim.sample_density(t, 1000, alpha=al, beta=be, seed=11, out=out)[0]
+        assert Y.dtype == dtype and np.array_equal(Y, X)
+    for chunk in (1000, 333, 64, 5000):
+        np.random.set_state(state)
+        parts = list(sim.sample_density_chunks(t, 1000, chunk, alpha=al, beta=be, seed=11, out="numpy16"))
+        assert len(parts) == -(-1000 // chunk) and all(p[0].dtype == np.uint16 for p in parts)
+        assert np.array_equal(np.concatenate([p[0] for p in parts]), X)
+        assert np.array_equal(np.concatenate([p[1] for p in parts]), pt)
+        assert list(np.concatenate([p[2] for p in parts])) == list(br)
+        assert np.array_equal(np.concatenate([p[3] for p in parts]), sc)
+    assert list(sim.sample_density_chunks(t, 0, 10, alpha=al, beta=be, seed=1)) == []
+    # a count beyond 65 535 does not fit uint16
+    mu = np.full((4, 8), 3.0e5)
+    assert cm.sample_counts(mu, 0.01, 1.5, seed=3, out="numpy32").max() > 65535
+    with pytest.raises(OverflowError):
+        cm.sample_counts(mu, 0.01, 1.5, seed=3, out="numpy16")
+    # the domain check travels with the chunks
+    bad = {b: np.array(t.means[b]) for b in t.branches}
+    bad["B"][3, 5] = 0.0
+    t.means = bad
+    with pytest.raises(ValueError):
+        for _ in sim.sample_density_chunks(t, 2000, 500, alpha=al, beta=be, seed=11):
+            pass
+
+
 def test_max_attempts_guard():
     from prosstt_amd import simulation as sim
     from prosstt_amd import tree as ptree
