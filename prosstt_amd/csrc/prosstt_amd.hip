@@ -311,6 +311,96 @@ __global__ __launch_bounds__(256) void lineage_attempt_kernel(
     }
 }
 
+// The same for program matrices that fit the block's LDS (every benchmark configuration: K <= 32 and
+// max(T, 2 * common_j) * K <= kAttLdsDoubles): the attempt's programs are staged in LDS once per block (the kernel
+// above re-reads every program row from global memory for every dot product and runs at a tenth of the binary64
+// FMA rate), and every thread carries TWO genes, so that one broadcast LDS read of a program entry feeds two FMAs --
+// the ratio at which the LDS (256 B/clk/CU) keeps up with the four SIMDs' binary64 pipes.  Same operations in the same
+// order per gene as the kernel above: identical maxima and counts.
+constexpr int kAttLdsDoubles = 6144;      // 48 KB
+constexpr int kAttGenes = 128;            // genes per block: 64 lanes x 2
+
+__global__ __launch_bounds__(256) void lineage_attempt_lds_kernel(
+    const double* __restrict__ progs, const int32_t* __restrict__ meta, int32_t T, int32_t K,
+    const double* __restrict__ H, int64_t G, unsigned long long* __restrict__ max_bits,
+    unsigned long long* __restrict__ anticorr, int64_t attempt_stride, int32_t result_stride)
+{
+    extern __shared__ double buf[];                // max(T, 2 * common_j) * K doubles: sized by the launch
+    __shared__ double part[kLinChunks][kAttGenes][3];
+    progs += (int64_t)blockIdx.y * attempt_stride;
+    max_bits += (int64_t)blockIdx.y * result_stride;
+    anticorr += (int64_t)blockIdx.y * result_stride;
+    const int gl = threadIdx.x & 63, c = threadIdx.x >> 6;
+    const int64_t g0 = (int64_t)blockIdx.x * kAttGenes + gl, g1 = g0 + 64;
+    const bool live0 = g0 < G, live1 = g1 < G;
+    const double* h0 = H + (live0 ? g0 : 0);
+    const double* h1 = H + (live1 ? g1 : 0);
+    const int n_sib = meta[0];
+    double a0[32], a1[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        a0[k] = k < K ? h0[(int64_t)k * G] : 0.0;
+        a1[k] = k < K ? h1[(int64_t)k * G] : 0.0;
+    }
+    auto dot2 = [&](const double* row, double& x0, double& x1) {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+            if (k < K) {
+                const double p = row[k];
+                s0 = fma(p, a0[k], s0);
+                s1 = fma(p, a1[k], s1);
+            }
+        x0 = s0;
+        x1 = s1;
+    };
+    auto stage = [&](const double* src, int doubles) {
+        __syncthreads();                               // (the previous phase has finished with buf)
+        for (int i = threadIdx.x; i < doubles; i += 256) buf[i] = src[i];
+        __syncthreads();
+    };
+
+    stage(progs, T * K);
+    double mx = -std::numeric_limits<double>::infinity();
+    for (int t = (c * T) / kLinChunks; t < ((c + 1) * T) / kLinChunks; ++t) {
+        double x0, x1;
+        dot2(buf + t * K, x0, x1);
+        if (live0) mx = fmax(mx, x0);
+        if (live1) mx = fmax(mx, x1);
+    }
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
+    if (gl == 0) atomicMax(max_bits, ordered_bits(mx));
+
+    const double* blk = progs + (int64_t)T * K;
+    for (int j = 0; j < n_sib; ++j) {
+        const int common = meta[1 + j];
+        stage(blk, 2 * common * K);
+        blk += 2 * (int64_t)common * K;
+        const double* pc = buf;
+        const double* ps = buf + common * K;
+        double cov0 = 0.0, vx0 = 0.0, vy0 = 0.0, cov1 = 0.0, vx1 = 0.0, vy1 = 0.0;
+        for (int t = (c * common) / kLinChunks; t < ((c + 1) * common) / kLinChunks; ++t) {
+            double x0, x1, y0, y1;
+            dot2(pc + t * K, x0, x1);
+            dot2(ps + t * K, y0, y1);
+            cov0 = fma(x0, y0, cov0); vx0 = fma(x0, x0, vx0); vy0 = fma(y0, y0, vy0);
+            cov1 = fma(x1, y1, cov1); vx1 = fma(x1, x1, vx1); vy1 = fma(y1, y1, vy1);
+        }
+        part[c][gl][0] = cov0; part[c][gl][1] = vx0; part[c][gl][2] = vy0;
+        part[c][gl + 64][0] = cov1; part[c][gl + 64][1] = vx1; part[c][gl + 64][2] = vy1;
+        __syncthreads();
+        if (c < 2) {                                   // wave 0 sums up the block's first 64 genes, wave 1 the other 64
+            const int gi = gl + 64 * c;
+            double cov = part[0][gi][0], vx = part[0][gi][1], vy = part[0][gi][2];
+            for (int o = 1; o < kLinChunks; ++o) { cov += part[o][gi][0]; vx += part[o][gi][1]; vy += part[o][gi][2]; }
+            // Pearson r < 0  <=>  cov < 0 with both series non-constant (scipy returns NaN otherwise)
+            const bool neg = (c == 0 ? live0 : live1) && cov < 0.0 && vx > 0.0 && vy > 0.0;
+            const unsigned long long votes = __ballot(neg);
+            if (gl == 0 && votes) atomicAdd(&anticorr[j], (unsigned long long)__popcll(votes));
+        }
+    }
+}
+
 // K1: one lane per expression program, T sequential steps (walk definition PRLW-1)
 __global__ void lineage_walk_kernel(uint32_t k0, uint32_t k1, uint32_t sid_lo, uint32_t sid_hi, int32_t T,
                                     int32_t K, double* out)
@@ -965,7 +1055,13 @@ PA_EXPORT int prosstt_amd_lineage_attempt_batch(prosstt_amd_ctx* c, const double
     HIP_TRY(hipMemcpyAsync(d_meta, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(d_res, 0, res_bytes, c->stream));   // ordered_bits(x) > 0 for every x
     const dim3 grid((unsigned)((G + 63) / 64), (unsigned)B);
-    if (K <= 32)
+    int64_t lds_need = (int64_t)T * K;
+    for (int j = 0; j < n_sib; ++j) lds_need = lds_need > 2 * (int64_t)meta[1 + j] * K ? lds_need : 2 * (int64_t)meta[1 + j] * K;
+    if (K <= 32 && lds_need <= kAttLdsDoubles)
+        lineage_attempt_lds_kernel<<<dim3((unsigned)((G + kAttGenes - 1) / kAttGenes), (unsigned)B), dim3(256),
+                                     (size_t)lds_need * 8, c->stream>>>(
+            d_prog, d_meta, T, K, H, G, d_res, d_res + 1, (int64_t)per, words);
+    else if (K <= 32)
         lineage_attempt_kernel<true><<<grid, dim3(256), 0, c->stream>>>(d_prog, d_meta, T, K, H, G, d_res, d_res + 1,
                                                                        (int64_t)per, words);
     else

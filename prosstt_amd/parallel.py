@@ -86,7 +86,7 @@ def assign_branches_by_density(tree, world_size):
 
 
 def simulate_lineage_sharded(tree, rel_exp_cutoff=8, intra_branch_tol=0.5, inter_branch_tol=0, *, group=None,
-                             max_attempts=None, stats=None, batch=16, **kwargs):
+                             max_attempts=None, stats=None, batch=16, keep_on_device=False, **kwargs):
     """``simulation.simulate_lineage`` (simulation.py:215-286) by the ranks of ``group`` together.
 
     Every rank makes the same host draws (seed numpy identically); a batch of attempts is evaluated on the
@@ -105,7 +105,8 @@ def simulate_lineage_sharded(tree, rel_exp_cutoff=8, intra_branch_tol=0.5, inter
     rank, size = world(group)
     if size == 1:
         return sim.simulate_lineage(tree, rel_exp_cutoff, intra_branch_tol, inter_branch_tol,
-                                    max_attempts=max_attempts, stats=stats, batch=batch, **kwargs)
+                                    max_attempts=max_attempts, stats=stats, batch=batch, keep_on_device=keep_on_device,
+                                    **kwargs)
     if not len(tree.time) == tree.num_branches:
         raise ValueError("the parameters are not enough for %i branches" % tree.num_branches)
     ctx = _device.get_context()
@@ -147,7 +148,7 @@ def simulate_lineage_sharded(tree, rel_exp_cutoff=8, intra_branch_tol=0.5, inter
     g_all = gene_max.to(dev)
     dist.all_reduce(g_all, op=dist.ReduceOp.MAX, group=group)
     gene_max = g_all.to(ctx.torch_device)
-    return sim._finish_lineage(tree, rel, gene_max, H, programs, offsets, coefficients)
+    return sim._finish_lineage(tree, rel, gene_max, H, programs, offsets, coefficients, keep_on_device)
 
 
 def cells_of_rank(branch_of_cell, owner, rank):

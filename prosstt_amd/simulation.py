@@ -208,7 +208,7 @@ def _device_gene_max(tree, relative_means):
 
 
 def simulate_lineage(tree, rel_exp_cutoff=8, intra_branch_tol=0.5, inter_branch_tol=0,
-                     *, max_attempts=None, stats=None, rng="numpy", seed=None, batch=16, **kwargs):
+                     *, max_attempts=None, stats=None, rng="numpy", seed=None, batch=16, keep_on_device=False, **kwargs):
     """Relative mean expression of every gene at every point of the tree
     (simulation.py:215-286).
 
@@ -226,7 +226,10 @@ def simulate_lineage(tree, rel_exp_cutoff=8, intra_branch_tol=0.5, inter_branch_
     ``(branch, max, [anticorrelated counts])`` record per attempt; ``rng="device"``
     draws the random walks on the device (``lineage_walk`` kernel, one lane per program,
     Philox streams keyed by ``seed``, branch and attempt) instead of numpy's global stream --
-    same walk law, different numbers (``seed`` defaults to two draws of numpy's stream).
+    same walk law, different numbers (``seed`` defaults to two draws of numpy's stream);
+    ``keep_on_device=True`` returns handles of the relative means (``DeviceRows``) instead of copying the
+    (sum T_b, G) binary64 matrix to the host -- 3 GB at 256 branches x 30 000 genes -- which
+    ``simulate_base_gene_exp`` and ``Tree.add_genes`` accept as they accept the arrays.
     """
     import torch
     if not len(tree.time) == tree.num_branches:
@@ -248,7 +251,7 @@ def simulate_lineage(tree, rel_exp_cutoff=8, intra_branch_tol=0.5, inter_branch_
 
     programs = _lineage_loop(tree, ctx, evaluate, commit, rel_exp_cutoff, intra_branch_tol, inter_branch_tol,
                              max_attempts, stats, rng, seed, batch)
-    return _finish_lineage(tree, rel, gene_max, H, programs, offsets, coefficients)
+    return _finish_lineage(tree, rel, gene_max, H, programs, offsets, coefficients, keep_on_device)
 
 
 def _lineage_loop(tree, ctx, evaluate, commit, rel_exp_cutoff, intra_branch_tol, inter_branch_tol,
@@ -325,13 +328,39 @@ def _lineage_loop(tree, ctx, evaluate, commit, rel_exp_cutoff, intra_branch_tol,
     return programs
 
 
-def _finish_lineage(tree, rel, gene_max, H, programs, offsets, coefficients):
-    """Host copies of the resident branches' relative means, the device cache, the reference's return value."""
-    host = rel.cpu().numpy()
+class DeviceRows:
+    """The relative means of one branch, left on the device (``simulate_lineage(..., keep_on_device=True)``):
+    ``simulate_base_gene_exp`` and ``Tree.add_genes`` take it as they take the host array; ``np.asarray`` of it
+    (or indexing) copies the branch's (T_b, G) rows to the host on demand."""
+
+    def __init__(self, rel, first_row, steps):
+        self._rel, self._at, self._steps = rel, int(first_row), int(steps)
+        self.shape = (int(steps), int(rel.shape[1]))
+        self.dtype = np.dtype(np.float64)
+        self.ndim = 2
+
+    def __array__(self, dtype=None, copy=None):
+        host = self._rel[self._at:self._at + self._steps].cpu().numpy()
+        return host if dtype is None else host.astype(dtype, copy=False)
+
+    def __getitem__(self, index):
+        return np.asarray(self)[index]
+
+    def __len__(self):
+        return self._steps
+
+
+def _finish_lineage(tree, rel, gene_max, H, programs, offsets, coefficients, keep_on_device=False):
+    """Host copies of the resident branches' relative means (or handles of their device rows), the device cache,
+    the reference's return value."""
+    held = tree.resident_branches()
+    if keep_on_device:
+        rel_means = {b: DeviceRows(rel, offsets[b], tree.time[b]) for b in held}
+    else:
+        host = rel.cpu().numpy()
+        rel_means = {b: host[offsets[b]:offsets[b] + int(tree.time[b])] for b in held}
     # the device keeps `rel` for simulate_base_gene_exp / add_genes, which recognise these arrays by
     # identity and fingerprint: writable like the reference's; edited arrays are uploaded afresh
-    held = tree.resident_branches()
-    rel_means = {b: host[offsets[b]:offsets[b] + int(tree.time[b])] for b in held}
     tree._lineage = dict(rel=rel, gene_max=gene_max, host=rel_means, H=H,
                          print=_device.host_fingerprint([rel_means[b] for b in held]))
     ordered = {}

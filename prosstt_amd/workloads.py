@@ -94,10 +94,11 @@ def build(name, *, a=0.05, rel_exp_cutoff=8, max_attempts=20000, G=None, verbose
         sharded = parallel.world(group)[1] > 1
     if sharded:
         rel, _, _ = parallel.simulate_lineage_sharded(tree, rel_exp_cutoff, 0, 0, group=group, a=a,
-                                                      max_attempts=max_attempts, stats=stats)
+                                                      max_attempts=max_attempts, stats=stats, keep_on_device=True)
     else:
         rel, _, _ = sim.simulate_lineage(tree, a=a, intra_branch_tol=0, inter_branch_tol=0,
-                                         rel_exp_cutoff=rel_exp_cutoff, max_attempts=max_attempts, stats=stats)
+                                         rel_exp_cutoff=rel_exp_cutoff, max_attempts=max_attempts, stats=stats,
+                                         keep_on_device=True)       # (3 GB of binary64 at C5 stay where add_genes reads them)
     t1 = _time.perf_counter()
     base = sut.simulate_base_gene_exp(tree, rel)
     tree.add_genes(rel, base)
