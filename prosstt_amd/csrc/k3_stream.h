@@ -110,7 +110,6 @@ struct WaveLds {
     S1Entry s1[kS1Cap];
     S2Entry s2[kS2Cap];
     uint32_t s2p[kS2Cap];          // pos of the S2 entries
-    uint8_t ring[kRing * 256];     // [row slot][gene-in-tile]; a count of 256 or more is left to K3h
     uint32_t late[kLateCap];       // (pos << 16) | count of results whose row has left the ring already
 };
 
@@ -142,6 +141,9 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
     __shared__ __attribute__((aligned(16))) float inv_k_store[4 + kInvTab];
     float* const inv_k = inv_k_store + 4;
     __shared__ WaveLds lds_all[kBlock / 64];
+    // the row rings, [wave][row slot][gene-in-tile] (8 bits per count), each aligned to its own size: a delivery's LDS
+    // address is then (pos AND (size - 1)) OR base -- one instruction
+    __shared__ __attribute__((aligned(kRing * 256))) uint8_t ring_all[kBlock / 64][kRing * 256];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -200,7 +202,8 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
     const uint32_t ld32 = (uint32_t)ld;              // strip rows * ld * 4 < 2^31, checked by the host
     // pos of the last sample whose row has already left the ring (wave-uniform; -1: none)
     int32_t flushed_pos = -1;
-    for (int i = lane; i < kRing * 64; i += 64) reinterpret_cast<uint32_t*>(L.ring)[i] = 0u;
+    uint8_t* const ring = ring_all[wv];
+    for (int i = lane; i < kRing * 64; i += 64) reinterpret_cast<uint32_t*>(ring)[i] = 0u;
     if (lane < 4) reinterpret_cast<uint32_t*>(&L.s1_null)[lane] = 0u;
 
     // Rows are stored through a buffer resource over the strip's part of the matrix: the row is the scalar offset,
@@ -212,9 +215,8 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
 
     // store row `cl` of the strip from ring slot cl % kRing and clear the slot
     auto flush_row = [&](int cl) {
-        uint32_t* slot = reinterpret_cast<uint32_t*>(L.ring + (cl & (kRing - 1)) * 256) + lane;
-        const uint32_t packed = *slot;
-        *slot = 0u;
+        uint32_t* slot = reinterpret_cast<uint32_t*>(ring + (cl & (kRing - 1)) * 256) + lane;
+        const uint32_t packed = __hip_atomic_exchange(slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // read and clear: one ds_wrxchg_rtn_b32
         const int32_t v[4] = {(int32_t)(packed & 0xffu), (int32_t)((packed >> 8) & 0xffu),
                               (int32_t)((packed >> 16) & 0xffu), (int32_t)(packed >> 24)};
         if (VEC) {
@@ -250,7 +252,9 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
     // (Wave-level tests are written on 64-bit lane masks, each the SGPR result of ONE compare taken
     // outside divergent control flow; masks are combined on the scalar unit and applied as exec.)
 #define K3_MASK(x) __builtin_amdgcn_ballot_w64(x)
-    const uint32_t ring_lds = (uint32_t)(uintptr_t)&L.ring[0];
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)&ring[0];
+    uint32_t ring_mask = (uint32_t)(kRing * 256 - 1);
+    asm volatile("" : "+v"(ring_mask));            // (a register: v_and_or_b32 takes one scalar operand, the base)
     const uint32_t late_lds = (uint32_t)(uintptr_t)&L.late[0];
     // write the samples the lanes hold for K3h to this wave's region of the list (about ten entries
     // each time on the headline workload: the first lane to meet its second sample triggers it)
@@ -272,8 +276,9 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
     auto deliver = [&](unsigned long long ok_m, unsigned long long give_m, uint32_t p, uint32_t res) {
         const unsigned long long late_m = K3_MASK((int32_t)p <= flushed_pos);
         // slot = cell % kRing, gene-in-tile
-        asm volatile("s_mov_b64 exec, %0\n\tds_write_b8 %1, %2\n\ts_mov_b64 exec, -1"
-                     :: "s"(ok_m & ~late_m), "v"(ring_lds + (p & (uint32_t)(kRing * 256 - 1))), "v"(res) : "memory");
+        uint32_t ring_at;
+        asm volatile("v_and_or_b32 %0, %2, %3, %4\n\ts_mov_b64 exec, %1\n\tds_write_b8 %0, %5\n\ts_mov_b64 exec, -1"
+                     : "=&v"(ring_at) : "s"(ok_m & ~late_m), "v"(p), "v"(ring_mask), "s"(ring_lds), "v"(res) : "memory");
         const unsigned long long ml = ok_m & late_m;
         if ((ml | give_m) != 0ull) {
             if (ml != 0ull) {

@@ -148,6 +148,42 @@ VARIANTS = {
                   ("        const unsigned long long ml = ok_m & late_m;\n", "        const unsigned long long ml = ok_m & late_m;\n        deliv_total += __popcll(ok_m);\n"),
                   ("    flush_late();\n    if (__builtin_amdgcn_ballot_w64(hpend != kNoHeavy) != 0ull) flush_heavy();",
                    "    flush_late();\n    if (lane == 0 && (region % 4093u) == 7u) printf(\"LATE region %u cells %d delivered %d late %d listed %u\\n\", region, cells, deliv_total, late_total, h_cnt);\n    if (__builtin_amdgcn_ballot_w64(hpend != kNoHeavy) != 0ull) flush_heavy();")],
+    # round 4 (real variants): how many waves a small problem is cut into (strips are halved while there are fewer)
+    "minwaves10k": [("* g.tiles_g < 4 * 5 * 1024) g.strip_cells /= 2;", "* g.tiles_g < 2 * 5 * 1024) g.strip_cells /= 2;")],
+    "minwaves5k": [("* g.tiles_g < 4 * 5 * 1024) g.strip_cells /= 2;", "* g.tiles_g < 5 * 1024) g.strip_cells /= 2;")],
+    "minwaves40k": [("* g.tiles_g < 4 * 5 * 1024) g.strip_cells /= 2;", "* g.tiles_g < 8 * 5 * 1024) g.strip_cells /= 2;"), ("g.strip_cells > 8 &&", "g.strip_cells > 4 &&")],
+    # round 4 (real variant): the next cell's mean segment AND record loaded mid-pass into the registers this pass has finished
+    # with (no rotation at all: ten instructions fewer per pass, one pass of prefetch distance instead of two)
+    "inplace_all": [
+        ("""        const Seg nn = load_seg(row2);
+        const uint64_t row3 = cinfo[3].row_bytes;
+        const float s_next = cinfo[1].s;
+        const uint32_t posbase_next = cinfo[1].pos_base;
+        const uint32_t ph_next[4] = {cinfo[1].ph[0], cinfo[1].ph[1], cinfo[1].ph[2], cinfo[1].ph[3]};
+        ++cinfo;
+        __builtin_amdgcn_sched_barrier(0);
+        const prnb::Words W = philox_count_row(ph, quad_hi, quad_lo, k0, k1);
+        const uint32_t pos4 = posbase | lane4;
+""", """        const prnb::Words W = philox_count_row(ph, quad_hi, quad_lo, k0, k1);
+        const uint32_t pos4 = posbase | lane4;
+        __builtin_amdgcn_sched_barrier(0);
+        cur = load_seg(row2);
+        row2 = cinfo[2].row_bytes;
+        s = cinfo[1].s; posbase = cinfo[1].pos_base;
+        ph[0] = cinfo[1].ph[0]; ph[1] = cinfo[1].ph[1]; ph[2] = cinfo[1].ph[2]; ph[3] = cinfo[1].ph[3];
+        ++cinfo;
+        __builtin_amdgcn_sched_barrier(0);
+"""),
+        ("""        cur = nxt;
+        nxt = nn;
+        row2 = row3;
+        s = s_next;
+        ph[0] = ph_next[0]; ph[1] = ph_next[1]; ph[2] = ph_next[2]; ph[3] = ph_next[3];
+        posbase = posbase_next;
+""", ""),
+        ("    Seg cur = load_seg(cinfo[0].row_bytes), nxt = load_seg(cinfo[1].row_bytes);\n    uint64_t row2 = cinfo[2].row_bytes;",
+         "    Seg cur = load_seg(cinfo[0].row_bytes);\n    uint64_t row2 = cinfo[1].row_bytes;"),
+    ],
     # mean segments one cell ahead, requested at the END of a pass (one register rotation; the row store gets a whole pass before anything waits behind it)
     "pf1": [("        const Seg nn = load_seg(row2);\n        const uint64_t row3 = cinfo[3].row_bytes;",
              "        const uint64_t row3 = cinfo[3].row_bytes;"),
