@@ -349,16 +349,18 @@ def time_gather(job, res, out, mine):
     Bounded so that root's copy of the whole matrix plus its own shard stays far inside 288 GB."""
     from prosstt_amd import parallel
     n_total, G = res["n_total"], res["G"]
-    if job.world == 1 or 4 * n_total * G > 64e9:
+    to_host = job.args.gather_to == "host"
+    if job.world == 1 or (4 * n_total * G > 64e9 and not to_host):
         return
     small = min(64, len(mine))
     parallel.gather_rows(out[:small], mine[:small], n_total)        # connections come up outside the timed region
     job.fence()
     if job.backend == "nccl":
         t0 = time.perf_counter()
-        full = parallel.gather_rows(out, mine, n_total)
+        full = parallel.gather_rows(out, mine, n_total, to_host=to_host)
         job.fence()
         res["gather_ms"] = job.max_over_ranks(time.perf_counter() - t0) * 1e3
+        res["gather_to"] = job.args.gather_to
         del full
     else:
         # functional run on another backend (gloo stages device tensors through the host at ~25 MB/s):
@@ -388,6 +390,9 @@ def main():
                     help="with N > 1: configurations also run at their own cell count split over the GPUs "
                          "(reported under 'strong_scaling'; '' = none)")
     ap.add_argument("--no-gather", action="store_true", help="do not time the row gather to rank 0 (N > 1)")
+    ap.add_argument("--gather-to", default="device", choices=["device", "host"],
+                    help="where rank 0 assembles the gathered matrix: its device (default; skipped beyond 64 GB) or "
+                         "page-locked host memory (any size: C5's 120 GB of counts)")
     ap.add_argument("--ramp-ms", type=float, default=400.0,
                     help="untimed passes of the step for this long before the W warmup steps (device clock ramp; 0 = none)")
     ap.add_argument("--fail-on-extras-error", action="store_true",
@@ -544,8 +549,14 @@ def assemble_line(args, job, main_case, strong, end_to_end, extras_error):
                              "ranks); frac_whole_step prices them against ms_per_step (K3h, prep kernels, gaps). "
                              "VALU-issue-bound sampler: DESIGN.md section 6 and profiles/"},
     }
+    if world > 1:
+        line["scaling_note"] = ("value is the WEAK figure (the C3 cell count on every GPU): value(N) / value(1) is the "
+                                "weak-scaling factor; BASELINE.json's '>= 6x at 8 GPUs' for its 32-branch configuration "
+                                "is strong_scaling[config C4].value / the 1-GPU C4 rate (python bench.py --config C4), "
+                                "sampling only -- gather_ms is the one exchange on top")
     if main_case["gather_ms"] is not None:
         line["gather_ms"] = main_case["gather_ms"]
+        line["gather_to"] = main_case.get("gather_to", "device")
     if "gather_rows_functional" in main_case:
         line["gather_ms"] = None
         line["gather_note"] = "backend %s: gather exercised on %d rows per rank, not timed" % (job.backend, main_case["gather_rows_functional"])

@@ -271,7 +271,8 @@ def sample_density_sharded(tree, no_cells, alpha=0.3, beta=2, scale=True, scale_
     return counts, mine, pt, br, sc
 
 
-def gather_rows(local_rows, cell_index, total_rows, group=None, dst=0, chunk_rows=None, chunk_bytes=256 << 20):
+def gather_rows(local_rows, cell_index, total_rows, group=None, dst=0, chunk_rows=None, chunk_bytes=256 << 20,
+                to_host=False):
     """Collect row shards on rank ``dst`` (a rank of ``group``) into a (total_rows, G) tensor in global order.
 
     ``local_rows`` (n_local, G) and ``cell_index`` (n_local,) of every rank; returns the full
@@ -280,13 +281,33 @@ def gather_rows(local_rows, cell_index, total_rows, group=None, dst=0, chunk_row
     sender, so the root stages 2 rounds x (size - 1) x 256 MB whatever G is): the root posts the
     receives of a round from ALL senders at once (``batch_isend_irecv``: every xGMI link of the root
     carries data at the same time) and scatters round r with ``index_copy_`` while round r + 1 is in
-    flight.  A rank may own no rows."""
+    flight.  A rank may own no rows.
+
+    ``to_host=True``: the full matrix is assembled in HOST memory on ``dst`` (page-locked when the allocator
+    grants it) and returned as an ndarray -- the root then stages only the rounds in flight on its device, so a
+    result larger than one GPU's memory (C5: 120 GB of int32 counts) still has somewhere to go."""
     import torch
     dist = _dist()
     rank, size = world(group)
     index = torch.as_tensor(np.asarray(cell_index), dtype=torch.int64, device=local_rows.device)
     G = local_rows.shape[1]
+    def host_matrix():
+        try:
+            return torch.empty((total_rows, G), dtype=local_rows.dtype, pin_memory=True)
+        except RuntimeError:
+            return torch.empty((total_rows, G), dtype=local_rows.dtype)
+
+    def scatter_to_host(host, idx, buf, step=1 << 16):
+        """host[idx] = buf, a bounded piece at a time (the device-to-host copy of a piece, then the row scatter)."""
+        idx_h = idx.cpu()
+        for lo in range(0, buf.shape[0], step):
+            host.index_copy_(0, idx_h[lo:lo + step], buf[lo:lo + step].cpu())
+
     if size == 1:
+        if to_host:
+            host = host_matrix()
+            scatter_to_host(host, index, local_rows)
+            return host.numpy()
         out = torch.empty((total_rows, G), dtype=local_rows.dtype, device=local_rows.device)
         out.index_copy_(0, index, local_rows)
         return out
@@ -310,8 +331,12 @@ def gather_rows(local_rows, cell_index, total_rows, group=None, dst=0, chunk_row
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
         return None
-    out = torch.empty((total_rows, G), dtype=local_rows.dtype, device=local_rows.device)
-    out.index_copy_(0, index, local_rows)
+    if to_host:
+        out = host_matrix()
+        scatter_to_host(out, index, local_rows)
+    else:
+        out = torch.empty((total_rows, G), dtype=local_rows.dtype, device=local_rows.device)
+        out.index_copy_(0, index, local_rows)
 
     def post(r):
         """Receives of round r from every sender that still has rows: [(idx, buf)], requests."""
@@ -333,5 +358,8 @@ def gather_rows(local_rows, cell_index, total_rows, group=None, dst=0, chunk_row
             req.wait()
         pending = post(r + 1) if r + 1 < rounds else ([], [])
         for idx, buf in bufs:
-            out.index_copy_(0, idx, buf)
-    return out
+            if to_host:
+                scatter_to_host(out, idx, buf)
+            else:
+                out.index_copy_(0, idx, buf)
+    return out.numpy() if to_host else out

@@ -229,6 +229,29 @@ def test_deferred_domain_check_and_cached_row_flags(ctx):
         ctx.sample_counts(means, roc, sc, al, be, seed=3, check_domain=True)
 
 
+def test_corner_of_the_inversion_class_long_walks(ctx):
+    """5e7 samples at the corner of the inversion class -- theta about 14.8, mean about 101, tail ratio 0.937: the
+    longest walks the class has (hundreds of terms; round 3's definition let such walks run past the 1/k table).
+    Counts equal the model's one for one; nothing above the walk's end; first two moments hold."""
+    from oracle import nb_model
+    rng = np.random.default_rng(8)
+    G, N = 20000, 2500
+    means = (101.0 * np.exp(rng.normal(0, 0.03, (4, G)))).astype(np.float32)
+    roc = rng.integers(0, 4, N).astype(np.int32)
+    sc = np.exp(rng.normal(0, 0.02, N))
+    al = np.full(G, 13.8 / 101.0)
+    be = np.full(G, 2.0)
+    got = ctx.sample_counts(means, roc, sc, al, be, seed=2024).cpu().numpy()
+    want = nb_model.sample_counts(means, roc, sc, al, be, 2024)
+    np.testing.assert_array_equal(got, want)
+    path = nb_model.nb_params(means[:, :64], roc[:50], sc[:50], al[:64], be[:64])[3]
+    assert (path == 1).mean() > 0.5                      # the inversion class, mostly (t is just under 19 around m = 101)
+    mu = means[roc].astype(np.float64) * sc[:, None]
+    var = al * mu * mu + be * mu
+    assert abs(got.sum() / mu.sum() - 1) < 5 * np.sqrt(var.sum()) / mu.sum()
+    assert got.max() < 3000 and got.min() >= 0
+
+
 def test_empty_inputs(ctx):
     means = np.ones((3, 16), np.float32)
     out = ctx.sample_counts(means, np.zeros(0, np.int32), np.zeros(0), np.full(16, 0.2), np.full(16, 2.0), seed=3)

@@ -1,0 +1,62 @@
+"""
+CPU: the scalar model of the count sampler under AddressSanitizer / UBSan at the corner of the inversion class
+(theta = 16, -log P(X = 0) just under 19: means around 107, tail ratio 16/17), where walks are longest.  Round 3's
+definition let a walk run past its 1/k table there (a read beyond the table in the model, beyond the LDS copy on the
+device); PRNB-5 ends every walk at k = 1022 and the table covers it.  The driver below is compiled together with
+oracle/nb_model.c (no GPU: the libm stand-ins of the three hardware functions).
+"""
+import os
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+DRIVER = r"""
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+void prnb_sample_iid(float m, double a, double b, uint64_t seed, uint64_t first_cell, uint32_t gene, int64_t n, int32_t* out);
+int main(void)
+{
+    const int64_t n = 400000;
+    int32_t* out = malloc(sizeof(int32_t) * n);
+    /* (m, alpha, beta): theta = alpha*m + beta - 1 */
+    const double cases[][3] = {{101.0, 0.1366, 2.0}, {100.0, 0.14, 2.0}, {107.0, 0.1402, 2.0}, {106.9, 0.0, 17.0},
+                               {60.0, 0.25, 2.0}, {18.9, 0.0, 1.00000001}, {90.0, 0.1, 3.0}};
+    long worst = 0;
+    for (unsigned c = 0; c < sizeof(cases) / sizeof(cases[0]); ++c) {
+        prnb_sample_iid((float)cases[c][0], cases[c][1], cases[c][2], 77 + c, 1000000ull * c, c, n, out);
+        double sum = 0;
+        for (int64_t i = 0; i < n; ++i) { sum += out[i]; if (out[i] > worst) worst = out[i]; if (out[i] < 0) return 3; }
+        printf("case %u: mean %.3f (m = %.1f)\n", c, sum / n, cases[c][0]);
+        if (sum / n < 0.97 * cases[c][0] || sum / n > 1.03 * cases[c][0]) return 2;
+    }
+    printf("largest count %ld\n", worst);
+    free(out);
+    return worst > 100000 ? 4 : 0;
+}
+"""
+
+
+def test_model_walks_stay_inside_their_table_under_asan():
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    tmp = tempfile.mkdtemp(prefix="prnb_asan_")
+    try:
+        open(os.path.join(tmp, "driver.c"), "w").write(DRIVER)
+        exe = os.path.join(tmp, "driver")
+        build = subprocess.run([gcc, "-O1", "-g", "-ffp-contract=off", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                                "-fvisibility=default", "-o", exe, os.path.join(tmp, "driver.c"),
+                                os.path.join(ROOT, "oracle", "nb_model.c"), "-lm"], capture_output=True, text=True)
+        if build.returncode != 0 and "sanitize" in build.stderr:
+            pytest.skip("this gcc has no sanitizer runtime")
+        assert build.returncode == 0, build.stderr[-2000:]
+        run = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, OMP_NUM_THREADS="2", ASAN_OPTIONS="detect_leaks=0"))
+        assert run.returncode == 0, (run.stdout + run.stderr)[-3000:]
+        assert "largest count" in run.stdout
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)

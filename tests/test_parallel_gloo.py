@@ -161,6 +161,12 @@ def _worker_sharded(rank, world_size, port, tmpdir, same_seed):
             assert full is None
         other = parallel.gather_rows(counts, mine, N, dst=1, chunk_rows=1000)      # another root, one round
         assert (other is not None) == (rank == 1)
+        # the same gather assembled in host memory on the root (a result too large for one device)
+        on_host = parallel.gather_rows(counts, mine, N, chunk_rows=16, to_host=True)
+        if rank == 0:
+            assert isinstance(on_host, np.ndarray) and np.array_equal(on_host, want.numpy())
+        else:
+            assert on_host is None
         dist.barrier()
         open(os.path.join(tmpdir, "ok%d" % rank), "w").write("ok")
     finally:
