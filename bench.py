@@ -539,6 +539,7 @@ def assemble_line(args, job, main_case, strong, end_to_end, extras_error):
                    "lineage_attempts": work.info["attempts"], "lineage_s": round(work.info["lineage_s"], 3),
                    "lineage_sharded_by_genes": bool(work.info["sharded"]),
                    "clock_ramp": "%d untimed passes (%.0f ms) before the %d warmup steps" % (main_case["ramp_calls"], args.ramp_ms, args.warmup),
+                   "cold_steps": 5,
                    "sum_counts_over_sum_means": round(main_case["ratio"], 5)},
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,

@@ -184,6 +184,15 @@ VARIANTS = {
         ("    Seg cur = load_seg(cinfo[0].row_bytes), nxt = load_seg(cinfo[1].row_bytes);\n    uint64_t row2 = cinfo[2].row_bytes;",
          "    Seg cur = load_seg(cinfo[0].row_bytes);\n    uint64_t row2 = cinfo[1].row_bytes;"),
     ],
+    # round 4 (real variant): logical block index = transpose of the hardware's round-robin over the 8 XCDs (one XCD's blocks
+    # cover a contiguous eighth of the gene tiles: a tile's slice of the mean tensor in one L2 instead of eight)
+    "xcd_transpose": [
+        ("    const int32_t tile_g = blockIdx.x / groups;\n    const int32_t strip = (blockIdx.x - tile_g * groups) * 4 + wv;",
+         "    const uint32_t per_xcd = gridDim.x >> 3;\n"
+         "    const uint32_t blk = blockIdx.x < (per_xcd << 3) ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;\n"
+         "    const int32_t tile_g = (int32_t)blk / groups;\n    const int32_t strip = ((int32_t)blk - tile_g * groups) * 4 + wv;"),
+        ("    const uint32_t region = blockIdx.x * 4u + (uint32_t)wv;", "    const uint32_t region = blk * 4u + (uint32_t)wv;"),
+    ],
     # mean segments one cell ahead, requested at the END of a pass (one register rotation; the row store gets a whole pass before anything waits behind it)
     "pf1": [("        const Seg nn = load_seg(row2);\n        const uint64_t row3 = cinfo[3].row_bytes;",
              "        const uint64_t row3 = cinfo[3].row_bytes;"),

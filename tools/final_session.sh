@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box: the round's closing measurements.  usage: tools/final_session.sh <tag>
-TAG=${1:-r03}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final_$TAG; mkdir -p $O; cd $R
+TAG=${1:-r04}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final_$TAG; mkdir -p $O; cd $R
 timeout 1800 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
 timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 bash tools/profile_bench.sh $TAG > /dev/null 2>&1; grep "under the tracer\|derived" -A2 gpurun_out/prof_$TAG/summary.txt | cut -c1-300

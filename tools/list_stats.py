@@ -13,6 +13,7 @@ sys.path.insert(0, ROOT)
 def main():
     from prosstt_amd import device, workloads
     from oracle import nb_model
+    nb_model.install_hw_tables_from_device()
     cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
     ctx = device.get_context()
     work = workloads.build(cfg)
@@ -21,18 +22,16 @@ def main():
     means = work.tree.device_means()
     X = ctx.sample_counts(means, rows, sc, work.alpha, work.beta, seed=424242)
     cells, genes, total, over = ctx.last_list(cap=1 << 25)
-    margins = (4096.0, 8192.0, 2048.0)
-    path, count, t2, close, tail = nb_model.walk_detail(means.cpu().numpy(), rows, sc, work.alpha, work.beta, 424242,
-                                                        cells, genes, margins)
+    path, count = nb_model.sample_selected(means.cpu().numpy(), rows, sc, work.alpha, work.beta, 424242, cells, genes)
     heavy = path == 2
-    near = (path == 1) & (close < 1.5)
-    rest = (path == 1) & ~near
+    big = (path == 1) & (count > 254)
+    rest = (path == 1) & ~big
     samples = N * work.tree.G
-    print("%s %d x %d: %d listed (%.3f %% of the samples, overflowed %s): gamma-Poisson %d, near a threshold %d "
-          "(mean count %.1f), other (unfinished, > 255, tail band) %d (mean count %.1f, max %d); mean count of the matrix %.2f"
-          % (cfg, N, work.tree.G, total, 100.0 * total / samples, over, heavy.sum(), near.sum(),
-             count[near].mean() if near.any() else 0, rest.sum(), count[rest].mean() if rest.any() else 0,
-             count[rest].max() if rest.any() else 0, float(X[:4096].double().mean())))
+    print("%s %d x %d: %d listed (%.3f %% of the samples, overflowed %s): gamma-Poisson %d, walks past k = 254: %d, "
+          "unfinished at the end of their strip %d (mean count %.1f, max %d); mean count of the matrix %.2f"
+          % (cfg, N, work.tree.G, total, 100.0 * total / samples, over, heavy.sum(), big.sum(), rest.sum(),
+             count[rest].mean() if rest.any() else 0, count[rest].max() if rest.any() else 0,
+             float(X[:4096].double().mean())))
     q = np.percentile(count[rest], [50, 90, 99]) if rest.any() else [0, 0, 0]
     print("   unfinished walks: count percentiles 50/90/99 = %d/%d/%d" % tuple(q))
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box: rocprofv3 kernel trace + PMC passes of the default bench command.
 # usage: tools/profile_bench.sh <tag>     (summaries land in gpurun_out/prof_<tag>/)
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O

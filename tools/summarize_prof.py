@@ -22,7 +22,7 @@ import re
 try:
     line = json.loads([l for l in open(os.path.join(root, "bench_trace.json")) if l.startswith("{")][-1])
     ramp = int(re.match(r"(\d+) untimed", line["config"].get("clock_ramp", "0 untimed")).group(1))
-    first, count = ramp + line["warmup"], line["steps"]
+    first, count = int(line["config"].get("cold_steps", 0)) + ramp + line["warmup"], line["steps"]
     for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
         rows = [r for r in csv.DictReader(open(f)) if "sample_counts_stream_kernel" in r["Kernel_Name"]]
         rows.sort(key=lambda r: int(r["Start_Timestamp"]))
