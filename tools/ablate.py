@@ -19,11 +19,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "prosstt_amd", "csrc")
 OUT = os.path.join(ROOT, "build", "ab")
 
-RUN_23 = """        while (s1_at - s1_lds >= 64u * 16u) {
-            stage2_pass(std::true_type{});
-            while (s2_top >= kS2Run) stage3_pass();
+RUN_23 = """            while (s1_at - s1_lds >= 64u * 16u) {
+                stage2_pass(std::true_type{});
+                while (s2_top >= kS2Run) stage3_pass();
+            }
         }
         cur = nxt;"""
+S1_ONLY = (RUN_23, "            s1_at = s1_lds;\n        }\n        cur = nxt;")
 
 PHILOX_OFF = ("        const prnb::Words W = philox_count_row(ph, quad_hi, quad_lo, k0, k1);",
               "        prnb::Words W; W.w[0] = (ph[0] * 2654435761u) ^ ((uint32_t)g0 * 40503u); W.w[1] = W.w[0] * 3u + k0;\n"
@@ -39,14 +41,14 @@ K3H_LAUNCH = """    k3::sample_counts_heavy_kernel<<<dim3((unsigned)c->heavy_gri
 VARIANTS = {
     "base": [],
     # stage 1 only: survivors are pushed, then dropped
-    "s1": [(RUN_23, "        s1_at = s1_lds;\n        cur = nxt;")],
+    "s1": [S1_ONLY],
     # stages 1 + 2: what stage 2 pushes on S2 is dropped
-    "s12": [(RUN_23, "        while (s1_at - s1_lds >= 64u * 16u) { stage2_pass(std::true_type{}); s2_top = 0; }\n        cur = nxt;")],
+    "s12": [(RUN_23, "            while (s1_at - s1_lds >= 64u * 16u) { stage2_pass(std::true_type{}); s2_top = 0; }\n        }\n        cur = nxt;")],
     # stage 1 without the Philox call (a 2-instruction hash stands in)
-    "s1_nophilox": [(RUN_23, "        s1_at = s1_lds;\n        cur = nxt;"), PHILOX_OFF],
+    "s1_nophilox": [S1_ONLY, PHILOX_OFF],
     # stage 1 only, rows not stored (pure issue time of stage 1)
-    "s1_nostore": [(RUN_23, "        s1_at = s1_lds;\n        cur = nxt;"), STORE_OFF],
-    "s1_nostore_nophilox": [(RUN_23, "        s1_at = s1_lds;\n        cur = nxt;"), STORE_OFF, PHILOX_OFF],
+    "s1_nostore": [S1_ONLY, STORE_OFF],
+    "s1_nostore_nophilox": [S1_ONLY, STORE_OFF, PHILOX_OFF],
     # everything, mean segments not loaded (constant means)
     "noload": [("            const float4 v = *reinterpret_cast<const float4*>(rowp + gload);",
                 "            const float4 v = make_float4(0.4f, 1.1f, 0.05f, 2.5f); asm volatile(\"\" :: \"v\"(rowp + gload));")],
@@ -95,11 +97,9 @@ VARIANTS = {
     "strip32": [("    g.strip_cells = k3::kStripCells / 2;", "    g.strip_cells = k3::kStripCells / 4;")],
     # plain instead of non-temporal row stores
     "plainstore": [("store_voff, flush_off, 2 /* nt */);", "store_voff, flush_off, 0);")],
-    # stage 3 waits for 48 entries (the late list shrinks to pay for the deeper S2)
-    "run48": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 48;"), ("constexpr int kS2Cap = 96;", "constexpr int kS2Cap = 112;"),
-              ("constexpr int kLateCap = 128;", "constexpr int kLateCap = 64;")],
-    "run40": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 40;"), ("constexpr int kS2Cap = 96;", "constexpr int kS2Cap = 104;"),
-              ("constexpr int kLateCap = 128;", "constexpr int kLateCap = 64;")],
+    # stage 3 waits for 48 / 40 entries (a deeper S2; the block's LDS still allows five per CU)
+    "run48": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 48;"), ("constexpr int kS2Cap = 96;", "constexpr int kS2Cap = 112;")],
+    "run40": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 40;"), ("constexpr int kS2Cap = 96;", "constexpr int kS2Cap = 104;")],
     # round 4: K3h on a second stream with no dependency on the stream kernel (it reads the PREVIOUS call's list: timing only) --
     # the upper bound of what overlapping the two kernels can give
     "k3h_overlap": [
@@ -133,14 +133,14 @@ VARIANTS = {
 """, ""),
     ],
     # round 4: the shipped kernel held at four / three blocks per CU by LDS padding (what the fifth block is worth)
-    "occ4": [("    __shared__ WaveLds lds_all[kBlock / 64];\n\n    const int tid = threadIdx.x;",
-              "    __shared__ WaveLds lds_all[kBlock / 64];\n    __shared__ uint32_t occ_pad[2400];\n    if (N < 0) occ_pad[threadIdx.x] = 1u;\n    asm volatile(\"\" :: \"v\"((uint32_t)(uintptr_t)&occ_pad[0]));\n\n    const int tid = threadIdx.x;")],
-    "occ3": [("    __shared__ WaveLds lds_all[kBlock / 64];\n\n    const int tid = threadIdx.x;",
-              "    __shared__ WaveLds lds_all[kBlock / 64];\n    __shared__ uint32_t occ_pad[5600];\n    if (N < 0) occ_pad[threadIdx.x] = 1u;\n    asm volatile(\"\" :: \"v\"((uint32_t)(uintptr_t)&occ_pad[0]));\n\n    const int tid = threadIdx.x;")],
+    "occ4": [("    __shared__ __attribute__((aligned(kRing * 256))) uint8_t ring_all[kBlock / 64][kRing * 256];\n\n    const int tid = threadIdx.x;",
+              "    __shared__ __attribute__((aligned(kRing * 256))) uint8_t ring_all[kBlock / 64][kRing * 256];\n    __shared__ uint32_t occ_pad[2400];\n    if (N < 0) occ_pad[threadIdx.x] = 1u;\n    asm volatile(\"\" :: \"v\"((uint32_t)(uintptr_t)&occ_pad[0]));\n\n    const int tid = threadIdx.x;")],
+    "occ3": [("    __shared__ __attribute__((aligned(kRing * 256))) uint8_t ring_all[kBlock / 64][kRing * 256];\n\n    const int tid = threadIdx.x;",
+              "    __shared__ __attribute__((aligned(kRing * 256))) uint8_t ring_all[kBlock / 64][kRing * 256];\n    __shared__ uint32_t occ_pad[5600];\n    if (N < 0) occ_pad[threadIdx.x] = 1u;\n    asm volatile(\"\" :: \"v\"((uint32_t)(uintptr_t)&occ_pad[0]));\n\n    const int tid = threadIdx.x;")],
     # round 4: four rows in the ring instead of eight, at the shipped five blocks per CU (padding keeps the block's LDS)
     "ring4": [("constexpr int kRing = 8; ", "constexpr int kRing = 4; "),
-              ("    __shared__ WaveLds lds_all[kBlock / 64];\n\n    const int tid = threadIdx.x;",
-               "    __shared__ WaveLds lds_all[kBlock / 64];\n    __shared__ uint32_t occ_pad[1000];\n    if (N < 0) occ_pad[threadIdx.x] = 1u;\n    asm volatile(\"\" :: \"v\"((uint32_t)(uintptr_t)&occ_pad[0]));\n\n    const int tid = threadIdx.x;")],
+              ("    __shared__ __attribute__((aligned(kRing * 256))) uint8_t ring_all[kBlock / 64][kRing * 256];\n\n    const int tid = threadIdx.x;",
+               "    __shared__ __attribute__((aligned(kRing * 256))) uint8_t ring_all[kBlock / 64][kRing * 256];\n    __shared__ uint32_t occ_pad[1000];\n    if (N < 0) occ_pad[threadIdx.x] = 1u;\n    asm volatile(\"\" :: \"v\"((uint32_t)(uintptr_t)&occ_pad[0]));\n\n    const int tid = threadIdx.x;")],
     # round 4 (diagnosis): how many counts miss their row in the ring (printf of a few waves: late deliveries, nonzero deliveries)
     "latecount": [("    int late_top = 0;                                // wave-uniform",
                    "    int late_top = 0;                                // wave-uniform\n    int late_total = 0, deliv_total = 0;"),
