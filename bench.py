@@ -202,8 +202,40 @@ def launch_ranks(gpus, argv, script=None):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this pool
     env.setdefault("OMP_NUM_THREADS", "1")
-    env.setdefault("NCCL_DEBUG", "WARN")                   # an RCCL failure says why on the ranks' stderr
+    rccl_debug_to_file(env)
     return subprocess.run(cmd, env=env).returncode
+
+
+LINE_OUT = sys.stdout
+
+
+def keep_stdout_for_the_line():
+    """Only the contract's JSON line may reach stdout, and libraries print there too (RCCL's version banner under
+    NCCL_DEBUG, the ROCm runtime's notices): the line goes out through a private copy of the descriptor, and
+    descriptor 1 itself is pointed at stderr for everything else in this process."""
+    global LINE_OUT
+    sys.stdout.flush()
+    LINE_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
+
+def rccl_debug_to_file(env):
+    """RCCL says why it failed -- into a FILE: with NCCL_DEBUG set it also prints a version banner to stdout, where
+    only the contract's JSON line may go."""
+    env.setdefault("NCCL_DEBUG", "WARN")
+    env.setdefault("NCCL_DEBUG_FILE", os.path.join(os.environ.get("TMPDIR", "/tmp"), "prosstt_bench_rccl.%h.%p.log"))
+
+
+def rccl_debug_tail(limit=1500):
+    import glob
+    pattern = os.environ.get("NCCL_DEBUG_FILE", "").replace("%h", "*").replace("%p", "*")
+    text = ""
+    for f in sorted(glob.glob(pattern))[-8:] if pattern else []:
+        try:
+            text += "[%s] %s\n" % (os.path.basename(f), open(f).read()[-400:].strip())
+        except OSError:
+            pass
+    return text[-limit:]
 
 
 class Job:
@@ -224,12 +256,16 @@ class Job:
         self.use_dist = self.world > 1 or os.environ.get("PROSSTT_BENCH_FORCE_DIST") == "1"   # the latter: RCCL path on 1 GPU
         if self.use_dist:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("NCCL_DEBUG", "WARN")
+            rccl_debug_to_file(os.environ)
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            if self.backend == "nccl":
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-            else:
-                dist.init_process_group(self.backend)
+            try:
+                if self.backend == "nccl":
+                    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+                else:
+                    dist.init_process_group(self.backend)
+            except Exception:
+                sys.stderr.write("process group initialisation failed; RCCL's own log:\n%s\n" % rccl_debug_tail())
+                raise
         from prosstt_amd import device
         self.ctx = device.get_context(local)
         self.red_dev = self.ctx.torch_device if self.backend == "nccl" else torch.device("cpu")
@@ -404,6 +440,7 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))      # before anything here has touched torch.cuda
+    keep_stdout_for_the_line()
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world_env:
         sys.exit("--gpus %d but the launcher started %d rank(s)" % (args.gpus, world_env))
@@ -431,7 +468,8 @@ def main():
         if rank != 0:
             return
         line = assemble_line(args, job, main_case, strong, end_to_end, why or extras_error)
-        print(json.dumps(line), flush=True)
+        LINE_OUT.write(json.dumps(line) + "\n")
+        LINE_OUT.flush()
 
     guard = ExtrasGuard(rank, float(os.environ.get("PROSSTT_BENCH_EXTRAS_TIMEOUT_S", "600")),
                         exit_code=3 if args.fail_on_extras_error else 0)
@@ -460,6 +498,9 @@ def main():
                 del case
         except Exception as exc:          # noqa: BLE001 -- whatever it is, the line must still go out
             extras_error = "%s: %s" % (type(exc).__name__, str(exc)[:300])
+            tail = rccl_debug_tail(400)
+            if tail:
+                extras_error += " | RCCL: " + tail.replace("\n", " ")
     main_case.pop("shard", None)
 
     if not guard.disarm():
