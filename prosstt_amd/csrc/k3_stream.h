@@ -420,16 +420,17 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const int32_t gload = VEC ? (g0 < G ? g0 : G - 4) - gbase : 0;
     const float* const mcol = means + gbase;
-    struct Seg { float M[4]; };
+    typedef float Seg __attribute__((ext_vector_type(4)));      // (a vector: the two-deep rotation below is then four 64-bit moves)
     auto load_seg = [&](uint64_t row_bytes) -> Seg {
         Seg r;
         const float* rowp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(mcol) + row_bytes);
         if (VEC) {
-            const float4 v = *reinterpret_cast<const float4*>(rowp + gload);
-            r.M[0] = v.x; r.M[1] = v.y; r.M[2] = v.z; r.M[3] = v.w;
+            r = *reinterpret_cast<const Seg*>(rowp + gload);
         } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) r.M[j] = (g0 + j < G) ? rowp[lane4 + j] : 0.0f;
+            r.x = (g0 + 0 < G) ? rowp[lane4 + 0] : 0.0f;
+            r.y = (g0 + 1 < G) ? rowp[lane4 + 1] : 0.0f;
+            r.z = (g0 + 2 < G) ? rowp[lane4 + 2] : 0.0f;
+            r.w = (g0 + 3 < G) ? rowp[lane4 + 3] : 0.0f;
         }
         return r;
     };
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
     for (int cl = 0; cl < cells; ++cl) {
         // every lane runs the whole pass: the stack tops must stay wave-uniform, so no ballot
         // may sit under a divergent branch
-        const float m4[4] = {cur.M[0] * s, cur.M[1] * s, cur.M[2] * s, cur.M[3] * s};
+        const float m4[4] = {cur.x * s, cur.y * s, cur.z * s, cur.w * s};
         if (cl >= kRing) flush_row(cl - kRing);
         // The scalar loads go out only now, behind the flush's LDS read: scalar and LDS returns
         // share one counter that can only be waited down to zero, and the next LDS read is a
