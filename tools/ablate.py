@@ -50,8 +50,8 @@ VARIANTS = {
     "s1_nostore": [S1_ONLY, STORE_OFF],
     "s1_nostore_nophilox": [S1_ONLY, STORE_OFF, PHILOX_OFF],
     # everything, mean segments not loaded (constant means)
-    "noload": [("            const float4 v = *reinterpret_cast<const float4*>(rowp + gload);",
-                "            const float4 v = make_float4(0.4f, 1.1f, 0.05f, 2.5f); asm volatile(\"\" :: \"v\"(rowp + gload));")],
+    "noload": [("            r = *reinterpret_cast<const Seg*>(rowp + gload);",
+                "            r = Seg{0.4f, 1.1f, 0.05f, 2.5f}; asm volatile(\"\" :: \"v\"(rowp + gload));")],
     # everything, rows not stored
     "nostore": [STORE_OFF],
     # K3h without the redo walks / without the gamma-Poisson samples
