@@ -193,6 +193,10 @@ VARIANTS = {
          "    const int32_t tile_g = (int32_t)blk / groups;\n    const int32_t strip = ((int32_t)blk - tile_g * groups) * 4 + wv;"),
         ("    const uint32_t region = blockIdx.x * 4u + (uint32_t)wv;", "    const uint32_t region = blk * 4u + (uint32_t)wv;"),
     ],
+    # round 4 (real variants, for C2): strips of 20 / 24 / 12 cells -- one round of waves on the chip's 5120 wave slots
+    "strip20": [("    g.strips = (n + g.strip_cells - 1) / g.strip_cells;", "    g.strip_cells = 20;\n    g.strips = (n + g.strip_cells - 1) / g.strip_cells;")],
+    "strip24": [("    g.strips = (n + g.strip_cells - 1) / g.strip_cells;", "    g.strip_cells = 24;\n    g.strips = (n + g.strip_cells - 1) / g.strip_cells;")],
+    "strip12": [("    g.strips = (n + g.strip_cells - 1) / g.strip_cells;", "    g.strip_cells = 12;\n    g.strips = (n + g.strip_cells - 1) / g.strip_cells;")],
     # mean segments one cell ahead, requested at the END of a pass (one register rotation; the row store gets a whole pass before anything waits behind it)
     "pf1": [("        const Seg nn = load_seg(row2);\n        const uint64_t row3 = cinfo[3].row_bytes;",
              "        const uint64_t row3 = cinfo[3].row_bytes;"),
