@@ -5,7 +5,7 @@
 // The scalar algorithm (PRNB-5, prnb_device.h) has very different costs per sample:
 //   ~65 % of the samples of the headline workload are zeros that a 6-instruction bound
 //         settles (exp(-m * phi_gene) <= P(X = 0), prnb::zero_test_factor);
-//   the rest need P(X = 0) exactly (reciprocal + log1p + exp, ~100 VALU), and
+//   the rest need P(X = 0) itself (two reciprocals, a log2 and an exp2 of the hardware: PRNB-5), and
 //   ~33 % then walk the pmf for k >= 1 (data-dependent length, half of them end at k <= 2);
 //   ~0.1 % need gamma-Poisson.
 // Run lane-per-sample, every wave pays for its slowest lane in every one of these.  Here
@@ -16,10 +16,11 @@
 //                       undecided is pushed on S2 with the pmf state at k = 3;
 //   stage 3 (lanes pull from S2)  four pmf steps per lane per pass; a lane that finishes
 //                       writes its count into the LDS row ring and pulls the next entry;
-//   output              the last kRing rows of the strip live in LDS, 8 bits per count (a count above
-//                       255 -- 1 in 10^4 -- is left to K3h); a row
+//   output              the last kRing rows of the strip live in LDS, 8 bits per count (a walk past
+//                       k = 254 -- 70 per 10^9 samples of the headline workload -- is left to K3h); a row
 //                       is stored (one coalesced 1 KiB store per wave) kRing cells after stage 1
-//                       started it.  The few counts that arrive later than that (long walks)
+//                       started it.  The few counts that arrive later than that (long walks, and the
+//                       entries at the bottom of the two LIFO stacks, which wait for the drain)
 //                       are collected in LDS and written in bursts of 4-B stores -- a store per
 //                       late count would sit in front of every wait for the next mean load
 //                       (loads and stores retire in order on one counter);
@@ -36,13 +37,13 @@
 // order in which the stacks are drained cannot change them.
 //
 // Written against the issue model measured on gfx950 (tools/microbench5.hip, microbench6.hip;
-// DESIGN.md section 6): a SIMD issues one vector instruction per ~2.4 cycles; binary32
-// mul/add/sub/fma run beside everything else, the other kinds (compare, select, convert, min/max,
-// left shift, mbcnt, 3-operand integer forms, 64-bit multiply) occupy a second unit for ~4.3 cycles
-// each (simple integer add/xor/and/or/right shift ~2.4 there, transcendentals ~8.3), and scalar
-// instructions issue beside both.  The kernel is bound by that second unit, so the walk is pure
-// binary32 arithmetic on a binary32 remainder, hits are counted from sign bits, wave-level
-// tests are lane masks formed by ONE compare each, and per-cell values arrive by scalar loads.
+// DESIGN.md section 6): a SIMD issues one instruction per ~2.3 cycles at five waves per SIMD, whatever its kind;
+// binary32 mul/add/sub/fma run beside the other vector kinds (compare, select, convert, min/max, left shift, mbcnt,
+// 3-operand integer forms, 64-bit multiply: ~4.3 cycles each on a second unit; transcendentals ~8.3), and scalar
+// instructions weigh little beside both.  The kernel is bound by the number of (vector) instructions it issues and by
+// how many waves a CU holds (five blocks: the LDS budget below), so the walk is pure binary32 arithmetic on a binary32
+// remainder, counts come from arithmetic shifts of sign bits, wave-level tests are lane masks formed by ONE compare each,
+// and per-cell values arrive by scalar loads.
 #pragma once
 #include <type_traits>
 #include "prnb_device.h"

@@ -1,15 +1,21 @@
 // libprosstt_amd.so -- HIP kernels (gfx950) and the C ABI of include/prosstt_amd.h.
 //
 // Kernels
-//   prep_kernel             binary64 scaling/alpha/beta -> binary32 sampler parameters, per-cell records, flag words
+//   prep_kernel             binary64 scaling/alpha/beta -> binary32 sampler parameters, per-cell records, flag words,
+//                           the per-cell / per-gene part of the domain check
 //   k3::sample_counts_stream_kernel + k3::sample_counts_heavy_kernel (k3_stream.h, k3_heavy.h)
 //                           K3: fused gather * scale -> get_pr_umi -> NB draw
 //                           (simulation.py:602-651, count_model.py:131-161)
+//   row_flags_kernel, domain_full_kernel   the rest of scipy's argument check (simulation.py:647-648)
 //   nb_params_kernel        the deterministic intermediates of the same path
-//   lineage_attempt_kernel  K2a: max(programs@H) and per-sibling anticorrelated-gene
+//   hw_math_kernel          the probe of the three hardware functions of the sampler's definition
+//   lineage_attempt_lds_kernel / lineage_attempt_kernel
+//                           K2a: max(programs@H) and per-sibling anticorrelated-gene
 //                           counts without materialising (T,G)   (simulation.py:269-272)
 //   lineage_commit_kernel   K2b: rel = programs@H in binary64 + per-gene max
+//   lineage_walk_kernel     K1: device-mode expression programs (simulation.py:89-124)
 //   means_from_rel_kernel   Tree.add_genes: exp(rel)*base -> binary32 mean tensor (tree.py:181-182)
+// Host only: prosstt_amd_numpy_programs (numpy_stream.h): numpy's legacy stream for a batch of attempts.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
