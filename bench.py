@@ -55,11 +55,16 @@ def algorithmic_bytes(n_cells, G, rows):
 
 
 def kernel_source_sha():
-    """Fingerprint of the kernel sources (what a profile is a profile OF)."""
+    """Fingerprint of the kernel sources (what a profile is a profile OF): the code of the device translation
+    unit with comments and blank space taken out, so that an edited comment does not orphan a profile."""
     import hashlib
+    import re
     h = hashlib.sha256()
-    for fn in ("k3_stream.h", "k3_heavy.h", "prnb_device.h", "prosstt_amd.hip"):
-        h.update(open(os.path.join(ROOT, "prosstt_amd", "csrc", fn), "rb").read())
+    for fn in ("k3_stream.h", "k3_heavy.h", "prnb_device.h", "numpy_stream.h", "prosstt_amd.hip"):
+        text = open(os.path.join(ROOT, "prosstt_amd", "csrc", fn), "r").read()
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)          # block comments
+        text = re.sub(r"//[^\n]*", " ", text)                       # line comments (no string of these sources holds //)
+        h.update(" ".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 
