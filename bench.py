@@ -225,8 +225,11 @@ def keep_stdout_for_the_line():
 
 
 def rccl_debug_to_file(env):
-    """RCCL says why it failed -- into a FILE: with NCCL_DEBUG set it also prints a version banner to stdout, where
-    only the contract's JSON line may go."""
+    """PROSSTT_BENCH_RCCL_DEBUG=1: RCCL says why it failed (NCCL_DEBUG=WARN, into a FILE).  Off by default: with
+    NCCL_DEBUG set, RCCL also prints a version banner when the process group goes down -- behind the contract's JSON
+    line, on whatever the caller reads."""
+    if env.get("PROSSTT_BENCH_RCCL_DEBUG") != "1":
+        return
     env.setdefault("NCCL_DEBUG", "WARN")
     env.setdefault("NCCL_DEBUG_FILE", os.path.join(os.environ.get("TMPDIR", "/tmp"), "prosstt_bench_rccl.%h.%p.log"))
 
@@ -269,7 +272,8 @@ class Job:
                 else:
                     dist.init_process_group(self.backend)
             except Exception:
-                sys.stderr.write("process group initialisation failed; RCCL's own log:\n%s\n" % rccl_debug_tail())
+                sys.stderr.write("process group initialisation failed; RCCL's own log (PROSSTT_BENCH_RCCL_DEBUG=1 turns it on):\n%s\n"
+                                 % rccl_debug_tail())
                 raise
         from prosstt_amd import device
         self.ctx = device.get_context(local)
