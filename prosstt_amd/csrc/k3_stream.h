@@ -70,7 +70,7 @@ constexpr int kInvTab = 260;       // 1/k for k < 260: the reciprocals a pass at
 // row of the count matrix: ph[0] = cell_hi ^ k0, ph[1] = hi(M1 * (hi(M0 * cell_lo) ^ k1)) ^ (k0 + W0),
 // ph[2] = lo(M0 * cell_lo) ^ (k1 + W1), ph[3] = lo(M1 * (hi(M0 * cell_lo) ^ k1))  (philox_cell_part).
 // The array holds N + 4 entries (the last cell repeated) so that prefetches need no clamp.
-struct CellInfo { uint64_t row_bytes; float s; uint32_t pos_base; uint32_t ph[4]; };
+struct CellInfo { uint64_t row_bytes; float s; uint32_t reserved; uint32_t ph[4]; };
 static_assert(sizeof(CellInfo) == 32, "one s_load_dwordx8");
 
 constexpr uint32_t kPhiloxM0 = 0xD2511F53u, kPhiloxM1 = 0xCD9E8D57u, kPhiloxW0 = 0x9E3779B9u, kPhiloxW1 = 0xBB67AE85u;
@@ -186,19 +186,19 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
     constexpr uint32_t kNoHeavy = 0xffffffffu;
     uint32_t hpend = kNoHeavy;                       // pos of the sample this lane holds for the next append to K3h's list
     // stage-3 lane state: st = {the next term (k = k3 - 3), d = mp - q, q, what is left of wf}; pos; k3 = the walk's
-    // group ends at k3 (6, 10, ...).  An idle lane has st.x = NaN (it then takes part in no mask: NaN compares false)
-    // and a k3 far below zero that the +4 of a pass cannot bring to zero within a strip.
+    // group ends at k3 (6, 10, ...).  WHICH lanes walk is wave-level state on the scalar unit (idle_s: bit = the lane
+    // holds no walk): a pass takes every mask it forms AND NOT idle_s, so an idle lane may compute on whatever its
+    // registers hold (its k3 keeps growing by 4 per pass: some hundreds by the end of a strip, inside the block's LDS
+    // as a table index), and no vector instruction is spent on asking or marking who is idle.
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    constexpr int kIdleK3 = -(1 << 30) + 2;          // = 2 mod 4: the read-ahead of four reciprocals stays 16-byte aligned
-    f32x4 st = {__builtin_nanf(""), 0.0f, 0.0f, 0.0f};
+    f32x4 st = {0.0f, 0.0f, 0.0f, 0.0f};
     uint32_t pos = 0u;
-    int k3 = kIdleK3;
+    int k3 = 6;
     f32x4 inv = {0.0f, 0.0f, 0.0f, 0.0f};               // 1/(k+1) .. 1/(k+4): read one pass ahead
-    float nan_v = __builtin_nanf("");
-    int idle_v = kIdleK3;
-    asm volatile("" : "+v"(nan_v), "+v"(idle_v));    // constants kept in registers (v_cndmask below takes them beside an SGPR mask)
+    unsigned long long idle_s = ~0ull;                   // wave-uniform
 
-    // S1/S2 entries carry pos = (cell-in-strip << 8) | gene-in-tile
+    // S1/S2 entries carry pos = (cell-in-strip << 8) | gene-in-tile, under the bits of 2^23 (kPosMagic, below)
+    constexpr uint32_t kPosMagic = 0x4B000000u;
     int32_t* const strip_out = out + n0 * ld + gbase;
     const uint32_t ld32 = (uint32_t)ld;              // strip rows * ld * 4 < 2^31, checked by the host
     // pos of the last sample whose row has already left the ring (wave-uniform; -1: none)
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
                 if (g0 + j < G) dst[j] = v[j];
         }
         flush_off += ld32 * 4u;
-        flushed_pos = (cl << 8) | 255;
+        flushed_pos = (int32_t)kPosMagic | (cl << 8) | 255;
     };
 
     // a finished count (> 0) goes into the row ring while its row is still there, else (rare) on
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
         const unsigned long long mp_ = K3_MASK(hpend != kNoHeavy);
         if (hpend != kNoHeavy) {
             const uint32_t slot = h_cnt + (uint32_t)lane_rank(mp_);
-            if (slot < heavy.cap) my_list[slot] = hpend;
+            if (slot < heavy.cap) my_list[slot] = hpend & 0xffffu;
         }
         h_cnt += (uint32_t)__popcll(mp_);
         hpend = kNoHeavy;
@@ -302,18 +302,16 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
     // A walk enters at k = 3 and advances by 4: the four reciprocals 1/(k+1)..1/(k+4) are one aligned
     // 16-byte LDS read.  The remainders only fall, so there is a hit iff the last one is negative, and
     // the count is k3 less the number of negative remainders among the first three: arithmetic shifts of the
-    // sign bits, no compares.  An idle lane's NaN term makes every remainder NaN: it is in no mask, whatever
-    // its integers hold, so the pass never asks which lanes are busy.
+    // sign bits, no compares.  An idle lane runs the same arithmetic on stale registers; the three lane masks of a pass
+    // are cleared of idle_s on the scalar unit.
     const uint32_t s2_lds = (uint32_t)(uintptr_t)&L.s2[0];
     const uint32_t s2p_lds = (uint32_t)(uintptr_t)&L.s2p[0];
     const uint32_t inv47_lds = (uint32_t)(uintptr_t)&inv_k[4];
     auto stage3_pass = [&]() {
-        unsigned long long idle_m;
-        asm("v_cmp_gt_i32 %0, 0, %1" : "=s"(idle_m) : "v"(k3));
-        if (idle_m != 0ull && s2_top > 0) {
+        if (idle_s != 0ull && s2_top > 0) {
             // the idle lanes take the top entries of S2, under exec = (idle and an entry left): loads only
-            const int rank = lane_rank(idle_m);
-            const unsigned long long take_m = idle_m & K3_MASK(rank < s2_top);
+            const int rank = lane_rank(idle_s);
+            const unsigned long long take_m = idle_s & K3_MASK(rank < s2_top);
             const uint32_t idx = (uint32_t)(s2_top - 1 - rank);
             asm volatile("s_mov_b64 exec, %[tm]\n\t"
                          "ds_read_b128 %[st], %[ea]\n\t"
@@ -325,8 +323,9 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
                          : [st] "+v"(st), [pos] "+v"(pos), [inv] "+v"(inv), [k3] "+v"(k3)
                          : [tm] "s"(take_m), [ea] "v"(s2_lds + (idx << 4)), [pa] "v"(s2p_lds + (idx << 2)), [ia] "v"(inv47_lds)
                          : "memory");
-            const int left = s2_top - __popcll(idle_m);
+            const int left = s2_top - __popcll(idle_s);
             s2_top = left > 0 ? left : 0;
+            idle_s &= ~take_m;
         }
         const float d = st.y, q = st.z;
         const float r1 = st.w - st.x;
@@ -338,20 +337,15 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
         const float r4 = r3 - ps3;
         const unsigned long long hit_m = K3_MASK(r4 < 0.0f);
         const unsigned long long tail_m = K3_MASK(ps3 < 1.0f);
-        const unsigned long long big_m = K3_MASK(k3 >= kRingMaxK3);       // undecided there: the rest of the walk is K3h's
+        const unsigned long long big_m = K3_MASK(k3 >= kRingMaxK3) & ~idle_s;       // undecided there: the rest of the walk is K3h's
         // the count: k3 less one for each of r1, r2, r3 that is negative (no hit: they are not, and the count is k3)
         const int32_t res_k = (k3 + ((int32_t)prnb::f2u(r1) >> 31) + ((int32_t)prnb::f2u(r2) >> 31)) + ((int32_t)prnb::f2u(r3) >> 31);
-        const unsigned long long end_m = hit_m | tail_m;
+        const unsigned long long end_m = (hit_m | tail_m) & ~idle_s;
         deliver(end_m, big_m & ~end_m, pos, (uint32_t)res_k);
-        const unsigned long long done_m = end_m | big_m;
-        const float ps4 = ps3 * PRNB_FMA(d, inv.w, q);
-        const int k3n = k3 + 4;
+        idle_s |= end_m | big_m;                          // done lanes go idle
+        st.x = ps3 * PRNB_FMA(d, inv.w, q);
+        k3 += 4;
         st.w = r4;
-        // done lanes go idle
-        float ps_next;
-        asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(ps_next) : "v"(ps4), "v"(nan_v), "s"(done_m));
-        st.x = ps_next;
-        asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(k3) : "v"(k3n), "v"(idle_v), "s"(done_m));
         inv = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(&inv_k[k3 - 2], 16));   // 1/(k+1..k+4), k = k3 - 3
     };
 
@@ -438,13 +432,17 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
     Seg cur = load_seg(cinfo[0].row_bytes), nxt = load_seg(cinfo[1].row_bytes);
     uint64_t row2 = cinfo[2].row_bytes;
     float s = cinfo[0].s;
-    uint32_t posbase = cinfo[0].pos_base;
     uint32_t ph[4] = {cinfo[0].ph[0], cinfo[0].ph[1], cinfo[0].ph[2], cinfo[0].ph[3]};
     const uint64_t quad_p1 = (uint64_t)kPhiloxM1 * ((uint32_t)g0 >> 2);     // the gene quad's part of round 1
     const uint32_t quad_hi = (uint32_t)(quad_p1 >> 32), quad_lo = (uint32_t)quad_p1;
     // Nothing may be pending on the vector-memory counter when the loop is entered: the compiler's wait
     // for the first pass's mean segment would otherwise sit in the loop body, behind the row store.
     __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0)
+    // pos travels as the binary32 number 2^23 + pos, whose low mantissa bits ARE pos (pos < 2^15): the step to the next
+    // cell and the gene's offset within the quad are then binary32 additions, which issue beside the integer work of
+    // the pass (-0.6 %: profiles/r04_ablation.txt).  Every reader masks (the ring address, the late list's shift) or
+    // compares against a bound that carries the same 2^23 (flushed_pos); the list for K3h gets the low 16 bits.
+    float posf = __uint_as_float(kPosMagic | lane4);
 #pragma unroll 1
     for (int cl = 0; cl < cells; ++cl) {
         // every lane runs the whole pass: the stack tops must stay wave-uniform, so no ballot
@@ -463,12 +461,10 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
         const Seg nn = load_seg(row2);
         const uint64_t row3 = cinfo[3].row_bytes;
         const float s_next = cinfo[1].s;
-        const uint32_t posbase_next = cinfo[1].pos_base;
         const uint32_t ph_next[4] = {cinfo[1].ph[0], cinfo[1].ph[1], cinfo[1].ph[2], cinfo[1].ph[3]};
         ++cinfo;
         __builtin_amdgcn_sched_barrier(0);
         const prnb::Words W = philox_count_row(ph, quad_hi, quad_lo, k0, k1);
-        const uint32_t pos4 = posbase | lane4;
         // P(X=0) = exp(-m*log1p(theta)/theta) >= exp(-x) >= 1 - x + x^2/2 - x^3/6, x = m * phi
         // (prnb::zero_test_factor).  The polynomial is evaluated times 2^32 with 1e-5 taken off
         // the constant term: far more than every rounding and the hardware functions' error of the exact
@@ -490,7 +486,7 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
             e[j].x = __float_as_uint(m);
             e[j].y = __float_as_uint(PRNB_FMA(a[j], m, bm1[j]));
             e[j].z = __float_as_uint(wf);
-            e[j].w = pos4 | (uint32_t)j;
+            e[j].w = __float_as_uint(posf + (float)j);
         }
         // The pushes: one LDS store each under exec = its mask, at the stack's top + 16 * (rank among the pushing
         // lanes) -- no branch, no exec save, exec restored once per pair.  (v_mbcnt counts the bits of the mask it is GIVEN
@@ -528,7 +524,7 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
         row2 = row3;
         s = s_next;
         ph[0] = ph_next[0]; ph[1] = ph_next[1]; ph[2] = ph_next[2]; ph[3] = ph_next[3];
-        posbase = posbase_next;
+        posf += 256.0f;
     }
 
     // ---- drain ------------------------------------------------------------------------------------
@@ -540,12 +536,12 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
     // pass per cell on the headline workload): once nothing waits on S2 and at most kBail lanes still walk,
     // their samples go on K3h's list instead, which redoes them from the start.
     for (;;) {
-        const unsigned long long busy_m = __builtin_amdgcn_ballot_w64(k3 > 0);
+        const unsigned long long busy_m = ~idle_s;
         if (s2_top == 0) {
             if (busy_m == 0ull) break;
             if (__popcll(busy_m) <= kBail) {
                 if ((busy_m & __builtin_amdgcn_ballot_w64(hpend != kNoHeavy)) != 0ull) flush_heavy();
-                if (k3 > 0) hpend = pos;
+                if ((busy_m >> lane) & 1ull) hpend = pos;
                 break;
             }
         }

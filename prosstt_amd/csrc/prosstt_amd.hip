@@ -191,7 +191,7 @@ __global__ void prep_kernel(const double* __restrict__ scaling, int64_t N,
         const int64_t row = row_of_cell[n] < 0 ? 0 : (row_of_cell[n] >= rows ? rows - 1 : row_of_cell[n]);
         c.row_bytes = (uint64_t)row * (uint64_t)G * 4u;
         c.s = (float)scaling[n];
-        c.pos_base = (uint32_t)(n % strip_cells) << 8;
+        c.reserved = 0u;
         k3::philox_cell_part((uint32_t)cell, (uint32_t)(cell >> 32), k0, k1, c.ph);
         info[i] = c;
     }

@@ -38,6 +38,19 @@ K3H_LAUNCH = """    k3::sample_counts_heavy_kernel<<<dim3((unsigned)c->heavy_gri
         A.scal, A.ga, A.gbm1, N, k0, k1, cell_offset, d_cell_index, d_out, ld_out);
 """
 
+SVGPR = ("        const float m4[4] = {cur.x * s, cur.y * s, cur.z * s, cur.w * s};",
+         "        float sv_; asm volatile(\"v_mov_b32 %0, %1\" : \"=v\"(sv_) : \"s\"(s));\n"
+         "        const float m4[4] = {cur.x * sv_, cur.y * sv_, cur.z * sv_, cur.w * sv_};")
+THETA2 = ("            e[j].y = __float_as_uint(PRNB_FMA(a[j], m, bm1[j]));", "            e[j].y = __float_as_uint(a[j] * m + bm1[j]);")
+# pos as a binary32 number 2^23 + pos (its low bits ARE pos): the cell's step and the gene's offset are binary32 adds
+POSF = [("        const uint32_t pos4 = posbase | lane4;\n", ""),
+        ("            e[j].w = pos4 | (uint32_t)j;", "            e[j].w = __float_as_uint(posf_ + (float)j);"),
+        ("        posbase = posbase_next;\n    }", "        posbase = posbase_next;\n        posf_ += 256.0f;\n    }"),
+        ("    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0)\n",
+         "    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0)\n    float posf_ = __uint_as_float(0x4B000000u | posbase | lane4);\n"),
+        ("        flushed_pos = (cl << 8) | 255;", "        flushed_pos = 0x4B000000 | (cl << 8) | 255;"),
+        ("            if (slot < heavy.cap) my_list[slot] = hpend;", "            if (slot < heavy.cap) my_list[slot] = hpend & 0xffffu;")]
+
 VARIANTS = {
     "base": [],
     # stage 1 only: survivors are pushed, then dropped
@@ -201,6 +214,15 @@ VARIANTS = {
     "pf1": [("        const Seg nn = load_seg(row2);\n        const uint64_t row3 = cinfo[3].row_bytes;",
              "        const uint64_t row3 = cinfo[3].row_bytes;"),
             ("        cur = nxt;\n        nxt = nn;\n        row2 = row3;", "        cur = nxt;\n        nxt = load_seg(row2);\n        row2 = row3;")],
+    # round 4, the two-pipe hypothesis (binary32 mul/add/fma with <= 2 register operands issue beside everything else):
+    # instructions moved from the "everything else" side to the binary32 side, count unchanged or higher
+    "svgpr": [SVGPR],
+    "theta2": [THETA2],
+    "posf": POSF,
+    "pipes3": [SVGPR, THETA2] + POSF,
+    # one reciprocal for 1/u1 and 1/theta: r = rcp(u1 * th), 1/u1 = r * th, 1/th = r * u1 (a transcendental less, two multiplies more)
+    "rcp1": [("    h.iu = hw_rcp(u1);\n    h.t2 = m * (hw_log2(u1) * hw_rcp(u1 - 1.0f));",
+              "    const float th_ = u1 - 1.0f;\n    const float r_ = hw_rcp(u1 * th_);\n    h.iu = r_ * th_;\n    h.t2 = m * (hw_log2(u1) * (r_ * u1));")],
 }
 
 

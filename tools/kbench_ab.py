@@ -13,6 +13,7 @@ args = sys.argv[1:]
 cfg = args.pop(0) if args and args[0] in workloads.CONFIGS else "C3"
 rounds = int(args.pop(0)) if args and args[0].isdigit() else 12
 libs = args or ["shipped"]
+BURST = int(os.environ.get("KBENCH_BURST", "1"))
 ctx0 = device.get_context()
 w = workloads.build(cfg)
 pt, br, sc, rows = w.plan(int(os.environ["KBENCH_CELLS"]) if "KBENCH_CELLS" in os.environ else (125000 if cfg == "C5" else None))
@@ -37,16 +38,18 @@ class Variant:
         self.kernel, self.call, self.sum = [], [], None
 
     def run(self, seed):
+        # KBENCH_BURST=n: n calls back to back per round (the device keeps its clock), the call time is their mean
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        rc = self.lib.prosstt_amd_sample_counts(self.h, vp(dm.data_ptr()), dm.shape[0], G, vp(dr.data_ptr()), vp(ds.data_ptr()),
-                                                vp(da.data_ptr()), vp(db.data_ptr()), len(rows), seed, 0, None,
-                                                vp(out.data_ptr()), out.stride(0), _native.TIME_KERNEL)
-        assert rc == 0, self.lib.prosstt_amd_last_error()
+        for _ in range(BURST):
+            rc = self.lib.prosstt_amd_sample_counts(self.h, vp(dm.data_ptr()), dm.shape[0], G, vp(dr.data_ptr()), vp(ds.data_ptr()),
+                                                    vp(da.data_ptr()), vp(db.data_ptr()), len(rows), seed, 0, None,
+                                                    vp(out.data_ptr()), out.stride(0), _native.TIME_KERNEL)
+            assert rc == 0, self.lib.prosstt_amd_last_error()
         e1.record(); torch.cuda.synchronize()
         ms = ctypes.c_float(0)
         self.lib.prosstt_amd_last_kernel_ms(self.h, ctypes.byref(ms))
-        self.kernel.append(ms.value); self.call.append(e0.elapsed_time(e1))
+        self.kernel.append(ms.value); self.call.append(e0.elapsed_time(e1) / BURST)
 
 
 vs = [Variant(p) for p in libs]
@@ -60,5 +63,6 @@ n = len(rows) * G
 base = float(np.median(vs[0].kernel))
 for v in vs:
     k = float(np.median(v.kernel))
-    print("%-44s %s kernel median %.3f min %.3f ms (%+5.1f %% vs first) | call median %.3f | %.1f %% of 8 TB/s | sum %d" % (
-        v.name[-44:], cfg, k, min(v.kernel), (k / base - 1) * 100, float(np.median(v.call)), n * 4.0325 / (k * 1e-3) / 8e12 * 100, v.sum))
+    print("%-44s %s kernel median %.3f min %.3f ms (%+5.1f %% vs first) | call median %.3f (%+5.2f %%) | %.1f %% of 8 TB/s | sum %d" % (
+        v.name[-44:], cfg, k, min(v.kernel), (k / base - 1) * 100, float(np.median(v.call)),
+        (float(np.median(v.call)) / float(np.median(vs[0].call)) - 1) * 100, n * 4.0325 / (k * 1e-3) / 8e12 * 100, v.sum))
