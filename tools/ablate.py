@@ -42,14 +42,6 @@ SVGPR = ("        const float m4[4] = {cur.x * s, cur.y * s, cur.z * s, cur.w * 
          "        float sv_; asm volatile(\"v_mov_b32 %0, %1\" : \"=v\"(sv_) : \"s\"(s));\n"
          "        const float m4[4] = {cur.x * sv_, cur.y * sv_, cur.z * sv_, cur.w * sv_};")
 THETA2 = ("            e[j].y = __float_as_uint(PRNB_FMA(a[j], m, bm1[j]));", "            e[j].y = __float_as_uint(a[j] * m + bm1[j]);")
-# pos as a binary32 number 2^23 + pos (its low bits ARE pos): the cell's step and the gene's offset are binary32 adds
-POSF = [("        const uint32_t pos4 = posbase | lane4;\n", ""),
-        ("            e[j].w = pos4 | (uint32_t)j;", "            e[j].w = __float_as_uint(posf_ + (float)j);"),
-        ("        posbase = posbase_next;\n    }", "        posbase = posbase_next;\n        posf_ += 256.0f;\n    }"),
-        ("    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0)\n",
-         "    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0)\n    float posf_ = __uint_as_float(0x4B000000u | posbase | lane4);\n"),
-        ("        flushed_pos = (cl << 8) | 255;", "        flushed_pos = 0x4B000000 | (cl << 8) | 255;"),
-        ("            if (slot < heavy.cap) my_list[slot] = hpend;", "            if (slot < heavy.cap) my_list[slot] = hpend & 0xffffu;")]
 
 VARIANTS = {
     "base": [],
@@ -94,7 +86,7 @@ VARIANTS = {
                   ("    light_service(true);\n    while (hg_top > 0) gamma_pass();\n    while (hp_top > 0) poisson_pass();",
                    "    const long long T1 = clock64();\n    light_service(true);\n    while (hg_top > 0) gamma_pass();\n    while (hp_top > 0) poisson_pass();\n"
                    "    const long long T2 = clock64();\n"
-                   "    if (lane == 0 && (wave_id % 1021) == 5) printf(\"K3HTRACE wave %lld total %lld feedloop %lld drain %lld | light %d starts %d walk passes %lld | gamma %d passes %lld | poisson %d passes %lld\\n\", (long long)wave_id, T2 - T0, T1 - T0, T2 - T1, np_l, np_w, TL, np_g, TG, np_p, TP);")],
+                   "    if (lane == 0 && (wave_id % 97) == 5) printf(\"K3HTRACE wave %lld total %lld feedloop %lld drain %lld | light %d starts %d walk passes %lld | gamma %d passes %lld | poisson %d passes %lld\\n\", (long long)wave_id, T2 - T0, T1 - T0, T2 - T1, np_l, np_w, TL, np_g, TG, np_p, TP);")],
     # the library default of 10 Philox rounds instead of 7 (timing only: the model is not changed along)
     "philox10": [("constexpr int kCountRounds = 7;", "constexpr int kCountRounds = 10;")],
     # real variants (correct results): tuning constants
@@ -125,24 +117,20 @@ VARIANTS = {
     # round 4 (real variant): the next cell's record loaded mid-pass into the registers this pass has finished with (no scalar rotation)
     "inplace_scalars": [
         ("""        const float s_next = cinfo[1].s;
-        const uint32_t posbase_next = cinfo[1].pos_base;
         const uint32_t ph_next[4] = {cinfo[1].ph[0], cinfo[1].ph[1], cinfo[1].ph[2], cinfo[1].ph[3]};
         ++cinfo;
         __builtin_amdgcn_sched_barrier(0);
         const prnb::Words W = philox_count_row(ph, quad_hi, quad_lo, k0, k1);
-        const uint32_t pos4 = posbase | lane4;
 """, """        __builtin_amdgcn_sched_barrier(0);
         const prnb::Words W = philox_count_row(ph, quad_hi, quad_lo, k0, k1);
-        const uint32_t pos4 = posbase | lane4;
         __builtin_amdgcn_sched_barrier(0);
-        s = cinfo[1].s; posbase = cinfo[1].pos_base;
+        s = cinfo[1].s;
         ph[0] = cinfo[1].ph[0]; ph[1] = cinfo[1].ph[1]; ph[2] = cinfo[1].ph[2]; ph[3] = cinfo[1].ph[3];
         ++cinfo;
         __builtin_amdgcn_sched_barrier(0);
 """),
         ("""        s = s_next;
         ph[0] = ph_next[0]; ph[1] = ph_next[1]; ph[2] = ph_next[2]; ph[3] = ph_next[3];
-        posbase = posbase_next;
 """, ""),
     ],
     # round 4: the shipped kernel held at four / three blocks per CU by LDS padding (what the fifth block is worth)
@@ -171,18 +159,15 @@ VARIANTS = {
         ("""        const Seg nn = load_seg(row2);
         const uint64_t row3 = cinfo[3].row_bytes;
         const float s_next = cinfo[1].s;
-        const uint32_t posbase_next = cinfo[1].pos_base;
         const uint32_t ph_next[4] = {cinfo[1].ph[0], cinfo[1].ph[1], cinfo[1].ph[2], cinfo[1].ph[3]};
         ++cinfo;
         __builtin_amdgcn_sched_barrier(0);
         const prnb::Words W = philox_count_row(ph, quad_hi, quad_lo, k0, k1);
-        const uint32_t pos4 = posbase | lane4;
 """, """        const prnb::Words W = philox_count_row(ph, quad_hi, quad_lo, k0, k1);
-        const uint32_t pos4 = posbase | lane4;
         __builtin_amdgcn_sched_barrier(0);
         cur = load_seg(row2);
         row2 = cinfo[2].row_bytes;
-        s = cinfo[1].s; posbase = cinfo[1].pos_base;
+        s = cinfo[1].s;
         ph[0] = cinfo[1].ph[0]; ph[1] = cinfo[1].ph[1]; ph[2] = cinfo[1].ph[2]; ph[3] = cinfo[1].ph[3];
         ++cinfo;
         __builtin_amdgcn_sched_barrier(0);
@@ -192,7 +177,6 @@ VARIANTS = {
         row2 = row3;
         s = s_next;
         ph[0] = ph_next[0]; ph[1] = ph_next[1]; ph[2] = ph_next[2]; ph[3] = ph_next[3];
-        posbase = posbase_next;
 """, ""),
         ("    Seg cur = load_seg(cinfo[0].row_bytes), nxt = load_seg(cinfo[1].row_bytes);\n    uint64_t row2 = cinfo[2].row_bytes;",
          "    Seg cur = load_seg(cinfo[0].row_bytes);\n    uint64_t row2 = cinfo[1].row_bytes;"),
@@ -218,8 +202,14 @@ VARIANTS = {
     # instructions moved from the "everything else" side to the binary32 side, count unchanged or higher
     "svgpr": [SVGPR],
     "theta2": [THETA2],
-    "posf": POSF,
-    "pipes3": [SVGPR, THETA2] + POSF,
+    # C2 (5 000 x 5 000): strips of a fixed number of cells, whatever the problem size
+    "c2strip10": [("    g.strips = (n + g.strip_cells - 1) / g.strip_cells;", "    g.strip_cells = 10;\n    g.strips = (n + g.strip_cells - 1) / g.strip_cells;")],
+    "c2strip12": [("    g.strips = (n + g.strip_cells - 1) / g.strip_cells;", "    g.strip_cells = 12;\n    g.strips = (n + g.strip_cells - 1) / g.strip_cells;")],
+    "c2strip16": [("    g.strips = (n + g.strip_cells - 1) / g.strip_cells;", "    g.strip_cells = 16;\n    g.strips = (n + g.strip_cells - 1) / g.strip_cells;")],
+    "c2strip20": [("    g.strips = (n + g.strip_cells - 1) / g.strip_cells;", "    g.strip_cells = 20;\n    g.strips = (n + g.strip_cells - 1) / g.strip_cells;")],
+    "c2strip24": [("    g.strips = (n + g.strip_cells - 1) / g.strip_cells;", "    g.strip_cells = 24;\n    g.strips = (n + g.strip_cells - 1) / g.strip_cells;")],
+    "c2strip32": [("    g.strips = (n + g.strip_cells - 1) / g.strip_cells;", "    g.strip_cells = 32;\n    g.strips = (n + g.strip_cells - 1) / g.strip_cells;")],
+    "c2strip40": [("    g.strips = (n + g.strip_cells - 1) / g.strip_cells;", "    g.strip_cells = 40;\n    g.strips = (n + g.strip_cells - 1) / g.strip_cells;")],
     # one reciprocal for 1/u1 and 1/theta: r = rcp(u1 * th), 1/u1 = r * th, 1/th = r * u1 (a transcendental less, two multiplies more)
     "rcp1": [("    h.iu = hw_rcp(u1);\n    h.t2 = m * (hw_log2(u1) * hw_rcp(u1 - 1.0f));",
               "    const float th_ = u1 - 1.0f;\n    const float r_ = hw_rcp(u1 * th_);\n    h.iu = r_ * th_;\n    h.t2 = m * (hw_log2(u1) * (r_ * u1));")],

@@ -34,6 +34,18 @@ def main():
              float(X[:4096].double().mean())))
     q = np.percentile(count[rest], [50, 90, 99]) if rest.any() else [0, 0, 0]
     print("   unfinished walks: count percentiles 50/90/99 = %d/%d/%d" % tuple(q))
+    if heavy.any():
+        # parameters of the gamma-Poisson class: which branches of K3h its samples take
+        hc, hg = cells[heavy], genes[heavy]
+        M = means.cpu().numpy()
+        m = (M[np.asarray(rows)[hc], hg].astype(np.float64) * np.asarray(sc, dtype=np.float64)[hc])
+        theta = np.asarray(work.alpha, dtype=np.float64)[hg] * m + np.asarray(work.beta, dtype=np.float64)[hg] - 1.0
+        r = m / theta
+        cnt = count[heavy]
+        print("   gamma-Poisson class: theta > 16: %.1f %%; shape r = m/theta < 1: %.1f %%; m percentiles 10/50/90 = %.1f/%.1f/%.1f; "
+              "theta 10/50/90 = %.1f/%.1f/%.1f; counts: 0: %.1f %%, < 10: %.1f %%, mean %.1f"
+              % (100.0 * (theta > 16).mean(), 100.0 * (r < 1).mean(), *np.percentile(m, [10, 50, 90]), *np.percentile(theta, [10, 50, 90]),
+                 100.0 * (cnt == 0).mean(), 100.0 * (cnt < 10).mean(), cnt.mean()))
 
 
 if __name__ == "__main__":
