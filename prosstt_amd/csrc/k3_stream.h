@@ -309,10 +309,12 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
     const uint32_t inv47_lds = (uint32_t)(uintptr_t)&inv_k[4];
     auto stage3_pass = [&]() {
         if (idle_s != 0ull && s2_top > 0) {
-            // the idle lanes take the top entries of S2, under exec = (idle and an entry left): loads only
+            // the idle lanes take the top entries of S2 (the lane of rank r the entry left + r), under exec = (idle and an
+            // entry left): loads only.  (The stack's part of every address is formed on the scalar unit.)
+            const int left_ = s2_top - __popcll(idle_s);
+            const int left = left_ > 0 ? left_ : 0;
             const int rank = lane_rank(idle_s);
-            const unsigned long long take_m = idle_s & K3_MASK(rank < s2_top);
-            const uint32_t idx = (uint32_t)(s2_top - 1 - rank);
+            const unsigned long long take_m = idle_s & K3_MASK(rank < s2_top - left);
             asm volatile("s_mov_b64 exec, %[tm]\n\t"
                          "ds_read_b128 %[st], %[ea]\n\t"
                          "ds_read_b32 %[pos], %[pa]\n\t"
@@ -321,10 +323,10 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
                          "s_mov_b64 exec, -1\n\t"
                          "s_waitcnt lgkmcnt(0)"
                          : [st] "+v"(st), [pos] "+v"(pos), [inv] "+v"(inv), [k3] "+v"(k3)
-                         : [tm] "s"(take_m), [ea] "v"(s2_lds + (idx << 4)), [pa] "v"(s2p_lds + (idx << 2)), [ia] "v"(inv47_lds)
+                         : [tm] "s"(take_m), [ea] "v"(((uint32_t)rank << 4) + (s2_lds + ((uint32_t)left << 4))),
+                           [pa] "v"(((uint32_t)rank << 2) + (s2p_lds + ((uint32_t)left << 2))), [ia] "v"(inv47_lds)
                          : "memory");
-            const int left = s2_top - __popcll(idle_s);
-            s2_top = left > 0 ? left : 0;
+            s2_top = left;
             idle_s &= ~take_m;
         }
         const float d = st.y, q = st.z;
@@ -392,14 +394,15 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
         s1_at = top - taken;
         const unsigned long long push_m = walk_m & ~end_m;
         {
-            const uint32_t slot = (uint32_t)s2_top + (uint32_t)lane_rank(push_m);
+            const uint32_t rank = (uint32_t)lane_rank(push_m);
             f32x4 e2;
             e2.x = ps2 * PRNB_FMA(dd, 0.33333334f, qq);      // pmf at k = 3 (the 1/k table's 1/3)
             e2.y = dd;
             e2.z = qq;
             e2.w = r2;
             asm volatile("s_mov_b64 exec, %0\n\tds_write_b128 %1, %2\n\tds_write_b32 %3, %4\n\ts_mov_b64 exec, -1"
-                         :: "s"(push_m), "v"(s2_lds + (slot << 4)), "v"(e2), "v"(s2p_lds + (slot << 2)), "v"(p2) : "memory");
+                         :: "s"(push_m), "v"((rank << 4) + (s2_lds + ((uint32_t)s2_top << 4))), "v"(e2),
+                            "v"((rank << 2) + (s2p_lds + ((uint32_t)s2_top << 2))), "v"(p2) : "memory");
         }
         s2_top += __popcll(push_m);
     };
@@ -413,14 +416,19 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
     const CellInfo* cinfo = cellinfo + n0;                   // wave-uniform running pointers
     const uint32_t lane4 = (uint32_t)lane * 4u;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const int32_t gload = VEC ? (g0 < G ? g0 : G - 4) - gbase : 0;
+    const uint32_t gload_b = VEC ? (uint32_t)((g0 < G ? g0 : G - 4) - gbase) * 4u : 0u;
     const float* const mcol = means + gbase;
     typedef float Seg __attribute__((ext_vector_type(4)));      // (a vector: the two-deep rotation below is then four 64-bit moves)
     auto load_seg = [&](uint64_t row_bytes) -> Seg {
         Seg r;
         const float* rowp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(mcol) + row_bytes);
         if (VEC) {
-            r = *reinterpret_cast<const Seg*>(rowp + gload);
+            // a buffer load: the row address is the resource's base (scalar arithmetic), the lane's byte offset a
+            // loop-invariant register -- no vector add per pass (hipcc forms base + lane offset in a VGPR pair otherwise)
+            typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rowp), 0, 0x7fffffff, 0x00020000);
+            const u32x4_ raw = __builtin_amdgcn_raw_buffer_load_b128(rs, gload_b, 0, 0);
+            r.x = __uint_as_float(raw.x); r.y = __uint_as_float(raw.y); r.z = __uint_as_float(raw.z); r.w = __uint_as_float(raw.w);
         } else {
             r.x = (g0 + 0 < G) ? rowp[lane4 + 0] : 0.0f;
             r.y = (g0 + 1 < G) ? rowp[lane4 + 1] : 0.0f;
