@@ -55,8 +55,8 @@ VARIANTS = {
     "s1_nostore": [S1_ONLY, STORE_OFF],
     "s1_nostore_nophilox": [S1_ONLY, STORE_OFF, PHILOX_OFF],
     # everything, mean segments not loaded (constant means)
-    "noload": [("            r = *reinterpret_cast<const Seg*>(rowp + gload);",
-                "            r = Seg{0.4f, 1.1f, 0.05f, 2.5f}; asm volatile(\"\" :: \"v\"(rowp + gload));")],
+    "noload": [("            const u32x4_ raw = __builtin_amdgcn_raw_buffer_load_b128(rs, gload_b, 0, 0);",
+                "            const u32x4_ raw = {0x3ecccccdu, 0x3f8ccccdu, 0x3d4ccccdu, 0x40200000u}; asm volatile(\"\" :: \"s\"(rs), \"v\"(gload_b));")],
     # everything, rows not stored
     "nostore": [STORE_OFF],
     # K3h without the redo walks / without the gamma-Poisson samples
