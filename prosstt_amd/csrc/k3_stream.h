@@ -188,13 +188,12 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
     // stage-3 lane state: st = {the next term (k = k3 - 3), d = mp - q, q, what is left of wf}; pos; k3 = the walk's
     // group ends at k3 (6, 10, ...).  WHICH lanes walk is wave-level state on the scalar unit (idle_s: bit = the lane
     // holds no walk): a pass takes every mask it forms AND NOT idle_s, so an idle lane may compute on whatever its
-    // registers hold (its k3 keeps growing by 4 per pass: some hundreds by the end of a strip, inside the block's LDS
-    // as a table index), and no vector instruction is spent on asking or marking who is idle.
+    // registers hold, and no vector instruction is spent on asking who is idle.
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     f32x4 st = {0.0f, 0.0f, 0.0f, 0.0f};
     uint32_t pos = 0u;
     int k3 = 6;
-    f32x4 inv = {0.0f, 0.0f, 0.0f, 0.0f};               // 1/(k+1) .. 1/(k+4): read one pass ahead
+    f32x4 inv = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(&inv_k[4], 16));   // 1/(k+1) .. 1/(k+4): read one pass ahead
     unsigned long long idle_s = ~0ull;                   // wave-uniform
 
     // S1/S2 entries carry pos = (cell-in-strip << 8) | gene-in-tile, under the bits of 2^23 (kPosMagic, below)
@@ -306,7 +305,6 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
     // are cleared of idle_s on the scalar unit.
     const uint32_t s2_lds = (uint32_t)(uintptr_t)&L.s2[0];
     const uint32_t s2p_lds = (uint32_t)(uintptr_t)&L.s2p[0];
-    const uint32_t inv47_lds = (uint32_t)(uintptr_t)&inv_k[4];
     auto stage3_pass = [&]() {
         if (idle_s != 0ull && s2_top > 0) {
             // the idle lanes take the top entries of S2 (the lane of rank r the entry left + r), under exec = (idle and an
@@ -318,13 +316,11 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
             asm volatile("s_mov_b64 exec, %[tm]\n\t"
                          "ds_read_b128 %[st], %[ea]\n\t"
                          "ds_read_b32 %[pos], %[pa]\n\t"
-                         "ds_read_b128 %[inv], %[ia]\n\t"
-                         "v_mov_b32 %[k3], 6\n\t"
                          "s_mov_b64 exec, -1\n\t"
                          "s_waitcnt lgkmcnt(0)"
-                         : [st] "+v"(st), [pos] "+v"(pos), [inv] "+v"(inv), [k3] "+v"(k3)
+                         : [st] "+v"(st), [pos] "+v"(pos)
                          : [tm] "s"(take_m), [ea] "v"(((uint32_t)rank << 4) + (s2_lds + ((uint32_t)left << 4))),
-                           [pa] "v"(((uint32_t)rank << 2) + (s2p_lds + ((uint32_t)left << 2))), [ia] "v"(inv47_lds)
+                           [pa] "v"(((uint32_t)rank << 2) + (s2p_lds + ((uint32_t)left << 2)))
                          : "memory");
             s2_top = left;
             idle_s &= ~take_m;
@@ -339,14 +335,17 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
         const float r4 = r3 - ps3;
         const unsigned long long hit_m = K3_MASK(r4 < 0.0f);
         const unsigned long long tail_m = K3_MASK(ps3 < 1.0f);
-        const unsigned long long big_m = K3_MASK(k3 >= kRingMaxK3) & ~idle_s;       // undecided there: the rest of the walk is K3h's
+        const unsigned long long big_m = K3_MASK(k3 >= kRingMaxK3);       // undecided there: the rest of the walk is K3h's (an idle lane rests at 6)
         // the count: k3 less one for each of r1, r2, r3 that is negative (no hit: they are not, and the count is k3)
         const int32_t res_k = (k3 + ((int32_t)prnb::f2u(r1) >> 31) + ((int32_t)prnb::f2u(r2) >> 31)) + ((int32_t)prnb::f2u(r3) >> 31);
         const unsigned long long end_m = (hit_m | tail_m) & ~idle_s;
         deliver(end_m, big_m & ~end_m, pos, (uint32_t)res_k);
         idle_s |= end_m | big_m;                          // done lanes go idle
         st.x = ps3 * PRNB_FMA(d, inv.w, q);
-        k3 += 4;
+        // an idle lane rests at k3 = 6 with the reciprocals of a walk's first group (the read below fetches them again
+        // every pass): a pull then brings only the entry, not a third 16-byte read
+        const int k3n = k3 + 4;
+        asm("v_cndmask_b32 %0, %1, 6, %2" : "=v"(k3) : "v"(k3n), "s"(idle_s));
         st.w = r4;
         inv = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(&inv_k[k3 - 2], 16));   // 1/(k+1..k+4), k = k3 - 3
     };
