@@ -56,7 +56,7 @@ def algorithmic_bytes(n_cells, G, rows):
 
 def kernel_source_sha():
     """Fingerprint of the kernel sources (what a profile is a profile OF): the code of the device translation
-    unit with comments and blank space taken out, so that an edited comment does not orphan a profile."""
+    unit and its Makefile with comments and blank space taken out, so that an edited comment does not orphan a profile."""
     import hashlib
     import re
     h = hashlib.sha256()
@@ -65,6 +65,9 @@ def kernel_source_sha():
         text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)          # block comments
         text = re.sub(r"//[^\n]*", " ", text)                       # line comments (no string of these sources holds //)
         h.update(" ".join(text.split()).encode())
+    # and the flags they are compiled with (the Makefile without its comments)
+    mk = open(os.path.join(ROOT, "prosstt_amd", "csrc", "Makefile"), "r").read()
+    h.update(" ".join(re.sub(r"#[^\n]*", " ", mk).split()).encode())
     return h.hexdigest()[:16]
 
 

@@ -52,12 +52,14 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
 
     int hg_top = 0, hp_top = 0, hl_top = 0;      // wave-uniform
 
-    auto cell_id = [&](int32_t n) -> uint64_t {
+    auto cell_id = [&](int32_t n) __attribute__((always_inline)) -> uint64_t {
         return cell_index ? (uint64_t)cell_index[n] : cell_offset + (uint64_t)n;
     };
 
     // ---- one PTRS attempt (or the whole of the rare small/huge-lambda branches) ---------------
-    auto poisson_pass = [&]() {
+    // (every lambda of this kernel is inlined by force: left to its heuristics at -O2 the compiler keeps some as calls
+    // and their captured state in scratch memory)
+    auto poisson_pass = [&]() __attribute__((always_inline)) {
         const int cnt = hp_top < 64 ? hp_top : 64;
         bool again = false, small = false;
         HPEntry e;
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
     };
 
     // ---- one Marsaglia-Tsang attempt ------------------------------------------------------------
-    auto gamma_pass = [&]() {
+    auto gamma_pass = [&]() __attribute__((always_inline)) {
         const int cnt = hg_top < 64 ? hg_top : 64;
         bool again = false, accepted = false;
         HGEntry e;
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
     int32_t wk = -1;                                  // next term of this lane's walk; -1: idle
     float wps = 0.0f, wrem = 0.0f, wd = 0.0f, wq = 0.0f;         // the next term, the remainder, mp - q, q
     int32_t wn = 0, wg = 0;
-    auto light_start = [&]() {
+    auto light_start = [&]() __attribute__((always_inline)) {
         // idle lanes take entries: parameters, P(X = 0) and the terms k = 0, 1, 2 (the chop-down's first
         // group); a walk that does not end there goes on in light_walk
         const unsigned long long idle_m = __builtin_amdgcn_ballot_w64(wk < 0);
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
             }
         }
     };
-    auto light_walk = [&]() {
+    auto light_walk = [&]() __attribute__((always_inline)) {
         // two groups of four terms for every walking lane (an idle lane computes on zeros).  Most passes of a
         // strip's longest walks end nowhere: one wave-level test then skips everything but the arithmetic.
         const bool busy = wk >= 0;
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
             wrem = b4;
         }
     };
-    auto light_service = [&](bool drain) {
+    auto light_service = [&](bool drain) __attribute__((always_inline)) {
         for (;;) {
             const int busy = __popcll(__builtin_amdgcn_ballot_w64(wk >= 0));
             if (busy <= 32 && (drain ? hl_top > 0 : hl_top >= 32)) light_start();
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
     };
 
     // ---- 64 list entries per wave and step, sorted onto the gamma stack and the redo stack ---------
-    auto feed = [&](bool has, int32_t n, int32_t g) {
+    auto feed = [&](bool has, int32_t n, int32_t g) __attribute__((always_inline)) {
         bool heavy = false, light = false;
         float m = 0.0f;
         if (has) {

@@ -20,7 +20,8 @@ def isa():
         pytest.skip("no hipcc")
     tmp = tempfile.mkdtemp(prefix="prosstt_isa_")
     try:
-        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
+                               "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-fPIC", "-shared",
                                "-fvisibility=hidden", "-save-temps", "-o", os.path.join(tmp, "lib.so"),
                                os.path.join(ROOT, "prosstt_amd", "csrc", "prosstt_amd.hip")],
                               cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)

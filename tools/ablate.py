@@ -30,8 +30,8 @@ S1_ONLY = (RUN_23, "            s1_at = s1_lds;\n        }\n        cur = nxt;")
 PHILOX_OFF = ("        const prnb::Words W = philox_count_row(ph, quad_hi, quad_lo, k0, k1);",
               "        prnb::Words W; W.w[0] = (ph[0] * 2654435761u) ^ ((uint32_t)g0 * 40503u); W.w[1] = W.w[0] * 3u + k0;\n"
               "        W.w[2] = W.w[1] ^ 0x9E3779B9u; W.w[3] = W.w[2] + W.w[0];")
-STORE_OFF = ("__builtin_amdgcn_raw_buffer_store_b128(row4, out_rsrc, store_voff, flush_off, 2 /* nt */);",
-             "__builtin_amdgcn_raw_buffer_store_b128(row4, out_rsrc, 0x80000000u, flush_off, 2 /* nt */);")   # every lane out of range: dropped
+STORE_OFF = ("__builtin_amdgcn_raw_buffer_store_b128(row4, out_rsrc, store_voff, flush_off, 18 /* nt | sc1 */);",
+             "__builtin_amdgcn_raw_buffer_store_b128(row4, out_rsrc, 0x80000000u, flush_off, 18 /* nt | sc1 */);")   # every lane out of range: dropped
 
 K3H_LAUNCH = """    k3::sample_counts_heavy_kernel<<<dim3((unsigned)c->heavy_grid), dim3(k3::kHeavyBlock), 0, c->stream>>>(
         heavy, (uint32_t)geo.regions, (int32_t)geo.strips, (int32_t)geo.strip_cells, A.means, rows, G, A.row_of_cell,
@@ -76,11 +76,11 @@ VARIANTS = {
     # K3h with a device printf of per-phase cycle counts of a few waves (diagnosis; printf costs registers and time)
     "k3h_trace": [("    int hg_top = 0, hp_top = 0, hl_top = 0;      // wave-uniform",
                    "    int hg_top = 0, hp_top = 0, hl_top = 0;      // wave-uniform\n    int np_l = 0, np_w = 0, np_g = 0, np_p = 0; long long T0 = clock64(), TW = 0, TL = 0, TG = 0, TP = 0;"),
-                  ("    auto poisson_pass = [&]() {\n", "    auto poisson_pass = [&]() {\n        ++np_p; const long long tp0 = clock64();\n"),
+                  ("    auto poisson_pass = [&]() __attribute__((always_inline)) {\n", "    auto poisson_pass = [&]() __attribute__((always_inline)) {\n        ++np_p; const long long tp0 = clock64();\n"),
                   ("        hp_top += __popcll(m);\n    };", "        hp_top += __popcll(m);\n        TP += clock64() - tp0;\n    };"),
-                  ("    auto gamma_pass = [&]() {\n", "    auto gamma_pass = [&]() {\n        ++np_g; const long long tg0 = clock64();\n"),
+                  ("    auto gamma_pass = [&]() __attribute__((always_inline)) {\n", "    auto gamma_pass = [&]() __attribute__((always_inline)) {\n        ++np_g; const long long tg0 = clock64();\n"),
                   ("        hp_top += __popcll(mp);\n        while (hp_top >= 64) poisson_pass();", "        hp_top += __popcll(mp);\n        TG += clock64() - tg0;\n        while (hp_top >= 64) poisson_pass();"),
-                  ("    auto light_service = [&](bool drain) {\n        for (;;) {", "    auto light_service = [&](bool drain) {\n        const long long tl0 = clock64();\n        for (;;) {"),
+                  ("    auto light_service = [&](bool drain) __attribute__((always_inline)) {\n        for (;;) {", "    auto light_service = [&](bool drain) __attribute__((always_inline)) {\n        const long long tl0 = clock64();\n        for (;;) {"),
                   ("            if (busy <= 32 && (drain ? hl_top > 0 : hl_top >= 32)) light_start();\n            else if (drain ? busy > 0 : busy > 32) light_walk();\n            else break;\n        }",
                    "            if (busy <= 32 && (drain ? hl_top > 0 : hl_top >= 32)) { light_start(); ++np_l; }\n            else if (drain ? busy > 0 : busy > 32) { light_walk(); ++np_w; }\n            else break;\n        }\n        TL += clock64() - tl0;"),
                   ("    light_service(true);\n    while (hg_top > 0) gamma_pass();\n    while (hp_top > 0) poisson_pass();",
@@ -101,7 +101,7 @@ VARIANTS = {
     "strip128": [("    g.strip_cells = k3::kStripCells / 2;", "    g.strip_cells = k3::kStripCells;")],
     "strip32": [("    g.strip_cells = k3::kStripCells / 2;", "    g.strip_cells = k3::kStripCells / 4;")],
     # plain instead of non-temporal row stores
-    "plainstore": [("store_voff, flush_off, 2 /* nt */);", "store_voff, flush_off, 0);")],
+    "plainstore": [("store_voff, flush_off, 18 /* nt | sc1 */);", "store_voff, flush_off, 0);")],
     # stage 3 waits for 48 / 40 entries (a deeper S2; the block's LDS still allows five per CU)
     "run48": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 48;"), ("constexpr int kS2Cap = 96;", "constexpr int kS2Cap = 112;")],
     "run40": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 40;"), ("constexpr int kS2Cap = 96;", "constexpr int kS2Cap = 104;")],
@@ -215,6 +215,32 @@ VARIANTS = {
               "    const float th_ = u1 - 1.0f;\n    const float r_ = hw_rcp(u1 * th_);\n    h.iu = r_ * th_;\n    h.t2 = m * (hw_log2(u1) * (r_ * u1));")],
 }
 
+# round 4, late (the shipped kernel raises its issue priority to 2 in stages 2 and 3 and stores its rows nt | sc1):
+VARIANTS.update({
+    "prio_off": [("        __builtin_amdgcn_s_setprio(2);           // (see stage2_pass)\n", ""),
+                 ("        __builtin_amdgcn_s_setprio(2);\n        const uint32_t top = s1_at;", "        const uint32_t top = s1_at;")],
+    "store_nt_only": [("store_voff, flush_off, 18 /* nt | sc1 */);", "store_voff, flush_off, 2);")],
+    # the pushes of stage 1 at the raised priority as well
+    "prio_push": [("#pragma unroll\n        for (int h = 0; h < 2; ++h) {\n            uint32_t t0, t1, c_;", "        __builtin_amdgcn_s_setprio(2);\n#pragma unroll\n        for (int h = 0; h < 2; ++h) {\n            uint32_t t0, t1, c_;"),
+                  ("        row2 = row3;\n        s = s_next;", "        __builtin_amdgcn_s_setprio(0);\n        row2 = row3;\n        s = s_next;")],
+    # mean loads with other cache policies (0 shipped; 2 = nt; 1 = sc0; 16 = sc1)
+    "load_aux2": [("__builtin_amdgcn_raw_buffer_load_b128(rs, gload_b, 0, 0);", "__builtin_amdgcn_raw_buffer_load_b128(rs, gload_b, 0, 2);")],
+    "load_aux1": [("__builtin_amdgcn_raw_buffer_load_b128(rs, gload_b, 0, 0);", "__builtin_amdgcn_raw_buffer_load_b128(rs, gload_b, 0, 1);")],
+    "load_aux16": [("__builtin_amdgcn_raw_buffer_load_b128(rs, gload_b, 0, 0);", "__builtin_amdgcn_raw_buffer_load_b128(rs, gload_b, 0, 16);")],
+})
+
+# round 4, late: the order in which the hardware starts the blocks (a permutation of the logical block index: bit-exact)
+_BID = ("    const int32_t tile_g = blockIdx.x / groups;\n    const int32_t strip = (blockIdx.x - tile_g * groups) * 4 + wv;",
+        "    const int32_t tile_g = bid_ / groups;\n    const int32_t strip = (bid_ - tile_g * groups) * 4 + wv;")
+_REG = ("    const uint32_t region = blockIdx.x * 4u + (uint32_t)wv;", "    const uint32_t region = (uint32_t)bid_ * 4u + (uint32_t)wv;")
+def _order(expr):
+    return [("    const int32_t groups = (strips + 3) / 4;\n    const int32_t tile_g", "    const int32_t groups = (strips + 3) / 4;\n    const int32_t bid_ = %s;\n    const int32_t tile_g" % expr), _BID, _REG]
+VARIANTS.update({
+    "order_reverse": _order("(int32_t)(gridDim.x - 1u - blockIdx.x)"),
+    # strip-major: consecutive blocks take the same strips of consecutive gene tiles
+    "order_stripmajor": _order("(int32_t)((blockIdx.x % (gridDim.x / groups)) * groups + blockIdx.x / (gridDim.x / groups))"),
+})
+
 
 def build(name):
     work = os.path.join(OUT, "src_" + name)
@@ -232,7 +258,11 @@ def build(name):
     for fn, text in files.items():
         open(os.path.join(work, "prosstt_amd", "csrc", fn), "w").write(text)
     lib = os.path.join(OUT, "libprosstt_amd_%s.so" % name)
+    # ABLATE_FLAGS="-mllvm -amdgpu-sched-strategy=max-memory-clause" ABLATE_SUFFIX=_maxmem: the same variant under other compiler flags
+    lib = os.path.join(OUT, "libprosstt_amd_%s%s.so" % (name, os.environ.get("ABLATE_SUFFIX", "")))
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
+                           "-mllvm", "-amdgpu-sched-strategy=max-ilp",
+                           *os.environ.get("ABLATE_FLAGS", "").split(),
                            "-fPIC", "-shared", "-fvisibility=hidden", "-o", lib,
                            os.path.join(work, "prosstt_amd", "csrc", "prosstt_amd.hip")])
     shutil.rmtree(work, ignore_errors=True)

@@ -2,7 +2,7 @@
 # Register / LDS use of every kernel of the library, from the code object's own metadata (hipcc -save-temps).
 # usage: tools/kernel_resources.sh > profiles/rNN_kernel_resources.txt
 R="$(cd "$(dirname "$0")/.." && pwd)"; T=$(mktemp -d); cd $T
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -fvisibility=hidden -save-temps \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=max-ilp -fPIC -shared -fvisibility=hidden -save-temps \
     -o $T/lib.so $R/prosstt_amd/csrc/prosstt_amd.hip > /dev/null 2>&1
 python3 - <<PY
 import re, subprocess
