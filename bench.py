@@ -91,7 +91,7 @@ def profiled_traffic():
         return None, "%s was taken on other kernel sources" % name
     vals = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        m = re.search(r"sample_counts_stream_kernel<true>\s+%s\s+([0-9.e+]+)" % counter, text)
+        m = re.search(r"sample_counts_stream_kernel<true(?:, true)?>\s+%s\s+([0-9.e+]+)" % counter, text)
         if not m:
             return None, "%s lacks %s" % (name, counter)
         vals[counter] = float(m.group(1)) * 1024.0
@@ -596,7 +596,7 @@ def assemble_line(args, job, main_case, strong, end_to_end, extras_error):
                    "sum_counts_over_sum_means": round(main_case["ratio"], 5)},
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "k3::sample_counts_stream_kernel<true>", "kernel_ms": kms,
+                     "kernel": "k3::sample_counts_stream_kernel<true, true>", "kernel_ms": kms,
                      "frac_whole_step": abytes / (ms_per_step * 1e-3) / HBM_PEAK,
                      "algorithmic_bytes_per_launch": abytes, "kernel_source_sha": kernel_source_sha(),
                      "note": "frac = algorithmic bytes / the dominant kernel's mean duration (HIP events, max over "

@@ -131,7 +131,10 @@ __device__ __forceinline__ int lane_rank(unsigned long long mask)
                                           __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-template <bool VEC>
+// VEC: 16-byte mean loads and row stores (G, ld multiples of 4, both bases aligned).  BIG: the two settings that pay on a
+// problem of full-length strips whose output does not fit the last-level cache and cost 6 % each on a small one (C2:
+// 8-cell strips, 100 MB of counts) -- the raised issue priority of stages 2 and 3, and system scope on the row stores.
+template <bool VEC, bool BIG>
 __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
     const float* __restrict__ means, int32_t G, const CellInfo* __restrict__ cellinfo,
     const float* __restrict__ ga, const float* __restrict__ gbm1, const float* __restrict__ gphi,
@@ -220,11 +223,13 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
         const int32_t v[4] = {(int32_t)(packed & 0xffu), (int32_t)((packed >> 8) & 0xffu),
                               (int32_t)((packed >> 16) & 0xffu), (int32_t)(packed >> 24)};
         if (VEC) {
-            // non-temporal, system scope (nt sc1): the matrix is written once; keeping it out of L2 leaves that to the mean
-            // tensor (nt: -3.8 % on C3 against a plain store; sc1 on top: -0.4 %)
+            // non-temporal (and system scope when BIG): the matrix is written once; keeping it out of L2 leaves that to the
+            // mean tensor (nt: -3.8 % on C3 against a plain store; sc1 on top: -0.4 % on C3, +6 % on C2, whose 100 MB of counts
+            // the last-level cache takes)
             typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
             const u32x4_ row4 = {(uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]};
-            __builtin_amdgcn_raw_buffer_store_b128(row4, out_rsrc, store_voff, flush_off, 18 /* nt | sc1 */);
+            if (BIG) __builtin_amdgcn_raw_buffer_store_b128(row4, out_rsrc, store_voff, flush_off, 18 /* nt | sc1 */);
+            else __builtin_amdgcn_raw_buffer_store_b128(row4, out_rsrc, store_voff, flush_off, 2 /* nt */);
         } else {
             int32_t* dst = strip_out + (int64_t)cl * ld + lane * 4;
 #pragma unroll
@@ -307,7 +312,7 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
     const uint32_t s2_lds = (uint32_t)(uintptr_t)&L.s2[0];
     const uint32_t s2p_lds = (uint32_t)(uintptr_t)&L.s2p[0];
     auto stage3_pass = [&]() {
-        __builtin_amdgcn_s_setprio(2);           // (see stage2_pass)
+        if (BIG) __builtin_amdgcn_s_setprio(2);           // (see stage2_pass)
         if (idle_s != 0ull && s2_top > 0) {
             // the idle lanes take the top entries of S2 (the lane of rank r the entry left + r), under exec = (idle and an
             // entry left): loads only.  (The stack's part of every address is formed on the scalar unit.)
@@ -350,7 +355,7 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
         asm("v_cndmask_b32 %0, %1, 6, %2" : "=v"(k3) : "v"(k3n), "s"(idle_s));
         st.w = r4;
         inv = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(&inv_k[k3 - 2], 16));   // 1/(k+1..k+4), k = k3 - 3
-        __builtin_amdgcn_s_setprio(0);
+        if (BIG) __builtin_amdgcn_s_setprio(0);
     };
 
     // ---- stage 2: P(X = 0), class test, then the terms k = 0, 1, 2, for up to 64 entries of S1 -------
@@ -364,8 +369,9 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
         // every wave-level test below is a lane mask formed outside divergent control flow.
         // The passes of stages 2 and 3 run at a raised issue priority: they are chains of dependent instructions behind
         // LDS reads, and a wave that gets through them sooner is back in stage 1, where the vector pipe is fed
-        // (-0.8 % of the call; the same priority for stage 1 instead: +1.6 % -- profiles/r04_ablation.txt section 7)
-        __builtin_amdgcn_s_setprio(2);
+        // (-0.8 % of the call on C3; the same priority for stage 1 instead: +1.6 %; on C2's 8-cell strips +6 %, hence BIG --
+        // profiles/r04_ablation.txt section 7)
+        if (BIG) __builtin_amdgcn_s_setprio(2);
         const uint32_t top = s1_at;
         int32_t at_c = (int32_t)(top - lane16p);                               // byte address of this lane's entry
         if (!kFull) at_c = at_c > (int32_t)(s1_lds - 16u) ? at_c : (int32_t)(s1_lds - 16u);      // s1[-1] is s1_null: invalid
@@ -411,7 +417,7 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
                             "v"((rank << 2) + (s2p_lds + ((uint32_t)s2_top << 2))), "v"(p2) : "memory");
         }
         s2_top += __popcll(push_m);
-        __builtin_amdgcn_s_setprio(0);
+        if (BIG) __builtin_amdgcn_s_setprio(0);
     };
 #undef K3_MASK
 

@@ -844,14 +844,17 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
     }
     const dim3 grid((unsigned)(geo.groups * geo.tiles_g)), block(k3::kBlock);
     if (ev_start) HIP_TRY(hipEventRecord(ev_start, c->stream));    // the dominant kernel is timed alone
-    if (vec)
-        k3::sample_counts_stream_kernel<true><<<grid, block, 0, c->stream>>>(
-            A.means, G, cellinfo, A.ga, A.gbm1, A.gphi, N, k0, k1, d_out, ld_out, (int32_t)geo.strips,
-            (int32_t)geo.strip_cells, heavy);
-    else
-        k3::sample_counts_stream_kernel<false><<<grid, block, 0, c->stream>>>(
-            A.means, G, cellinfo, A.ga, A.gbm1, A.gphi, N, k0, k1, d_out, ld_out, (int32_t)geo.strips,
-            (int32_t)geo.strip_cells, heavy);
+    // full-length strips and more counts than the last-level cache (256 MB) takes: k3_stream.h, BIG
+    const bool big = geo.strip_cells >= k3::kStripCells / 2 && (double)N * (double)ld_out * 4.0 >= 1073741824.0;
+#define K3_LAUNCH(V, B)                                                                                          \
+    k3::sample_counts_stream_kernel<V, B><<<grid, block, 0, c->stream>>>(                                        \
+        A.means, G, cellinfo, A.ga, A.gbm1, A.gphi, N, k0, k1, d_out, ld_out, (int32_t)geo.strips,             \
+        (int32_t)geo.strip_cells, heavy)
+    if (vec && big) K3_LAUNCH(true, true);
+    else if (vec) K3_LAUNCH(true, false);
+    else if (big) K3_LAUNCH(false, true);
+    else K3_LAUNCH(false, false);
+#undef K3_LAUNCH
     HIP_TRY(hipGetLastError());
     if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, c->stream));
     // every wave takes whole regions of the list; as many blocks as the device holds at once (6 per CU: 1536 --

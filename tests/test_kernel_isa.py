@@ -44,7 +44,7 @@ def _meta(text, mangled_part, key):
     raise AssertionError(mangled_part)
 
 
-@pytest.mark.parametrize("kernel", ["sample_counts_stream_kernelILb1", "sample_counts_stream_kernelILb0"])
+@pytest.mark.parametrize("kernel", ["sample_counts_stream_kernelILb1ELb1E", "sample_counts_stream_kernelILb0ELb0E", "sample_counts_stream_kernelILb1ELb0E"])
 def test_stream_kernel_memory_operations_are_global(isa, kernel):
     # a late 4-byte store must land after its row's 16-byte store: global_* and buffer_* operations of a wave are
     # performed in issue order, flat_* are not (k3_stream.h, flush_late)
@@ -54,14 +54,14 @@ def test_stream_kernel_memory_operations_are_global(isa, kernel):
 
 
 def test_stream_kernel_rows_are_stored_non_temporally_and_nothing_spills(isa):
-    body = _body(isa, "sample_counts_stream_kernelILb1")
+    body = _body(isa, "sample_counts_stream_kernelILb1ELb1E")
     assert re.search(r"buffer_store_dwordx4 .* offen nt\b", body)       # rows: the row in soffset, the lane's 16 bytes in voffset
-    assert _meta(isa, "sample_counts_stream_kernelILb1", "private_segment_fixed_size") == 0
-    assert _meta(isa, "sample_counts_stream_kernelILb1", "vgpr_spill_count") == 0
+    assert _meta(isa, "sample_counts_stream_kernelILb1ELb1E", "private_segment_fixed_size") == 0
+    assert _meta(isa, "sample_counts_stream_kernelILb1ELb1E", "vgpr_spill_count") == 0
     # five blocks of 256 threads per CU (the fifth is worth 11 %: profiles/r04_ablation.txt): 96 VGPRs and
     # 32 KB of LDS each at most
-    assert _meta(isa, "sample_counts_stream_kernelILb1", "vgpr_count") <= 96
-    assert _meta(isa, "sample_counts_stream_kernelILb1", "group_segment_fixed_size") <= 32 * 1024
+    assert _meta(isa, "sample_counts_stream_kernelILb1ELb1E", "vgpr_count") <= 96
+    assert _meta(isa, "sample_counts_stream_kernelILb1ELb1E", "group_segment_fixed_size") <= 32 * 1024
     # packed binary32 instructions take two issue slots and cost moves to pair their operands (-fno-slp-vectorize)
     assert "v_pk_mul_f32" not in body and "v_pk_add_f32" not in body and "v_pk_fma_f32" not in body
 
@@ -83,7 +83,7 @@ def _sgpr_set(tok):
     return {tok}
 
 
-@pytest.mark.parametrize("kernel", ["sample_counts_stream_kernelILb1", "sample_counts_heavy_kernel"])
+@pytest.mark.parametrize("kernel", ["sample_counts_stream_kernelILb1ELb1E", "sample_counts_heavy_kernel"])
 def test_no_hand_written_valu_reads_a_mask_straight_behind_the_valu_that_wrote_it(isa, kernel):
     """gfx950: a VALU instruction that reads an SGPR (vcc, exec) as data within two instructions of the VALU
     instruction that wrote it sees the old value (tools/cmpx_probe.hip).  The compiler separates such pairs in its

@@ -30,8 +30,9 @@ S1_ONLY = (RUN_23, "            s1_at = s1_lds;\n        }\n        cur = nxt;")
 PHILOX_OFF = ("        const prnb::Words W = philox_count_row(ph, quad_hi, quad_lo, k0, k1);",
               "        prnb::Words W; W.w[0] = (ph[0] * 2654435761u) ^ ((uint32_t)g0 * 40503u); W.w[1] = W.w[0] * 3u + k0;\n"
               "        W.w[2] = W.w[1] ^ 0x9E3779B9u; W.w[3] = W.w[2] + W.w[0];")
-STORE_OFF = ("__builtin_amdgcn_raw_buffer_store_b128(row4, out_rsrc, store_voff, flush_off, 18 /* nt | sc1 */);",
-             "__builtin_amdgcn_raw_buffer_store_b128(row4, out_rsrc, 0x80000000u, flush_off, 18 /* nt | sc1 */);")   # every lane out of range: dropped
+STORE_2 = """            if (BIG) __builtin_amdgcn_raw_buffer_store_b128(row4, out_rsrc, store_voff, flush_off, 18 /* nt | sc1 */);
+            else __builtin_amdgcn_raw_buffer_store_b128(row4, out_rsrc, store_voff, flush_off, 2 /* nt */);"""
+STORE_OFF = (STORE_2, STORE_2.replace("store_voff", "0x80000000u"))   # every lane out of range: dropped
 
 K3H_LAUNCH = """    k3::sample_counts_heavy_kernel<<<dim3((unsigned)c->heavy_grid), dim3(k3::kHeavyBlock), 0, c->stream>>>(
         heavy, (uint32_t)geo.regions, (int32_t)geo.strips, (int32_t)geo.strip_cells, A.means, rows, G, A.row_of_cell,
@@ -101,7 +102,7 @@ VARIANTS = {
     "strip128": [("    g.strip_cells = k3::kStripCells / 2;", "    g.strip_cells = k3::kStripCells;")],
     "strip32": [("    g.strip_cells = k3::kStripCells / 2;", "    g.strip_cells = k3::kStripCells / 4;")],
     # plain instead of non-temporal row stores
-    "plainstore": [("store_voff, flush_off, 18 /* nt | sc1 */);", "store_voff, flush_off, 0);")],
+    "plainstore": [(STORE_2, "            __builtin_amdgcn_raw_buffer_store_b128(row4, out_rsrc, store_voff, flush_off, 0);")],
     # stage 3 waits for 48 / 40 entries (a deeper S2; the block's LDS still allows five per CU)
     "run48": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 48;"), ("constexpr int kS2Cap = 96;", "constexpr int kS2Cap = 112;")],
     "run40": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 40;"), ("constexpr int kS2Cap = 96;", "constexpr int kS2Cap = 104;")],
@@ -217,9 +218,14 @@ VARIANTS = {
 
 # round 4, late (the shipped kernel raises its issue priority to 2 in stages 2 and 3 and stores its rows nt | sc1):
 VARIANTS.update({
-    "prio_off": [("        __builtin_amdgcn_s_setprio(2);           // (see stage2_pass)\n", ""),
-                 ("        __builtin_amdgcn_s_setprio(2);\n        const uint32_t top = s1_at;", "        const uint32_t top = s1_at;")],
-    "store_nt_only": [("store_voff, flush_off, 18 /* nt | sc1 */);", "store_voff, flush_off, 2);")],
+    "prio_off": [("        if (BIG) __builtin_amdgcn_s_setprio(2);           // (see stage2_pass)\n", ""),
+                 ("        if (BIG) __builtin_amdgcn_s_setprio(2);\n        const uint32_t top = s1_at;", "        const uint32_t top = s1_at;")],
+    "store_nt_only": [(STORE_2, "            __builtin_amdgcn_raw_buffer_store_b128(row4, out_rsrc, store_voff, flush_off, 2);")],
+    "prio_off_nt_only": [("        if (BIG) __builtin_amdgcn_s_setprio(2);           // (see stage2_pass)\n", ""),
+                         ("        if (BIG) __builtin_amdgcn_s_setprio(2);\n        const uint32_t top = s1_at;", "        const uint32_t top = s1_at;"),
+                         (STORE_2, "            __builtin_amdgcn_raw_buffer_store_b128(row4, out_rsrc, store_voff, flush_off, 2);")],
+    "prio1": [("        if (BIG) __builtin_amdgcn_s_setprio(2);           // (see stage2_pass)\n", "        __builtin_amdgcn_s_setprio(1);\n"),
+              ("        if (BIG) __builtin_amdgcn_s_setprio(2);\n        const uint32_t top = s1_at;", "        __builtin_amdgcn_s_setprio(1);\n        const uint32_t top = s1_at;")],
     # the pushes of stage 1 at the raised priority as well
     "prio_push": [("#pragma unroll\n        for (int h = 0; h < 2; ++h) {\n            uint32_t t0, t1, c_;", "        __builtin_amdgcn_s_setprio(2);\n#pragma unroll\n        for (int h = 0; h < 2; ++h) {\n            uint32_t t0, t1, c_;"),
                   ("        row2 = row3;\n        s = s_next;", "        __builtin_amdgcn_s_setprio(0);\n        row2 = row3;\n        s = s_next;")],
