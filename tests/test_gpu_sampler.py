@@ -317,6 +317,28 @@ def test_chunking_offset_and_determinism(ctx):
     assert abs(ratio - 1) < 2e-3
 
 
+@pytest.mark.parametrize("G", [20000, 20001])      # 16-byte rows / the scalar-layout path (G % 4 != 0)
+def test_one_big_call_equals_its_small_chunks(ctx, G):
+    """A call with full-length strips and at least 1 GiB of counts runs the stream kernel's BIG instantiation
+    (raised issue priority in stages 2 and 3, system-scope row stores: k3_stream.h); the same cells in chunks under
+    that size run the other one.  Counts are a pure function of (inputs, seed, global cell index): equal, bit for bit."""
+    import torch
+    N = 13500                                        # N * G * 4 = 1.08e9 bytes >= 2^30
+    means, roc, sc, al, be = synthetic(33, 200, G, N, heavy_frac=0.002)
+    full = ctx.sample_counts(means, roc, sc, al, be, seed=4321, cell_offset=5)
+    start = 0
+    for size in (6000, 6000, 1500):                  # <= 0.48e9 bytes each
+        sl = slice(start, start + size)
+        part = ctx.sample_counts(means, roc[sl], sc[sl], al, be, seed=4321, cell_offset=5 + start)
+        assert torch.equal(full[sl], part)
+        del part
+        start += size
+    assert start == N
+    mu = torch.as_tensor(means, device=full.device)[torch.as_tensor(roc, device=full.device).long()] \
+        * torch.as_tensor(sc, device=full.device, dtype=torch.float32)[:, None]
+    assert abs(float(full.sum(dtype=torch.float64) / mu.sum(dtype=torch.float64)) - 1) < 2e-3
+
+
 def test_row_index_outside_the_tensor_is_reported(ctx):
     """A row_of_cell entry outside the mean tensor: the checked mode reports it (EINVAL), nothing is read
     or written outside the tensor in either mode."""
