@@ -247,6 +247,16 @@ VARIANTS.update({
     "order_stripmajor": _order("(int32_t)((blockIdx.x % (gridDim.x / groups)) * groups + blockIdx.x / (gridDim.x / groups))"),
 })
 
+# round 4, late: issue priority inside K3h
+VARIANTS.update({
+    "k3h_prio_walk": [("        const bool busy = wk >= 0;\n        const float* tab", "        __builtin_amdgcn_s_setprio(2);\n        const bool busy = wk >= 0;\n        const float* tab"),
+                      ("            wrem = b4;\n        }\n    };", "            wrem = b4;\n        }\n        __builtin_amdgcn_s_setprio(0);\n    };")],
+    "k3h_prio_gp": [("        const int cnt = hp_top < 64 ? hp_top : 64;\n        bool again = false, small = false;", "        __builtin_amdgcn_s_setprio(2);\n        const int cnt = hp_top < 64 ? hp_top : 64;\n        bool again = false, small = false;"),
+                    ("        hp_top += __popcll(m);\n    };", "        hp_top += __popcll(m);\n        __builtin_amdgcn_s_setprio(0);\n    };"),
+                    ("        const int cnt = hg_top < 64 ? hg_top : 64;\n        bool again = false, accepted = false;", "        __builtin_amdgcn_s_setprio(2);\n        const int cnt = hg_top < 64 ? hg_top : 64;\n        bool again = false, accepted = false;"),
+                    ("        hp_top += __popcll(mp);\n        while (hp_top >= 64) poisson_pass();", "        hp_top += __popcll(mp);\n        __builtin_amdgcn_s_setprio(0);\n        while (hp_top >= 64) poisson_pass();")],
+})
+
 
 def build(name):
     work = os.path.join(OUT, "src_" + name)
