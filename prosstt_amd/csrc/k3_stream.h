@@ -141,7 +141,9 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
     int64_t N, uint32_t k0, uint32_t k1, int32_t* __restrict__ out, int64_t ld, int32_t strips,
     int32_t strip_cells, HeavyList heavy)
 {
-    // 1/k for k = -4 .. kInvTab-1: 0 below k = 1 (never used: an idle stage-3 lane reads anywhere in the block's LDS)
+    // LDS of a block: 30 304 B.  gfx950 hands it out in 1 280-byte granules, so the five blocks per CU that the kernel's
+    // speed rests on (the fifth: -11 %) fit as long as a block stays at or under 32 000 B (measured: 32 352 B gives four).
+    // 1/k for k = -4 .. kInvTab-1: 0 below k = 1 (never used below 1: an idle stage-3 lane rests at k3 = 6)
     __shared__ __attribute__((aligned(16))) float inv_k_store[4 + kInvTab];
     float* const inv_k = inv_k_store + 4;
     __shared__ WaveLds lds_all[kBlock / 64];
