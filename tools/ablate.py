@@ -257,6 +257,13 @@ VARIANTS.update({
                     ("        hp_top += __popcll(mp);\n        while (hp_top >= 64) poisson_pass();", "        hp_top += __popcll(mp);\n        __builtin_amdgcn_s_setprio(0);\n        while (hp_top >= 64) poisson_pass();")],
 })
 
+# round 4, late: the two scheduling barriers around stage 1's load block left to the (max-ilp) scheduler
+VARIANTS.update({
+    "no_sched_barriers": [("        __builtin_amdgcn_sched_barrier(0);\n        const Seg nn = load_seg(row2);", "        const Seg nn = load_seg(row2);"),
+                          ("        ++cinfo;\n        __builtin_amdgcn_sched_barrier(0);\n        const prnb::Words W", "        ++cinfo;\n        const prnb::Words W")],
+    "no_sched_barrier_2": [("        ++cinfo;\n        __builtin_amdgcn_sched_barrier(0);\n        const prnb::Words W", "        ++cinfo;\n        const prnb::Words W")],
+})
+
 
 def build(name):
     work = os.path.join(OUT, "src_" + name)
