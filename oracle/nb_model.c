@@ -130,10 +130,14 @@ static inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t
 }
 /* the count sampler: Philox4x32-7, the fewest rounds that pass BigCrush (Salmon et al. 2011, table 2) */
 #define PRNB_COUNT_ROUNDS 7
+/* Rounds the sampler's draws use.  PRNB_COUNT_ROUNDS is the definition; prnb_set_count_rounds exists for ONE purpose:
+ * the joint-law tests draw the same matrix with 10 rounds (the library default of Random123) and hold its statistics of
+ * independence beside those of the 7-round definition (tests/test_joint_law.py). */
+static int g_count_rounds = PRNB_COUNT_ROUNDS;
 static inline void philox_count(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                 uint32_t k0, uint32_t k1, uint32_t out[4])
 {
-    philox4x32_r(PRNB_COUNT_ROUNDS, c0, c1, c2, c3, k0, k1, out);
+    philox4x32_r(g_count_rounds, c0, c1, c2, c3, k0, k1, out);
 }
 
 /* ---- deterministic binary32 math ----------------------------------------- */
@@ -412,6 +416,8 @@ PRNB_EXPORT void prnb_philox_rounds(int rounds, const uint32_t ctr[4], const uin
 }
 
 PRNB_EXPORT int prnb_count_rounds(void) { return PRNB_COUNT_ROUNDS; }
+/* test-only (see g_count_rounds): 0 restores the definition's round count */
+PRNB_EXPORT void prnb_set_count_rounds(int rounds) { g_count_rounds = rounds > 0 ? rounds : PRNB_COUNT_ROUNDS; }
 
 /* Install (or, with NULL pointers, remove) the tables of the three hardware functions -- see the comment at hw_rcp.
  * The arrays stay the caller's and must outlive their use. */

@@ -32,6 +32,8 @@ def lib():
         L.prnb_philox_rounds.argtypes = [ctypes.c_int, _u32p, _u32p, _u32p]
         L.prnb_philox_rounds.restype = None
         L.prnb_count_rounds.restype = ctypes.c_int
+        L.prnb_set_count_rounds.argtypes = [ctypes.c_int]
+        L.prnb_set_count_rounds.restype = None
         L.prnb_math.argtypes = [ctypes.c_int, _f32p, _f32p, ctypes.c_int64]
         L.prnb_sample_counts.argtypes = [_f32p, ctypes.c_int64, ctypes.c_int32, _i32p, _f64p, _f64p,
                                          _f64p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64,
@@ -73,6 +75,20 @@ def philox_rounds(rounds, ctr, key):
 def count_rounds():
     """Rounds of the Philox4x32 generator behind the count sampler."""
     return lib().prnb_count_rounds()
+
+
+class philox_rounds_for_draws:
+    """``with philox_rounds_for_draws(10): ...`` -- the model's draws with another round count (the joint-law tests hold
+    the 10-round matrix beside the 7-round definition's); the definition's count is restored on exit."""
+
+    def __init__(self, rounds):
+        self.rounds = int(rounds)
+
+    def __enter__(self):
+        lib().prnb_set_count_rounds(self.rounds)
+
+    def __exit__(self, *exc):
+        lib().prnb_set_count_rounds(0)
 
 
 MATH = dict(rcp=0, log=1, log1p=2, exp=3, cos2pi=4, unif=5, log1pmx=6)

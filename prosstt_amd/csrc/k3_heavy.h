@@ -75,14 +75,14 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
             } else if (lam < prnb::kPoisInv) {
                 small = true;                      // walked below, all such lanes side by side
             } else if (!(lam < prnb::kLamBig)) {
-                const prnb::Words w = prnb::philox_count(c0, c1, (uint32_t)e.g, 0x80000000u, k0, k1);
+                const prnb::Words w = prnb::philox_count<0>(c0, c1, (uint32_t)e.g, 0x80000000u, k0, k1);
                 const float z = prnb::det_sqrt(-2.0f * prnb::det_log(prnb::unif(w.w[0]))) * prnb::det_cos2pi(w.w[1]);
                 const float kf = __builtin_floorf(PRNB_FMA(prnb::det_sqrt(lam), z, lam) + 0.5f);
                 x = (int32_t)__builtin_fminf(__builtin_fmaxf(kf, 0.0f), 2147483520.0f);
             } else {
                 const int j = e.attempt;
                 const prnb::Words w =
-                    prnb::philox_count(c0, c1, (uint32_t)e.g, 0x80000000u + (uint32_t)(j >> 1), k0, k1);
+                    prnb::philox_count<0>(c0, c1, (uint32_t)e.g, 0x80000000u + (uint32_t)(j >> 1), k0, k1);
                 const float slam = prnb::det_sqrt(lam);
                 const float bb = PRNB_FMA(2.53f, slam, 0.931f);
                 const float aa = PRNB_FMA(0.02483f, bb, -0.059f);
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
         if (__builtin_amdgcn_ballot_w64(small) != 0ull) {
             // lambda under 10: inversion (the chop-down of prnb_device.h with q = 0)
             const uint64_t cell = cell_id(e.n);
-            const prnb::Words w = prnb::philox_count((uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)e.g, 0x80000000u, k0, k1);
+            const prnb::Words w = prnb::philox_count<0>((uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)e.g, 0x80000000u, k0, k1);
             const float lam = small ? e.lam : 1.0f;
             const int32_t xs = prnb::chop_down_wave(small, w.w[0], prnb::det_exp(-lam), lam, 0.0f, inv_k);
             if (small) x = xs;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
                 const float cc = prnb::det_rcp(3.0f * prnb::det_sqrt(dd));
                 const int i = e.attempt;
                 const bool last = (i == prnb::kMaxTries - 1);
-                const prnb::Words w = prnb::philox_count((uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)e.g,
+                const prnb::Words w = prnb::philox_count<0>((uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)e.g,
                                                           1u + (uint32_t)i, k0, k1);
                 const float x = prnb::det_sqrt(-2.0f * prnb::det_log(prnb::unif(w.w[0]))) * prnb::det_cos2pi(w.w[1]);
                 const float t = cc * x;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
         hl_top -= idle < hl_top ? idle : hl_top;
         const prnb::Params P = prnb::make_params_m(e.m, ga[e.g], gbm1[e.g]);
         const uint64_t cell = cell_id(e.n);
-        const prnb::Words w = prnb::philox_count((uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)e.g >> 2, 0u, k0, k1);
+        const prnb::Words w = prnb::philox_count<0>((uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)e.g >> 2, 0u, k0, k1);
         const uint32_t sel = (uint32_t)e.g & 3u;
         const uint32_t wj = sel == 0u ? w.w[0] : (sel == 1u ? w.w[1] : (sel == 2u ? w.w[2] : w.w[3]));
         const float mp = P.m * P.iu, q = P.theta * P.iu, d = mp - q;

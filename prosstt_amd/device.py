@@ -44,7 +44,7 @@ class Context:
             self.device, ctypes.c_void_p(self.stream.cuda_stream), ctypes.byref(handle)))
         self._h = handle
         self._checked_means = None      # (pointer, rows, G, token) of the mean tensor whose row flags the ctx holds
-        self._nonneg_cache = {}         # device alpha / beta tensors already verified (see _params_nonneg)
+        self._nonneg_seen = [None, None]   # (tensor, _version, verdict) of the device alpha / beta last looked at (see _params_nonneg)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -120,27 +120,31 @@ class Context:
             key = (means.data_ptr(), rows, G, means_token)
             if means_token is not None and key == self._checked_means:
                 flags |= _native.MEANS_CACHED
-            self._checked_means = key if N and G else None
+            self._checked_means = None              # the ctx holds this tensor's row flags only once the call has gone through
         _native.check(self._lib.prosstt_amd_sample_counts(
             self._h, _ptr(means), rows, G, _ptr(row_of_cell), _ptr(scaling), _ptr(alpha), _ptr(beta),
             N, ctypes.c_uint64(seed & (2 ** 64 - 1)), ctypes.c_uint64(cell_offset), _ptr(cell_index),
             _ptr(out), out.stride(0) if N else G, flags))
+        if check_domain and N and G and means_token is not None:
+            self._checked_means = key
         return out
 
     def _params_nonneg(self, alpha, beta):
         """alpha >= 0 and beta >= 1 for every gene (then alpha*m + beta < 1 cannot happen and the checked call
-        skips its per-sample pass).  Host arrays are looked at here (O(G)); device tensors once per
-        (storage, version) -- torch counts their in-place edits."""
+        skips its per-sample pass).  Host arrays are looked at here (O(G)).  A device tensor is looked at once per
+        (tensor OBJECT, version): the verdict is remembered beside a strong reference to the tensor itself and reused
+        only for that very object (``is``) while torch's count of its in-place edits stands -- never by address, which
+        the caching allocator hands to the next tensor.  Writes that bypass torch (a raw pointer in another
+        library) are not seen; ``check_domain=True`` with host arrays, or a fresh tensor, forces a new look."""
         torch = _torch()
         verdicts = []
-        for arr, floor in ((alpha, 0.0), (beta, 1.0)):
+        for slot, (arr, floor) in enumerate(((alpha, 0.0), (beta, 1.0))):
             if isinstance(arr, torch.Tensor):
-                key = (arr.data_ptr(), arr.numel(), arr._version, floor)
-                if key not in self._nonneg_cache:
-                    if len(self._nonneg_cache) > 64:
-                        self._nonneg_cache.clear()
-                    self._nonneg_cache[key] = bool((arr >= floor).all()) if arr.numel() else True
-                verdicts.append(self._nonneg_cache[key])
+                seen = self._nonneg_seen[slot]
+                if seen is None or seen[0] is not arr or seen[1] != arr._version:
+                    seen = (arr, arr._version, bool((arr >= floor).all()) if arr.numel() else True)
+                    self._nonneg_seen[slot] = seen
+                verdicts.append(seen[2])
             else:
                 a = np.asarray(arr)
                 verdicts.append(bool(np.all(a >= floor)))

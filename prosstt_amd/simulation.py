@@ -466,15 +466,23 @@ def sample_density_chunks(tree, no_cells, chunk_cells, alpha=0.3, beta=2, scale=
         return ctx.sample_counts(means, rows[lo:hi], scalings[lo:hi], alpha, beta, seed=seed, cell_offset=lo,
                                  check_domain="deferred" if strict else False, means_token=token)
 
+    # The verdict of the deferred domain check is sticky in the ctx and covers every chunk enqueued so far (an invalid
+    # chunk i + 1 may already be reported with chunk i: the plan is one call).  Whatever ends the generator -- exhaustion,
+    # an exception of the host copy, the consumer dropping it -- leaves no verdict behind for an unrelated later call.
     pending = launch(0) if no_cells else None
-    for lo in range(0, no_cells, chunk_cells):
-        hi = min(lo + chunk_cells, no_cells)
-        counts = pending
-        pending = launch(hi) if hi < no_cells else None      # enqueued behind `counts`, runs under its copy
-        host = counts if out == "torch" else _to_host(counts, _HOST_DTYPES[out])
-        if strict:
-            ctx.domain_status()
-        yield host, sample_time[lo:hi], sample_branches[lo:hi], scalings[lo:hi]
+    try:
+        for lo in range(0, no_cells, chunk_cells):
+            hi = min(lo + chunk_cells, no_cells)
+            counts = pending
+            pending = launch(hi) if hi < no_cells else None      # enqueued behind `counts`, runs under its copy
+            host = counts if out == "torch" else _to_host(counts, _HOST_DTYPES[out])
+            if strict:
+                ctx.domain_status()
+            yield host, sample_time[lo:hi], sample_branches[lo:hi], scalings[lo:hi]
+        pending = None
+    finally:
+        if strict and pending is not None:
+            _discard_verdict(ctx)
 
 
 def sample_whole_tree(tree, n_factor, alpha=0.3, beta=2, scale=True, scale_mean=0., scale_v=0.7,
@@ -573,10 +581,23 @@ def draw_counts(tree, pseudotime, branches, scalings, alpha, beta, *, seed=None,
         if strict:
             ctx.domain_status()
         return counts
-    host = _to_host(counts, _HOST_DTYPES[out])
+    try:
+        host = _to_host(counts, _HOST_DTYPES[out])
+    except BaseException:
+        if strict:
+            _discard_verdict(ctx)       # (an OverflowError of "numpy16", a failed page-lock: the call's verdict must not outlive it)
+        raise
     if strict:
         ctx.domain_status()
     return host
+
+
+def _discard_verdict(ctx):
+    """Read and clear the sticky verdict of deferred domain checks whose call is being abandoned."""
+    try:
+        ctx.domain_status()
+    except (ValueError, RuntimeError):
+        pass
 
 
 def add_non_diff_genes(inform_expr_matrix, genes, gene_params, cell_scalings, *, seed=None):

@@ -11,12 +11,16 @@ reference keep working.  What is new sits behind the same names:
  * ``add_genes(relative_means, base)`` evaluates ``exp(rel) * base``
    (tree.py:181-182) with the ``means_from_rel`` HIP kernel.
 """
+import itertools
 from collections import defaultdict
 
 import numpy as np
 import pandas as pd
 
 from . import device as _device
+
+# every device mean tensor of the process gets its own number (Tree.means_token)
+_DEVICE_TENSOR_SERIAL = itertools.count(1)
 
 
 class Tree(object):
@@ -37,7 +41,7 @@ class Tree(object):
         self.branches = list(time.keys())
         self._host_means = None        # dict label -> (T_b, G) float64, or None
         self._dev_means = None         # torch float32 (sum T_b, G), or None
-        self._dev_version = 0          # counts the device tensors this tree has had (see means_token)
+        self._dev_version = 0          # serial number of the device tensor this tree holds now (see means_token)
         self._dev_print = None         # fingerprint of _host_means when _dev_means was made from / mirrored to it
         self._lineage = None           # device cache left by simulate_lineage
         self._resident = None          # branches whose rows this process holds (None: all; see parallel.simulate_lineage_sharded)
@@ -193,7 +197,7 @@ class Tree(object):
                 tiny = np.float32(1.17549435e-38)      # positive means stay positive in binary32 (see means_from_rel)
                 as32[(stacked > 0) & (as32 < tiny)] = tiny
                 self._dev_means = ctx.tensor(as32, torch.float32)     # a private copy goes up
-                self._dev_version += 1
+                self._dev_version = next(_DEVICE_TENSOR_SERIAL)
                 self._dev_print = now
         if self._dev_means is None:
             raise ValueError("the tree has no gene expression yet: call add_genes first")
@@ -203,7 +207,9 @@ class Tree(object):
         """Changes whenever the content of ``device_means()`` does (a new upload or a new ``add_genes``): what the
         sampler's domain check keys its cached per-row flags of the mean tensor on."""
         self.device_means()            # compares the host fingerprint, uploads if the caller edited tree.means
-        return (id(self), self._dev_version)
+        # a process-wide serial number, never reused: (id(tree), per-tree count) can repeat when a tree is freed and the
+        # next one lands on the same address with its tensor on the same device address (ADVICE r4)
+        return ("means", self._dev_version)
 
     def add_genes(self, *args):
         """tree.py:154-163: one dict of average expression, or (relative means, base array)."""
@@ -230,7 +236,7 @@ class Tree(object):
         rel = sim._device_rel(self, relative_means)
         base = ctx.tensor(np.asarray(base_gene_expr, dtype=np.float64), torch.float64)
         self._dev_means = ctx.means_from_rel(rel, base)
-        self._dev_version += 1
+        self._dev_version = next(_DEVICE_TENSOR_SERIAL)
         self._host_means = None
         self._dev_print = None
 

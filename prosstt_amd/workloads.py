@@ -7,6 +7,7 @@ examples/generate_simN.py:91-113 of the reference scaled up):
     C2  single bifurcation (3 branches),   5k cells x    5k genes
     C3  8-branch tree,                    50k cells x   20k genes   <- the headline metric
     C4  32-branch tree,                  200k cells x   20k genes
+    T32 the same 32-branch tree,          50k cells x   20k genes   <- north_star's target shape on ONE GPU
     C5  256-branch tree,                   1M cells x   30k genes
 
 ``np.random.seed(seed)`` precedes the topology; ``np.random.seed(seed + 1)`` precedes the
@@ -26,6 +27,9 @@ CONFIGS = {
     "C2": dict(kind="bifurcation", T=50, G=5000, K=25, N=5000, seed=42),
     "C3": dict(kind="random", branch_points=3, T=50, G=20000, K=25, N=50000, seed=2024),
     "C4": dict(kind="random", branch_points=15, T=50, G=20000, K=25, N=200000, seed=2025),
+    # north_star: ">= 40 % HBM roofline on 50k cells x 20k genes x 32-branch tree on 1 MI355X" -- C4's tree (same seed,
+    # hence the same topology, lineage and mean tensor), C3's cell count
+    "T32": dict(kind="random", branch_points=15, T=50, G=20000, K=25, N=50000, seed=2025),
     "C5": dict(kind="binary", depth=7, T=50, G=30000, K=25, N=1000000, seed=2026),
 }
 

@@ -61,3 +61,48 @@ def test_accuracy_and_model_lookup():
         pick = rng.choice(len(bits), 2000, replace=False)
         dev = np.array([ctx.hw_math(op, int(b), 1)[0] for b in bits[pick[:200]]])
         assert np.array_equal(dev, nb_model.hw_math(op, x[pick[:200]]))
+
+
+def test_every_table_entry_against_binary64(capsys):
+    """What protects the LAW once the hardware functions are part of the definition: every entry of the three tables the
+    model was given (2^23 + 4.2e7 + 2.4e8 values -- all the sampler can present) against binary64 libm, host-side:
+    rcp within 1.5e-7, log2 within 2e-7 (relative; log2(1) == 0 exactly), exp2(-x) within 2e-7; exp2(-x) non-increasing in
+    x (the zero test's slack argument leans on it).  The tables' digests go into the test log so that two boxes (or two
+    microcode levels) can be compared."""
+    import hashlib
+    from oracle import nb_model
+    assert nb_model.hw_mode()
+    tabs = nb_model._HW_TABLES
+    worst = {}
+    step = 1 << 24
+    for op, (first, count) in nb_model.HW_RANGES.items():
+        t = tabs[op]
+        assert t.shape == (count,) and np.isfinite(t).all()
+        err = 0.0
+        for lo in range(0, count, step):
+            hi = min(lo + step, count)
+            x = (np.arange(lo, hi, dtype=np.uint32) + np.uint32(first)).view(np.float32).astype(np.float64)
+            y = t[lo:hi].astype(np.float64)
+            if op == "rcp":
+                e = np.abs(y * x - 1.0)
+            elif op == "log2":
+                ref = np.log2(x)
+                if lo == 0:
+                    assert y[0] == 0.0                      # log2(1)
+                    e = np.abs(y[1:] - ref[1:]) / ref[1:]
+                else:
+                    e = np.abs(y - ref) / ref
+            else:
+                e = np.abs(y / np.exp2(-x) - 1.0)
+            err = max(err, float(e.max()))
+        worst[op] = err
+    assert worst["rcp"] < 1.5e-7 and worst["log2"] < 2e-7 and worst["exp2neg"] < 2e-7, worst
+    ex = tabs["exp2neg"]
+    for lo in range(0, ex.size - 1, step):
+        seg = ex[lo:min(lo + step + 1, ex.size)]
+        assert (seg[1:] <= seg[:-1]).all(), "v_exp_f32(-x) increases somewhere in table entries %d.." % lo
+    assert ex[0] <= 1.0
+    digest = {op: hashlib.sha256(tabs[op].tobytes()).hexdigest()[:16] for op in tabs}
+    with capsys.disabled():
+        print("\n[hw tables] worst relative error vs binary64: rcp %.3g, log2 %.3g, exp2neg %.3g; sha256[:16]: %s"
+              % (worst["rcp"], worst["log2"], worst["exp2neg"], digest))

@@ -8,6 +8,8 @@ ctx = device.get_context()
 w = workloads.build(cfg)
 pt, br, sc, rows = w.plan(int(os.environ["KBENCH_CELLS"]) if "KBENCH_CELLS" in os.environ else (125000 if cfg == "C5" else None))
 sc = sc * float(os.environ.get('KBENCH_SCALE', '1'))
+if os.environ.get("KBENCH_SORT") == "1":
+    o = np.argsort(rows, kind="stable"); rows, sc = np.asarray(rows)[o], np.asarray(sc)[o]
 G = w.tree.G
 dm = w.tree.device_means(); dr = ctx.tensor(rows, torch.int32); ds = ctx.tensor(sc, torch.float64)
 da = ctx.tensor(w.alpha, torch.float64); db = ctx.tensor(w.beta, torch.float64)

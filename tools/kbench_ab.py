@@ -17,6 +17,8 @@ BURST = int(os.environ.get("KBENCH_BURST", "1"))
 ctx0 = device.get_context()
 w = workloads.build(cfg)
 pt, br, sc, rows = w.plan(int(os.environ["KBENCH_CELLS"]) if "KBENCH_CELLS" in os.environ else (125000 if cfg == "C5" else None))
+if os.environ.get("KBENCH_SORT") == "1":      # diagnosis: cells in the order of their rows of the mean tensor
+    o = np.argsort(rows, kind="stable"); rows, sc = np.asarray(rows)[o], np.asarray(sc)[o]
 G = w.tree.G
 dm = w.tree.device_means(); dr = ctx0.tensor(rows, torch.int32); ds = ctx0.tensor(sc, torch.float64)
 da = ctx0.tensor(w.alpha, torch.float64); db = ctx0.tensor(w.beta, torch.float64)

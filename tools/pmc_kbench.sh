@@ -14,9 +14,9 @@ for d in ("a","b","c","d"):
     for f in glob.glob("$O/%s/**/*counter_collection.csv" % d, recursive=True):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0][-34:]
-            if "sample_counts" in k: agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            k = r["Kernel_Name"].split("(")[0]
+            if "sample_counts" in k: agg[k[-40:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in agg.items():
-            for c, xs in sorted(v.items()): print("%-36s %-24s %.6g  (n=%d)" % (k, c, sum(xs)/len(xs), len(xs)))
+            for c, xs in sorted(v.items()): print("%-42s %-24s %.6g  (n=%d)" % (k, c, sum(xs)/len(xs), len(xs)))
 PY
 cat $O/summary.txt

@@ -2,7 +2,7 @@ import sys; sys.path.insert(0, '.')
 import numpy as np, torch
 from prosstt_amd import device, workloads
 ctx = device.get_context()
-w = workloads.build("C3")
+w = workloads.build(sys.argv[1] if len(sys.argv) > 1 else "C3")
 pt, br, sc, rows = w.plan(2000)
 mu, p, r, path = ctx.nb_params(w.tree.device_means(), rows, sc, w.alpha, w.beta)
 mu = mu.flatten(); path = path.flatten(); theta = (p/(1-p)).flatten()
