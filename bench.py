@@ -318,6 +318,15 @@ def run_case(job, config, scaling, cells_per_gpu, steps, warmup, strict_steps, g
         mine, _ = parallel.shard_cells(br, rank, world)
 
     means = tree.device_means()
+    # The step is the device part of the call simulation.draw_counts makes: the rank's cells PRESENTED grouped by their row
+    # of the mean tensor (a host-side counting sort of the plan, prosstt_amd_plan_order: part of planning, like the row index
+    # itself), every count keyed by the cell's position in the global plan (cell_index) -- so the matrix in HBM holds the counts
+    # of an unordered call, bit for bit, its rows in the order of presentation; draw_counts puts them back in plan order inside
+    # its copy to the host (end_to_end_ms includes that).  --plain-order presents the cells as planned (ms_per_step_plan_order).
+    from prosstt_amd import device as _dev
+    mine = np.asarray(mine, dtype=np.int64)
+    if not job.args.plain_order:
+        mine = mine[_dev.plan_order(rows[mine], means.shape[0])]
     d_rows = ctx.tensor(rows[mine], torch.int32)
     d_sc = ctx.tensor(sc[mine], torch.float64)
     d_al = ctx.tensor(work.alpha, torch.float64)
@@ -379,6 +388,25 @@ def run_case(job, config, scaling, cells_per_gpu, steps, warmup, strict_steps, g
             step(i, strict=False)
         job.fence()
         res["ms_unchecked"] = job.max_over_ranks(time.perf_counter() - t0) / strict_steps * 1e3
+
+    # the same steps with the cells presented in the order of the plan (what a caller who does not group them gets)
+    res["ms_plan_order"] = None
+    if strict_steps > 0 and not job.args.plain_order:
+        plain = np.sort(mine)
+        p_rows, p_sc, p_idx = ctx.tensor(rows[plain], torch.int32), ctx.tensor(sc[plain], torch.float64), ctx.tensor(plain, torch.int64)
+
+        def plain_step(seed):
+            ctx.sample_counts(means, p_rows, p_sc, d_al, d_be, seed=seed, out=out, cell_index=p_idx, check_domain="deferred",
+                              means_token=token)
+        plain_step(98)
+        job.fence()
+        t0 = time.perf_counter()
+        for i in range(strict_steps):
+            plain_step(i)
+        ctx.domain_status()
+        job.fence()
+        res["ms_plan_order"] = job.max_over_ranks(time.perf_counter() - t0) / strict_steps * 1e3
+        step(97)                      # (leaves `out` as the timed steps wrote it: the sanity check below goes by d_rows)
 
     # sanity inside the bench: first moment of this rank's shard (catches a silently dead kernel)
     mu_sum = float((means.double().sum(dim=1)[d_rows.long()] * d_sc).sum())
@@ -448,6 +476,9 @@ def main():
                          "(the line still goes out with 'extras_error'; default: exit code 0)")
     ap.add_argument("--no-target-shape", action="store_true",
                     help="skip the extra case on north_star's own target shape (T32: 32-branch tree, 50k x 20k; N = 1, default C3 run)")
+    ap.add_argument("--plain-order", action="store_true",
+                    help="present the cells in the order of the plan instead of grouped by mean-tensor row (what a caller who "
+                         "does not order its cells gets; simulation.draw_counts groups them)")
     ap.add_argument("--no-end-to-end", action="store_true",
                     help="skip the end-to-end time of the drop-in sample_density call (N = 1)")
     args = ap.parse_args()
@@ -593,7 +624,8 @@ def assemble_line(args, job, main_case, strong, end_to_end, extras_error):
         "metric": "simulated cells*genes per second (count sampling: sample_density -> draw_counts)",
         "value": main_case["value"], "unit": "cells*genes/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "ms_per_step_strict": ms_per_step,
-        "ms_per_step_unchecked": main_case["ms_unchecked"], "ms_per_step_cold": main_case["ms_cold"],
+        "ms_per_step_unchecked": main_case["ms_unchecked"], "ms_per_step_plan_order": main_case.get("ms_plan_order"),
+        "ms_per_step_cold": main_case["ms_cold"],
         "higher_is_better": True,
         "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %d-branch tree (T=50, K=25), %d genes, %d cells per GPU "
@@ -605,6 +637,9 @@ def assemble_line(args, job, main_case, strong, end_to_end, extras_error):
                    "lineage_sharded_by_genes": bool(work.info["sharded"]),
                    "clock_ramp": "%d untimed passes (%.0f ms) before the %d warmup steps" % (main_case["ramp_calls"], args.ramp_ms, args.warmup),
                    "cold_steps": 5,
+                   "presentation": "plan order" if args.plain_order else
+                                   "cells grouped by mean-tensor row (simulation.draw_counts' call: prosstt_amd_plan_order); rows of "
+                                   "the matrix in that order, put back in plan order inside the copy to the host",
                    "sum_counts_over_sum_means": round(main_case["ratio"], 5)},
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,

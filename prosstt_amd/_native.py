@@ -19,7 +19,7 @@ HOST_INPUTS, HOST_OUTPUT, CHECK_DOMAIN, TIME_KERNEL, CHECK_DEFERRED, MEANS_CACHE
 SYMBOLS = [
     "prosstt_amd_version", "prosstt_amd_last_error", "prosstt_amd_device_count",
     "prosstt_amd_ctx_create", "prosstt_amd_ctx_destroy", "prosstt_amd_ctx_synchronize",
-    "prosstt_amd_last_kernel_ms", "prosstt_amd_sample_counts", "prosstt_amd_last_list", "prosstt_amd_nb_params",
+    "prosstt_amd_last_kernel_ms", "prosstt_amd_sample_counts", "prosstt_amd_plan_order", "prosstt_amd_last_list", "prosstt_amd_nb_params",
     "prosstt_amd_hw_math", "prosstt_amd_domain_status", "prosstt_amd_numpy_programs",
     "prosstt_amd_lineage_attempt", "prosstt_amd_lineage_attempt_batch", "prosstt_amd_lineage_walk",
     "prosstt_amd_lineage_walk_batch",
@@ -67,6 +67,7 @@ def load():
         L.prosstt_amd_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
         L.prosstt_amd_sample_counts.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp, i64, u64, u64,
                                                 vp, vp, i64, u32]
+        L.prosstt_amd_plan_order.argtypes = [vp, i64, i64, vp]
         L.prosstt_amd_last_list.argtypes = [vp, vp, vp, i64, ctypes.POINTER(i64), ctypes.POINTER(i32)]
         L.prosstt_amd_nb_params.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp, u32]
         L.prosstt_amd_hw_math.argtypes = [vp, i32, u32, u64, vp, u32]

@@ -798,6 +798,21 @@ PA_EXPORT int prosstt_amd_domain_status(prosstt_amd_ctx* c, int32_t* status)
     return (rc == PROSSTT_AMD_EHIP) ? rc : 0;     // the verdict travels in *status; the message is in last_error
 }
 
+PA_EXPORT int prosstt_amd_plan_order(const int32_t* row_of_cell, int64_t N, int64_t rows, int32_t* order)
+{
+    if (N < 0 || rows < 0 || N > 0x7fffffffll) return fail(PROSSTT_AMD_EINVAL, "bad size");
+    if (N > 0 && (!row_of_cell || !order)) return fail(PROSSTT_AMD_EINVAL, "NULL argument");
+    std::vector<int64_t> first((size_t)rows + 1, 0);
+    for (int64_t n = 0; n < N; ++n) {
+        if (row_of_cell[n] < 0 || row_of_cell[n] >= rows)
+            return fail(PROSSTT_AMD_EINVAL, "row_of_cell[%lld] = %d outside [0,%lld)", (long long)n, row_of_cell[n], (long long)rows);
+        first[(size_t)row_of_cell[n] + 1] += 1;
+    }
+    for (int64_t r = 0; r < rows; ++r) first[(size_t)r + 1] += first[(size_t)r];
+    for (int64_t n = 0; n < N; ++n) order[first[(size_t)row_of_cell[n]]++] = (int32_t)n;
+    return 0;
+}
+
 PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, int64_t rows, int32_t G,
                                         const int32_t* row_of_cell, const double* scaling,
                                         const double* alpha, const double* beta, int64_t N,

@@ -271,6 +271,19 @@ class Context:
         return out
 
 
+def plan_order(row_of_cell, rows=None):
+    """int32 array ``order``: the cells grouped by their row of the mean tensor (stable): the order of presentation that
+    keeps a gene tile's rows of the mean tensor in cache (prosstt_amd_plan_order; host arrays, no device work).  Present
+    cell ``order[i]`` at position i with ``cell_index[i]`` = its global id; row i of the result is that cell's."""
+    roc = np.ascontiguousarray(row_of_cell, dtype=np.int32)
+    order = np.empty(roc.size, dtype=np.int32)
+    if roc.size:
+        n_rows = int(roc.max()) + 1 if rows is None else int(rows)
+        _native.check(_native.load().prosstt_amd_plan_order(
+            roc.ctypes.data_as(ctypes.c_void_p), roc.size, n_rows, order.ctypes.data_as(ctypes.c_void_p)))
+    return order
+
+
 def host_fingerprint(arrays):
     """Identity and content fingerprint of host arrays that a device tensor mirrors: the caches of
     ``Tree.device_means`` and of ``simulate_lineage`` compare it before they trust their device copy,
@@ -300,7 +313,7 @@ PINNED_RETURN_MAX = int(os.environ.get("PROSSTT_AMD_PINNED_MAX_BYTES", str(32 <<
 HOST_DTYPES = {"numpy": np.int64, "numpy32": np.int32, "numpy16": np.uint16}
 
 
-def to_host(counts, dtype=np.int64, chunk_bytes=256 << 20):
+def to_host(counts, dtype=np.int64, chunk_bytes=256 << 20, row_order=None):
     """int32 device counts -> host ndarray of ``dtype``: int64 (the reference's return type,
     simulation.py:651), int32 (what the device holds: half the bytes over PCIe) or uint16 (a quarter; raises
     OverflowError if a count does not fit -- counts of scRNA-seq simulations are far below 65 536).
@@ -311,7 +324,12 @@ def to_host(counts, dtype=np.int64, chunk_bytes=256 << 20):
     first-touch page faults; the block goes back to the allocator's cache when the caller drops the array, so
     the pinning cost is paid once per size.  Larger results (or a failed page-lock) take the same chunked path
     into ordinary memory.  int64 and uint16 are converted on the device, chunk by chunk (two staging buffers),
-    under the transfer of the previous chunk; int32 is copied as it lies."""
+    under the transfer of the previous chunk; int32 is copied as it lies.
+
+    row_order: the device matrix holds its cells in an order of PRESENTATION (``plan_order``): row i is cell
+    ``row_order[i]``.  The host array comes back in plan order -- row ``row_order[i]`` = device row i -- the rows of every
+    chunk gathered on the device into the staging buffer that the conversion uses anyway (a gather of whole rows under
+    the transfer of the previous chunk: nothing is added to the PCIe-bound copy)."""
     torch = _torch()
     dtype = np.dtype(dtype)
     n, g = counts.shape
@@ -333,7 +351,15 @@ def to_host(counts, dtype=np.int64, chunk_bytes=256 << 20):
     dev = counts.device
     compute = torch.cuda.current_stream(dev)
     copier = torch.cuda.Stream(dev)
-    convert = t_dtype != torch.int32
+    inv = None
+    if row_order is not None:
+        order = np.asarray(row_order, dtype=np.int64)
+        if order.shape != (n,):
+            raise ValueError("row_order must have one entry per row")
+        inv_host = np.empty(n, dtype=np.int64)
+        inv_host[order] = np.arange(n, dtype=np.int64)        # device row of host row j
+        inv = torch.as_tensor(inv_host).to(dev)
+    convert = t_dtype != torch.int32 or inv is not None
     staging = [torch.empty((rows, g), dtype=t_dtype, device=dev) for _ in range(2 if rows < n else 1)] if convert else []
     copied = [None, None]
     too_big = torch.zeros((), dtype=torch.int32, device=dev) if dtype.itemsize == 2 else None
@@ -346,7 +372,12 @@ def to_host(counts, dtype=np.int64, chunk_bytes=256 << 20):
             stage = staging[slot][:hi - lo]
             if too_big is not None:
                 too_big = torch.maximum(too_big, counts[lo:hi].max())
-            stage.copy_(counts[lo:hi])                      # int32 -> int64, or the low 16 bits
+            if inv is None:
+                stage.copy_(counts[lo:hi])                  # int32 -> int64, or the low 16 bits
+            elif t_dtype == torch.int32:
+                torch.index_select(counts, 0, inv[lo:hi], out=stage)
+            else:
+                stage.copy_(counts.index_select(0, inv[lo:hi]))
         else:
             stage = counts[lo:hi]
         ready = torch.cuda.Event()

@@ -266,8 +266,12 @@ def sample_density_sharded(tree, no_cells, alpha=0.3, beta=2, scale=True, scale_
             assert_replicas_agree(tree, alpha, beta, group)
     ctx = _device.get_context()
     rows = sim.cell_rows(tree, pt[mine], br[mine])
-    counts = ctx.sample_counts(tree.device_means(), rows, sc[mine], alpha, beta, seed=seed, cell_index=mine,
-                               check_domain=strict)
+    # the rank's cells are presented grouped by their row of the mean tensor (simulation.draw_counts says why); row i of
+    # `counts` is the cell at position `mine[i]` of the plan, which is what every consumer of the pair goes by
+    means = tree.device_means()
+    order = _device.plan_order(rows, means.shape[0])
+    mine = np.asarray(mine, dtype=np.int64)[order]
+    counts = ctx.sample_counts(means, rows[order], sc[mine], alpha, beta, seed=seed, cell_index=mine, check_domain=strict)
     return counts, mine, pt, br, sc
 
 

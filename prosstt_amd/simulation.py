@@ -462,9 +462,15 @@ def sample_density_chunks(tree, no_cells, chunk_cells, alpha=0.3, beta=2, scale=
     means = tree.device_means()
 
     def launch(lo):
+        # (presented grouped by mean-tensor row, put back in plan order inside the copy to the host: see draw_counts)
         hi = min(lo + chunk_cells, no_cells)
-        return ctx.sample_counts(means, rows[lo:hi], scalings[lo:hi], alpha, beta, seed=seed, cell_offset=lo,
-                                 check_domain="deferred" if strict else False, means_token=token)
+        if out == "torch":
+            return ctx.sample_counts(means, rows[lo:hi], scalings[lo:hi], alpha, beta, seed=seed, cell_offset=lo,
+                                     check_domain="deferred" if strict else False, means_token=token), None
+        order = _device.plan_order(rows[lo:hi], means.shape[0])
+        return ctx.sample_counts(means, rows[lo:hi][order], scalings[lo:hi][order], alpha, beta, seed=seed,
+                                 cell_index=lo + order.astype(np.int64),
+                                 check_domain="deferred" if strict else False, means_token=token), order
 
     # The verdict of the deferred domain check is sticky in the ctx and covers every chunk enqueued so far (an invalid
     # chunk i + 1 may already be reported with chunk i: the plan is one call).  Whatever ends the generator -- exhaustion,
@@ -473,9 +479,9 @@ def sample_density_chunks(tree, no_cells, chunk_cells, alpha=0.3, beta=2, scale=
     try:
         for lo in range(0, no_cells, chunk_cells):
             hi = min(lo + chunk_cells, no_cells)
-            counts = pending
+            counts, order = pending
             pending = launch(hi) if hi < no_cells else None      # enqueued behind `counts`, runs under its copy
-            host = counts if out == "torch" else _to_host(counts, _HOST_DTYPES[out])
+            host = counts if out == "torch" else _to_host(counts, _HOST_DTYPES[out], row_order=order)
             if strict:
                 ctx.domain_status()
             yield host, sample_time[lo:hi], sample_branches[lo:hi], scalings[lo:hi]
@@ -574,15 +580,25 @@ def draw_counts(tree, pseudotime, branches, scalings, alpha, beta, *, seed=None,
     # the domain check rides in the call's own kernels and is not waited for; its verdict is read behind the copy to the
     # host (which synchronises anyway), or at once when the device tensor itself is returned
     token = tree.means_token()
-    counts = ctx.sample_counts(tree.device_means(), rows, np.asarray(scalings, dtype=np.float64),
-                               np.asarray(alpha, dtype=np.float64), np.asarray(beta, dtype=np.float64),
-                               seed=seed, check_domain="deferred" if strict else False, means_token=token)
+    means = tree.device_means()
+    scalings = np.asarray(scalings, dtype=np.float64)
     if out == "torch":
+        counts = ctx.sample_counts(means, rows, scalings, np.asarray(alpha, dtype=np.float64), np.asarray(beta, dtype=np.float64),
+                                   seed=seed, check_domain="deferred" if strict else False, means_token=token)
         if strict:
             ctx.domain_status()
         return counts
+    # The cells are PRESENTED to the sampler grouped by their row of the mean tensor (every count is keyed by the cell's
+    # position in the plan -- cell_index --, so the matrix is the same whatever the order): the kernel then finds a gene
+    # tile's rows of the mean tensor in cache instead of fetching them once per cell, 2 to 5 % of its time
+    # (profiles/r05_ablation.txt).  The device matrix is in the order of presentation; the copy to the host puts the rows
+    # back in plan order chunk by chunk (a gather on the device, under the transfer of the previous chunk).
+    order = _device.plan_order(rows, means.shape[0])
+    counts = ctx.sample_counts(means, rows[order], scalings[order], np.asarray(alpha, dtype=np.float64),
+                               np.asarray(beta, dtype=np.float64), seed=seed, cell_index=order.astype(np.int64),
+                               check_domain="deferred" if strict else False, means_token=token)
     try:
-        host = _to_host(counts, _HOST_DTYPES[out])
+        host = _to_host(counts, _HOST_DTYPES[out], row_order=order)
     except BaseException:
         if strict:
             _discard_verdict(ctx)       # (an OverflowError of "numpy16", a failed page-lock: the call's verdict must not outlive it)

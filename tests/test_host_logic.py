@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_native.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert _native.load().prosstt_amd_version() == 400
+    assert _native.load().prosstt_amd_version() == 500
 
 
 def test_no_cpu_fallback():
@@ -400,3 +400,14 @@ def test_velocity_and_newick_against_reference_fixtures():
             assert list(time.values()) == [int(v) for v in g["nw_%s_time_vals" % name]]
             assert [branches, bpoints] == g["nw_%s_counts" % name].tolist()
             assert (root or "") == str(g["nw_%s_root" % name])
+
+
+def test_plan_order_is_a_stable_grouping_by_row():
+    """prosstt_amd_plan_order (host helper of the C ABI, no device): the order simulation.draw_counts presents its cells in."""
+    from prosstt_amd import device, _native
+    rng = np.random.default_rng(0)
+    for n, rows in ((0, 5), (1, 1), (1000, 7), (5000, 1600)):
+        roc = rng.integers(0, rows, n).astype(np.int32)
+        assert np.array_equal(device.plan_order(roc, rows), np.argsort(roc, kind="stable"))
+    with pytest.raises(_native.NativeError):
+        device.plan_order(np.array([0, 9], np.int32), 9)
