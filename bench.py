@@ -448,6 +448,33 @@ def time_gather(job, res, out, mine):
         del full
 
 
+def time_pipeline(job, res):
+    """Sampling AND the exchange as one pipeline (parallel.sample_and_gather: chunk c travels to rank 0 while chunk c + 1 is
+    sampled, received straight into final rows): whole-job cells x genes per second WITH the gather -- what a user who wants
+    the matrix on one GPU gets (SURVEY section 8 e).  Bounded like time_gather; timed on RCCL only."""
+    from prosstt_amd import parallel
+    n_total, G, tree, work = res["n_total"], res["G"], res["tree"], res["work"]
+    if job.world == 1 or 4 * n_total * G > 64e9:
+        return
+    seed_of = work.cfg["seed"] + 1
+    np.random.seed(seed_of)
+    if job.backend != "nccl":
+        parallel.sample_and_gather(tree, 1024 * job.world, alpha=work.alpha, beta=work.beta, seed=5, chunk_cells=256)
+        job.fence()
+        res["pipeline_functional"] = 1024 * job.world
+        return
+    parallel.sample_and_gather(tree, 4096, alpha=work.alpha, beta=work.beta, seed=5)       # connections, code paths
+    job.fence()
+    np.random.seed(seed_of)
+    t0 = time.perf_counter()
+    full, _, _, _, _ = parallel.sample_and_gather(tree, n_total, alpha=work.alpha, beta=work.beta, seed=5)
+    job.fence()
+    dt = job.max_over_ranks(time.perf_counter() - t0)
+    res["pipeline_ms"] = dt * 1e3
+    res["value_with_gather"] = n_total * G / dt
+    del full
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -534,6 +561,8 @@ def main():
             if not args.no_gather:
                 time_gather(job, main_case, *main_case["shard"])
             main_case.pop("shard", None)
+            if not args.no_gather:
+                time_pipeline(job, main_case)
             from prosstt_amd import workloads
             sharing = world if os.environ.get("PROSSTT_BENCH_ONE_GPU") == "1" else 1    # ranks on one device (functional test)
             for cfg in [c for c in args.strong_configs.split(",") if c]:
@@ -674,6 +703,14 @@ def assemble_line(args, job, main_case, strong, end_to_end, extras_error):
     if "gather_rows_functional" in main_case:
         line["gather_ms"] = None
         line["gather_note"] = "backend %s: gather exercised on %d rows per rank, not timed" % (job.backend, main_case["gather_rows_functional"])
+    if main_case.get("pipeline_ms") is not None:
+        line["value_with_gather"] = main_case["value_with_gather"]
+        line["pipeline_ms"] = main_case["pipeline_ms"]
+        line["pipeline_note"] = ("parallel.sample_and_gather: host plan + sampling + the exchange to rank 0 as one pipeline "
+                                 "(chunks of 256 MB travel while the next is sampled; rows land in their final place, the "
+                                 "permutation is returned); wall time incl. the host-side plan, max over ranks")
+    if "pipeline_functional" in main_case:
+        line["pipeline_note"] = "backend %s: sample_and_gather exercised on %d cells, not timed" % (job.backend, main_case["pipeline_functional"])
     if strong:
         line["strong_scaling"] = strong
     if end_to_end is not None:

@@ -41,7 +41,8 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
     const float* __restrict__ means, int64_t rows,
     int32_t G, const int32_t* __restrict__ row_of_cell, const float* __restrict__ scal,
     const float* __restrict__ ga, const float* __restrict__ gbm1, int64_t N, uint32_t k0, uint32_t k1,
-    uint64_t cell_offset, const int64_t* __restrict__ cell_index, int32_t* __restrict__ out, int64_t ld)
+    uint64_t cell_offset, const int64_t* __restrict__ cell_index, int32_t* __restrict__ out, int64_t ld,
+    int64_t* __restrict__ check_words, uint32_t check_request, uint32_t check_bad_row, uint32_t check_verdict)
 {
     __shared__ __attribute__((aligned(16))) float inv_k[prnb::kKTab];       // 1/k, k < kKTab (a walk ends at kWalkEnd)
     __shared__ HeavyLds lds_all[kHeavyBlock / 64];
@@ -371,6 +372,24 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
     light_service(true);
     while (hg_top > 0) gamma_pass();
     while (hp_top > 0) poisson_pass();
+
+    // The rest of the reference's argument check (scipy behind simulation.py:647-648), for the calls that ask for it
+    // (check_words: the ctx's flag words; NULL: an unchecked call, or the caller has verified alpha >= 0 and beta >= 1).
+    // The preparation kernel has done the per-cell and per-gene parts and raised check_words[check_request] iff some gene
+    // has alpha < 0 or beta < 1: only then can alpha*m + beta < 1 happen with every mean positive, and only then is the
+    // whole matrix looked at here -- m = M*s <= 0 (or NaN) or alpha*m + beta - 1 < 0 anywhere sets the verdict word.  It
+    // rides in this kernel so that a checked call launches nothing more than an unchecked one.
+    if (check_words && check_words[check_request] != 0 && check_words[check_bad_row] == 0) {
+        const int64_t total = N * (int64_t)G;
+        bool bad = false;
+        for (int64_t i = (int64_t)blockIdx.x * kHeavyBlock + tid; i < total; i += (int64_t)gridDim.x * kHeavyBlock) {
+            const int64_t n = i / G;
+            const int32_t g = (int32_t)(i - n * G);
+            const float m = means[(int64_t)row_of_cell[n] * G + g] * scal[n];
+            bad = bad || !(m > 0.0f) || (PRNB_FMA(ga[g], m, gbm1[g]) < 0.0f);
+        }
+        if (bad) check_words[check_verdict] = 1;
+    }
 }
 
 }  // namespace k3

@@ -6,7 +6,7 @@
 //   k3::sample_counts_stream_kernel + k3::sample_counts_heavy_kernel (k3_stream.h, k3_heavy.h)
 //                           K3: fused gather * scale -> get_pr_umi -> NB draw
 //                           (simulation.py:602-651, count_model.py:131-161)
-//   row_flags_kernel, domain_full_kernel   the rest of scipy's argument check (simulation.py:647-648)
+//   row_flags_kernel        the per-row part of scipy's argument check (simulation.py:647-648); the per-sample part rides in K3h
 //   nb_params_kernel        the deterministic intermediates of the same path
 //   hw_math_kernel          the probe of the three hardware functions of the sampler's definition
 //   lineage_attempt_lds_kernel / lineage_attempt_kernel
@@ -151,7 +151,7 @@ struct Staging {
 // check in the reference fails iff some mean m = M*s is <= 0 (or NaN) or some theta = a*m + b - 1 is < 0.  With every
 // scaling > 0 the first holds iff a USED row of the mean tensor has an entry that is not > 0 (row_bad, from
 // row_flags_kernel); with every a >= 0 and b >= 1 the second cannot happen -- only when a gene has a < 0 or b < 1
-// is the full N x G test needed (flags[kFullReq + parity], read by domain_full_kernel).
+// is the full N x G test needed (flags[kFullReq + parity], read at the end of K3h).
 __global__ void prep_kernel(const double* __restrict__ scaling, int64_t N,
                             const double* __restrict__ alpha, const double* __restrict__ beta, int32_t G,
                             float* __restrict__ scal_f, float* __restrict__ a_f,
@@ -540,23 +540,6 @@ __global__ __launch_bounds__(256) void row_flags_kernel(const float* __restrict_
     }
 }
 
-__global__ void domain_full_kernel(const float* __restrict__ means, int32_t G,
-                                   const int32_t* __restrict__ row_of_cell, const float* __restrict__ scal,
-                                   const float* __restrict__ ga, const float* __restrict__ gbm1, int64_t N,
-                                   int64_t rows, int64_t* __restrict__ flagp, uint32_t parity)
-{
-    if (flagp[kFullReq + parity] == 0 || flagp[kStickyRow] != 0) return;     // (a row index outside the tensor is reported as EINVAL)
-    const int64_t total = N * (int64_t)G;
-    bool bad = false;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t n = i / G;
-        const int32_t g = (int32_t)(i - n * G);
-        const float m = means[(int64_t)row_of_cell[n] * G + g] * scal[n];
-        bad = bad || !(m > 0.0f) || (__builtin_fmaf(ga[g], m, gbm1[g]) < 0.0f);
-    }
-    if (bad) flagp[kStickyDomain] = 1;
-}
-
 // ------------------------------------------------------------------ ABI
 
 PA_EXPORT int prosstt_amd_version(void) { return PROSSTT_AMD_VERSION; }
@@ -853,6 +836,7 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
     const bool vec = (G % 4 == 0) && (ld_out % 4 == 0) && (((uintptr_t)A.means & 15) == 0) &&
                      (((uintptr_t)d_out & 15) == 0);
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const bool checked = (flags & (PROSSTT_AMD_CHECK_DOMAIN | PROSSTT_AMD_CHECK_DEFERRED)) != 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     if (flags & PROSSTT_AMD_TIME_KERNEL) {
         if ((rc = next_event_pair(c, &ev_start, &ev_stop))) return rc;
@@ -876,7 +860,11 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
     // 1024, 2048 and 3072 blocks are 7-18 us slower at C3)
     k3::sample_counts_heavy_kernel<<<dim3((unsigned)c->heavy_grid), dim3(k3::kHeavyBlock), 0, c->stream>>>(
         heavy, (uint32_t)geo.regions, (int32_t)geo.strips, (int32_t)geo.strip_cells, A.means, rows, G, A.row_of_cell,
-        A.scal, A.ga, A.gbm1, N, k0, k1, cell_offset, d_cell_index, d_out, ld_out);
+        A.scal, A.ga, A.gbm1, N, k0, k1, cell_offset, d_cell_index, d_out, ld_out,
+        // the per-sample part of a checked call's domain test rides at the end of K3h (it leaves at once unless a gene has
+        // alpha < 0 or beta < 1: prep_kernel's request word of this call's parity)
+        (checked && !(flags & PROSSTT_AMD_PARAMS_NONNEG)) ? c->scratch : nullptr, (uint32_t)kFullReq + c->call_parity,
+        (uint32_t)kStickyRow, (uint32_t)kStickyDomain);
     HIP_TRY(hipGetLastError());
     c->list = heavy.list;
     c->list_count = heavy.count;
@@ -884,13 +872,6 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
     c->list_cap = heavy.cap;
     c->list_groups = geo.groups;
     c->list_strip_cells = geo.strip_cells;
-    const bool checked = (flags & (PROSSTT_AMD_CHECK_DOMAIN | PROSSTT_AMD_CHECK_DEFERRED)) != 0;
-    if (checked && !(flags & PROSSTT_AMD_PARAMS_NONNEG)) {
-        // (leaves at once unless a gene has alpha < 0 or beta < 1: prep_kernel's request word)
-        domain_full_kernel<<<dim3(8192), dim3(256), 0, c->stream>>>(A.means, G, A.row_of_cell, A.scal, A.ga,
-                                                                  A.gbm1, N, rows, c->scratch, c->call_parity);
-        HIP_TRY(hipGetLastError());
-    }
     c->call_parity ^= 1u;
     if (flags & PROSSTT_AMD_HOST_OUTPUT)   // G columns of every row; the caller's padding beyond G is left alone
         HIP_TRY(hipMemcpy2DAsync(out, (size_t)ld_out * 4, d_out, (size_t)ld_out * 4, (size_t)G * 4, (size_t)N,

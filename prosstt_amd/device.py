@@ -44,7 +44,6 @@ class Context:
             self.device, ctypes.c_void_p(self.stream.cuda_stream), ctypes.byref(handle)))
         self._h = handle
         self._checked_means = None      # (pointer, rows, G, token) of the mean tensor whose row flags the ctx holds
-        self._nonneg_seen = [None, None]   # (tensor, _version, verdict) of the device alpha / beta last looked at (see _params_nonneg)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -130,25 +129,17 @@ class Context:
         return out
 
     def _params_nonneg(self, alpha, beta):
-        """alpha >= 0 and beta >= 1 for every gene (then alpha*m + beta < 1 cannot happen and the checked call
-        skips its per-sample pass).  Host arrays are looked at here (O(G)).  A device tensor is looked at once per
-        (tensor OBJECT, version): the verdict is remembered beside a strong reference to the tensor itself and reused
-        only for that very object (``is``) while torch's count of its in-place edits stands -- never by address, which
-        the caching allocator hands to the next tensor.  Writes that bypass torch (a raw pointer in another
-        library) are not seen; ``check_domain=True`` with host arrays, or a fresh tensor, forces a new look."""
+        """alpha >= 0 and beta >= 1 for every gene, as far as the HOST can tell for free (then alpha*m + beta < 1 cannot
+        happen and the checked call tells the library so: PROSSTT_AMD_PARAMS_NONNEG).  Host arrays are looked at here
+        (O(G)).  Device tensors are not looked at at all: the preparation kernel tests them anyway and the per-sample
+        pass at the end of the call's second kernel runs only if it found a gene with alpha < 0 or beta < 1 -- no torch
+        kernel (whose first use in a process costs tens of milliseconds of code loading: tools/cold_probe.py), no cache
+        of verdicts that could outlive its tensor."""
         torch = _torch()
-        verdicts = []
-        for slot, (arr, floor) in enumerate(((alpha, 0.0), (beta, 1.0))):
-            if isinstance(arr, torch.Tensor):
-                seen = self._nonneg_seen[slot]
-                if seen is None or seen[0] is not arr or seen[1] != arr._version:
-                    seen = (arr, arr._version, bool((arr >= floor).all()) if arr.numel() else True)
-                    self._nonneg_seen[slot] = seen
-                verdicts.append(seen[2])
-            else:
-                a = np.asarray(arr)
-                verdicts.append(bool(np.all(a >= floor)))
-        return all(verdicts)
+        for arr, floor in ((alpha, 0.0), (beta, 1.0)):
+            if isinstance(arr, torch.Tensor) or not bool(np.all(np.asarray(arr) >= floor)):
+                return False
+        return True
 
     def domain_status(self):
         """Raise what the ``check_domain="deferred"`` calls since the last time found (ValueError where the

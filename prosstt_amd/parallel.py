@@ -18,7 +18,9 @@ are independent.  Every rank
   4. keeps its shard on its own device.  There is no collective on the data path; the one
      optional exchange is ``gather_rows``: count rows to rank 0 by point-to-point transfers
      (shards are unequal, so not ncclGather), all senders at once -- each drives its own xGMI
-     link into the root -- in chunks, the scatter of one chunk under the transfer of the next.
+     link into the root -- in chunks, the scatter of one chunk under the transfer of the next;
+     ``sample_and_gather`` is sampling and exchange as one pipeline (chunk c travels while chunk
+     c + 1 is sampled; the root receives straight into final rows and returns the permutation).
 """
 import numpy as np
 
@@ -273,6 +275,146 @@ def sample_density_sharded(tree, no_cells, alpha=0.3, beta=2, scale=True, scale_
     mine = np.asarray(mine, dtype=np.int64)[order]
     counts = ctx.sample_counts(means, rows[order], sc[mine], alpha, beta, seed=seed, cell_index=mine, check_domain=strict)
     return counts, mine, pt, br, sc
+
+
+def presentation_key(tree, pseudotime, branches):
+    """Row of every cell in the mean tensor of the WHOLE tree (branches in ``tree.branches`` order, time inside the
+    branch): what a rank groups its cells by when it presents them to the sampler (``simulation.draw_counts`` says why).
+    The same on every rank, whether or not the rank holds the branch's rows -- so every rank knows the order of every
+    other rank's shard without an exchange."""
+    bt = tree.branch_times()
+    first, at = {}, 0
+    for b in tree.branches:
+        first[b] = at - bt[b][0]
+        at += int(tree.time[b])
+    labels = np.asarray(branches)
+    key = np.asarray(pseudotime, dtype=np.int64).copy()
+    for b in np.unique(labels):
+        key[labels == b] += first[sim._plain_label(tree, b)]
+    return key
+
+
+def shards_in_presentation_order(tree, pseudotime, branches, size):
+    """[cells of rank 0, cells of rank 1, ...]: positions in the plan, each shard in its order of presentation."""
+    key = presentation_key(tree, pseudotime, branches)
+    shards = []
+    for r in range(size):
+        if tree._branch_owner is not None and size > 1:
+            cells = cells_of_rank(branches, tree._branch_owner, r)
+        else:
+            cells = shard_cells(branches, r, size)[0]
+        shards.append(cells[np.argsort(key[cells], kind="stable")])
+    return shards
+
+
+def sample_and_gather(tree, no_cells, alpha=0.3, beta=2, scale=True, scale_v=0.7, scale_mean=0., *, seed=None,
+                      group=None, dst=0, order="shard", chunk_cells=None, chunk_bytes=256 << 20, strict=True):
+    """``sample_density_sharded`` and the one exchange of the path as a PIPELINE (SURVEY section 8 e): every rank samples
+    its cells a chunk at a time and posts chunk c's transfer to rank ``dst`` while chunk c + 1 is being sampled -- the
+    exchange (C4: 14 GB into the root at 7 x 153 GB/s >= 13 ms) is several times the sampling of a rank's share, so the
+    sampling disappears under it instead of preceding it.
+
+    order="shard" (default): the root receives every chunk STRAIGHT INTO ITS FINAL ROWS -- the matrix holds rank 0's
+        cells, then rank 1's, ..., each shard in its order of presentation -- and the permutation comes back instead of a
+        scatter: row i is the cell at position ``cell_of_row[i]`` of the plan.  No staging buffer, no second pass over
+        the matrix on the root (``gather_rows`` lands every row in staging and copies it again).  The layout needs no
+        exchange either: every rank derives every shard from the broadcast plan.
+    order="plan": rows in plan order (row i = cell i), chunks staged and scattered on the root as ``gather_rows`` does,
+        one round behind the transfers.
+
+    Returns ``(counts, cell_of_row, sample_pt, branches, scalings)``; ``counts`` is the (no_cells, G) int32 device
+    tensor on ``dst`` and None elsewhere; ``cell_of_row`` is None for order="plan".  Counts equal the single-process
+    matrix cell for cell (they are keyed by the cell's position in the plan)."""
+    import torch
+    dist = _dist()
+    if order not in ("shard", "plan"):
+        raise ValueError("order must be 'shard' or 'plan'")
+    rank, size = world(group)
+    pt, br = sim._density_plan(tree, no_cells)
+    sc = sut.calc_scalings(no_cells, scale, scale_mean, scale_v)
+    if seed is None:
+        lo32, hi32 = np.random.randint(0, 2 ** 32, size=2, dtype=np.uint64)
+        seed = int(lo32) | (int(hi32) << 32)
+    pt, br, sc, seed = broadcast_plan((pt, br, sc, seed), group)
+    alpha = np.full(tree.G, alpha, np.float64) if np.ndim(alpha) == 0 else np.asarray(alpha, np.float64)
+    beta = np.full(tree.G, beta, np.float64) if np.ndim(beta) == 0 else np.asarray(beta, np.float64)
+    if strict and size > 1 and tree._branch_owner is None:
+        assert_replicas_agree(tree, alpha, beta, group)
+    shards = shards_in_presentation_order(tree, pt, br, size)
+    mine = shards[rank]
+    sizes = [len(c) for c in shards]
+    first_row = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    ctx = _device.get_context()
+    means = tree.device_means()
+    token = tree.means_token()
+    rows = sim.cell_rows(tree, pt[mine], br[mine])
+    G = tree.G
+    dev = ctx.torch_device
+    chunk = int(chunk_cells) if chunk_cells else max(1, int(chunk_bytes) // (4 * G))
+    rounds = (max(sizes) + chunk - 1) // chunk if max(sizes) else 0
+    is_root = rank == dst
+
+    def peer(r):                     # P2POp addresses GLOBAL ranks
+        return dist.get_global_rank(group, r) if group is not None else r
+
+    if is_root:
+        out = torch.empty((no_cells, G), dtype=torch.int32, device=dev)
+        # the root's own cells: straight into their final rows (order="shard"), or a local block scattered at the end
+        local = out[first_row[rank]:first_row[rank] + sizes[rank]] if order == "shard" else \
+            torch.empty((sizes[rank], G), dtype=torch.int32, device=dev)
+    else:
+        out = None
+        local = torch.empty((sizes[rank], G), dtype=torch.int32, device=dev)
+
+    def sample(r):
+        lo, hi = r * chunk, min((r + 1) * chunk, sizes[rank])
+        if lo < hi:
+            ctx.sample_counts(means, rows[lo:hi], sc[mine[lo:hi]], alpha, beta, seed=seed, cell_index=mine[lo:hi],
+                              out=local[lo:hi], check_domain="deferred" if strict else False, means_token=token)
+        return lo, hi
+
+    def post_receives(r):
+        """The root's receives of round r from every sender that still has rows: [(src, lo, hi, buffer)], requests."""
+        got, ops = [], []
+        for src in range(size):
+            lo, hi = r * chunk, min((r + 1) * chunk, sizes[src])
+            if src == dst or lo >= hi:
+                continue
+            buf = out[first_row[src] + lo:first_row[src] + hi] if order == "shard" else \
+                torch.empty((hi - lo, G), dtype=torch.int32, device=dev)
+            got.append((src, lo, hi, buf))
+            ops.append(dist.P2POp(dist.irecv, buf, peer(src), group))
+        return got, (dist.batch_isend_irecv(ops) if ops else [])
+
+    def land(got):
+        if order == "plan":
+            for src, lo, hi, buf in got:
+                out.index_copy_(0, torch.as_tensor(shards[src][lo:hi], dtype=torch.int64, device=dev), buf)
+
+    sends, pending = [], ([], [])
+    for r in range(rounds):
+        lo, hi = sample(r)                                   # enqueued; the transfers below are ordered behind it
+        if size > 1 and not is_root and lo < hi:
+            sends += dist.batch_isend_irecv([dist.P2POp(dist.isend, local[lo:hi], peer(dst), group)])
+        if size > 1 and is_root:
+            got, reqs = pending
+            for req in reqs:
+                req.wait()
+            pending = post_receives(r)                       # round r travels while round r + 1 is sampled
+            land(got)                                        # (order="plan": round r - 1 is scattered under it)
+    for req in sends:
+        req.wait()
+    if is_root:
+        got, reqs = pending
+        for req in reqs:
+            req.wait()
+        land(got)
+        if order == "plan":
+            out.index_copy_(0, torch.as_tensor(mine, dtype=torch.int64, device=dev), local)
+    if strict:
+        ctx.domain_status()
+    cell_of_row = np.concatenate(shards) if order == "shard" else None
+    return out, cell_of_row, pt, br, sc
 
 
 def gather_rows(local_rows, cell_index, total_rows, group=None, dst=0, chunk_rows=None, chunk_bytes=256 << 20,

@@ -42,6 +42,12 @@ sizes = [None] * world
 dist.all_gather_object(sizes, len(mine))
 assert sum(sizes) == N and min(sizes) > 0
 full = parallel.gather_rows(counts, mine, N, chunk_rows=500)
+# sampling and exchange as one pipeline: chunks of 300 cells, received straight into their final rows on rank 0
+np.random.seed(1000 + rank)
+piped, cell_of_row, pt_p, br_p, sc_p = parallel.sample_and_gather(tree, N, alpha=work.alpha, beta=work.beta, seed=11, chunk_cells=300)
+np.random.seed(1000 + rank)
+planned, _, _, _, _ = parallel.sample_and_gather(tree, N, alpha=work.alpha, beta=work.beta, seed=11, chunk_cells=700, order="plan")
+assert np.array_equal(pt_p, pt) and np.array_equal(sc_p, sc) and np.array_equal(np.sort(cell_of_row), np.arange(N))
 if rank == 0:
     np.random.seed(1000)
     pt0, br0 = sim._density_plan(tree, N)
@@ -57,10 +63,12 @@ if rank == 0:
                            whole.device_means()[at[b]:at[b] + int(whole.time[b])])
     want = ctx.sample_counts(whole.device_means(), sim.cell_rows(whole, pt, br), sc, work.alpha, work.beta, seed=11)
     assert torch.equal(full, want), "gathered shards differ from the single-process matrix"
+    assert torch.equal(piped, want[torch.as_tensor(cell_of_row, device=want.device)]), "pipelined gather (order='shard') differs"
+    assert torch.equal(planned, want), "pipelined gather (order='plan') differs"
     assert int(want.sum()) > 0
     print("TWO_RANKS_OK", sizes, int(want.sum()), flush=True)
 else:
-    assert full is None
+    assert full is None and piped is None and planned is None
 dist.barrier()
 dist.destroy_process_group()
 """

@@ -109,7 +109,14 @@ class _FakeContext:
         assert len(rows) == len(sc) == len(cell_index) and means.shape[1] == len(alpha) == len(beta)
         self.calls.append(len(rows))
         idx = torch.as_tensor(np.asarray(cell_index), dtype=torch.int64)
-        return (idx[:, None] * 1000 + torch.arange(means.shape[1])[None, :] + seed % 7).to(torch.int32)
+        values = (idx[:, None] * 1000 + torch.arange(means.shape[1])[None, :] + seed % 7).to(torch.int32)
+        if kw.get("out") is not None:
+            kw["out"].copy_(values)
+            return kw["out"]
+        return values
+
+    def domain_status(self):
+        pass
 
 
 def _worker_sharded(rank, world_size, port, tmpdir, same_seed):
@@ -154,8 +161,8 @@ def _worker_sharded(rank, world_size, port, tmpdir, same_seed):
         assert len(set(plans)) == 1
         # the gather: chunks smaller than every shard, all senders at once, an empty sender among them
         full = parallel.gather_rows(counts, mine, N, chunk_rows=16)
+        want = (torch.arange(N)[:, None] * 1000 + torch.arange(G)[None, :] + 3).to(torch.int32)
         if rank == 0:
-            want = (torch.arange(N)[:, None] * 1000 + torch.arange(G)[None, :] + 3).to(torch.int32)
             assert torch.equal(full, want)
         else:
             assert full is None
@@ -167,6 +174,32 @@ def _worker_sharded(rank, world_size, port, tmpdir, same_seed):
             assert isinstance(on_host, np.ndarray) and np.array_equal(on_host, want.numpy())
         else:
             assert on_host is None
+        # sampling and exchange as ONE pipeline (chunk c travels while chunk c + 1 is sampled): the same matrix.
+        # order="shard": every chunk is received straight into its final rows, the permutation comes back
+        np.random.seed(77)
+        before = len(fake.calls)
+        piped, cell_of_row, pt3, br3, sc3 = parallel.sample_and_gather(t, N, seed=3, chunk_cells=16)
+        assert np.array_equal(pt3, pt) and np.array_equal(sc3, sc)
+        assert np.array_equal(np.sort(cell_of_row), np.arange(N))
+        assert len(fake.calls) - before == -(-len(mine) // 16) and all(c <= 16 for c in fake.calls[before:])    # sampled chunk by chunk
+        # (every rank knows the layout: its own cells sit where it would expect them)
+        at = int(np.nonzero(cell_of_row == mine[0])[0][0]) if len(mine) else 0
+        assert np.array_equal(cell_of_row[at:at + len(mine)], mine)
+        if rank == 0:
+            assert torch.equal(piped, want[torch.as_tensor(cell_of_row)])
+            assert torch.equal(piped, parallel.gather_rows(counts, mine, N)[torch.as_tensor(cell_of_row)])
+        else:
+            assert piped is None and parallel.gather_rows(counts, mine, N) is None
+        # order="plan": rows in plan order (staged and scattered on the root, one round behind the transfers); another root
+        np.random.seed(77)
+        piped, none, _, _, _ = parallel.sample_and_gather(t, N, seed=3, chunk_cells=1000, order="plan", dst=2)
+        assert none is None and (piped is not None) == (rank == 2)
+        if rank == 2:
+            assert torch.equal(piped, want)
+        np.random.seed(77)
+        piped, _, _, _, _ = parallel.sample_and_gather(t, N, seed=3, chunk_cells=7, order="plan")
+        if rank == 0:
+            assert torch.equal(piped, want)
         dist.barrier()
         open(os.path.join(tmpdir, "ok%d" % rank), "w").write("ok")
     finally:

@@ -265,6 +265,22 @@ VARIANTS.update({
 })
 
 
+# round 5: where does the first CHECKED call of a process spend its time?  (stderr, synchronising: diagnosis only)
+_T = 'static auto T0_ = std::chrono::steady_clock::now();\n'
+def _tick(label):
+    return ('    { (void)hipStreamSynchronize(c->stream); auto t_ = std::chrono::steady_clock::now(); fprintf(stderr, "COLDTRACE %%-28s %%9.3f ms\\n", "%s", '
+            'std::chrono::duration<double, std::milli>(t_ - T0_).count()); T0_ = t_; }\n' % label)
+VARIANTS["cold_trace"] = [
+    ("#define PA_EXPORT extern", "#include <chrono>\n" + _T + "#define PA_EXPORT extern"),
+    ("            if ((size_t)rows > c->row_bad_cap) {\n", _tick("before row_bad alloc") + "            if ((size_t)rows > c->row_bad_cap) {\n"),
+    ("            row_flags_kernel<<<dim3((unsigned)(rows < 65536 ? rows : 65536))", _tick("row_bad alloc") + "            row_flags_kernel<<<dim3((unsigned)(rows < 65536 ? rows : 65536))"),
+    ("    const int64_t span = (N + 4 > G ? N + 4 : G);\n", _tick("row_flags_kernel") + "    const int64_t span = (N + 4 > G ? N + 4 : G);\n"),
+    ("    const bool vec = (G % 4 == 0)", _tick("prep_kernel + setup") + "    const bool vec = (G % 4 == 0)"),
+    ("    c->list = heavy.list;\n", _tick("stream kernel + K3h") + "    c->list = heavy.list;\n"),
+    ("    c->call_parity ^= 1u;\n", _tick("(end of the call)") + "    c->call_parity ^= 1u;\n"),
+]
+
+
 def build(name):
     work = os.path.join(OUT, "src_" + name)
     shutil.rmtree(work, ignore_errors=True)
