@@ -54,14 +54,14 @@ constexpr int kBlock = 256;        // 4 waves
 constexpr int kTileG = 256;        // genes per wave pass: 64 lanes x 4
 constexpr int kStripCells = 128;   // most cells per wave (pos keeps the cell in 7 bits); the host launches 64
 constexpr int kS1Cap = 192;        // < 64 left over + 128 pushed by half a pass (two samples per lane)
-constexpr int kS2Cap = 96;         // < 32 left over + 64 pushed by one stage-2 pass
-constexpr int kS2Run = 32;         // stage 3 runs while S2 holds at least this many entries (8, 16: 3-5 % slower)
+constexpr int kS2Cap = 104;        // < 40 left over + 64 pushed by one stage-2 pass
+constexpr int kS2Run = 40;         // stage 3 runs while S2 holds at least this many entries (with eight terms per pass: 32 +0.9 %, 24 +4 %, 16 +7 %, 44 and 48 +0.7 %: profiles/r05_ablation.txt)
 static_assert(kS2Cap >= kS2Run - 1 + 64 && kS1Cap >= 63 + 128, "a stack must take one more round of pushes");
 constexpr int kRing = 8;           // rows of the strip kept in LDS (8 bits per count) before they are stored; a power of 2
 constexpr int kBail = 6;           // walks left to K3h when a strip has nothing else to do (see the drain)
 constexpr int kLateCap = 64;       // results that missed their row wait here for one burst of stores (a pass delivers at most 64)
 constexpr int kRingMaxK3 = 254;    // a walk whose group k3-3..k3 with k3 = 254 ends undecided goes to K3h: counts fit the ring's 8 bits
-constexpr int kInvTab = 260;       // 1/k for k < 260: the reciprocals a pass at k3 <= 254 reads ahead (k3 + 5)
+constexpr int kInvTab = 272;       // 1/k for k < 272: the reciprocals a pass at k3 <= 254 reads ahead (k3 + 6 .. k3 + 13)
 
 // What stage 1 needs to know about a cell, packed by the preparation kernel so that one scalar load
 // fetches it: byte offset of the cell's row in the mean tensor, library-size factor, (cell index
@@ -190,8 +190,8 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
     int s2_top = 0;                                  // wave-uniform
     constexpr uint32_t kNoHeavy = 0xffffffffu;
     uint32_t hpend = kNoHeavy;                       // pos of the sample this lane holds for the next append to K3h's list
-    // stage-3 lane state: st = {the next term (k = k3 - 3), d = mp - q, q, what is left of wf}; pos; k3 = the walk's
-    // group ends at k3 (6, 10, ...).  WHICH lanes walk is wave-level state on the scalar unit (idle_s: bit = the lane
+    // stage-3 lane state: st = {the next term (k = k3 - 3), d = mp - q, q, what is left of wf}; pos; k3 = the first of the
+    // pass's two groups ends at k3 (6, 14, 22, ...).  WHICH lanes walk is wave-level state on the scalar unit (idle_s: bit = the lane
     // holds no walk): a pass takes every mask it forms AND NOT idle_s, so an idle lane may compute on whatever its
     // registers hold, and no vector instruction is spent on asking who is idle.
     typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -199,6 +199,7 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
     uint32_t pos = 0u;
     int k3 = 6;
     f32x4 inv = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(&inv_k[4], 16));   // 1/(k+1) .. 1/(k+4): read one pass ahead
+    f32x4 inv2 = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(&inv_k[8], 16));  // 1/(k+5) .. 1/(k+8)
     unsigned long long idle_s = ~0ull;                   // wave-uniform
 
     // S1/S2 entries carry pos = (cell-in-strip << 8) | gene-in-tile, under the bits of 2^23 (kPosMagic, below)
@@ -334,6 +335,10 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
             s2_top = left;
             idle_s &= ~take_m;
         }
+        // Two groups of four terms per pass (A: k3 - 3 .. k3, B: k3 + 1 .. k3 + 4).  The definition decides group by group:
+        // A ends the walk if it holds a negative remainder or its last term is under 1, else -- at k3 = kRingMaxK3 -- the
+        // walk is K3h's, else B decides the same way.  (One group per pass, round 4's form, pays the pass's fixed cost --
+        // the pull, the masks, the delivery -- per four terms: profiles/r05_ablation.txt.)
         const float d = st.y, q = st.z;
         const float r1 = st.w - st.x;
         const float ps1 = st.x * PRNB_FMA(d, inv.x, q);
@@ -342,21 +347,35 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
         const float r3 = r2 - ps2;
         const float ps3 = ps2 * PRNB_FMA(d, inv.z, q);
         const float r4 = r3 - ps3;
-        const unsigned long long hit_m = K3_MASK(r4 < 0.0f);
-        const unsigned long long tail_m = K3_MASK(ps3 < 1.0f);
+        const float ps4 = ps3 * PRNB_FMA(d, inv.w, q);
+        const float r5 = r4 - ps4;
+        const float ps5 = ps4 * PRNB_FMA(d, inv2.x, q);
+        const float r6 = r5 - ps5;
+        const float ps6 = ps5 * PRNB_FMA(d, inv2.y, q);
+        const float r7 = r6 - ps6;
+        const float ps7 = ps6 * PRNB_FMA(d, inv2.z, q);
+        const float r8 = r7 - ps7;
+        const unsigned long long hit_a = K3_MASK(r4 < 0.0f), tail_a = K3_MASK(ps3 < 1.0f);
+        const unsigned long long hit_b = K3_MASK(r8 < 0.0f), tail_b = K3_MASK(ps7 < 1.0f);
         const unsigned long long big_m = K3_MASK(k3 >= kRingMaxK3);       // undecided there: the rest of the walk is K3h's (an idle lane rests at 6)
-        // the count: k3 less one for each of r1, r2, r3 that is negative (no hit: they are not, and the count is k3)
-        const int32_t res_k = (k3 + ((int32_t)prnb::f2u(r1) >> 31) + ((int32_t)prnb::f2u(r2) >> 31)) + ((int32_t)prnb::f2u(r3) >> 31);
-        const unsigned long long end_m = (hit_m | tail_m) & ~idle_s;
-        deliver(end_m, big_m & ~end_m, pos, (uint32_t)res_k);
-        idle_s |= end_m | big_m;                          // done lanes go idle
-        st.x = ps3 * PRNB_FMA(d, inv.w, q);
-        // an idle lane rests at k3 = 6 with the reciprocals of a walk's first group (the read below fetches them again
-        // every pass): a pull then brings only the entry, not a third 16-byte read
-        const int k3n = k3 + 4;
+        // the count: the group's last k less one for each of its first three remainders that is negative (no hit: none is)
+        const int32_t res_a = (k3 + ((int32_t)prnb::f2u(r1) >> 31) + ((int32_t)prnb::f2u(r2) >> 31)) + ((int32_t)prnb::f2u(r3) >> 31);
+        const int32_t res_b = ((k3 + 4) + ((int32_t)prnb::f2u(r5) >> 31) + ((int32_t)prnb::f2u(r6) >> 31)) + ((int32_t)prnb::f2u(r7) >> 31);
+        const unsigned long long end_a = (hit_a | tail_a) & ~idle_s;
+        const unsigned long long give_m = big_m & ~end_a & ~idle_s;
+        const unsigned long long end_b = (hit_b | tail_b) & ~(idle_s | end_a | big_m);
+        int32_t res_k;
+        asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(res_k) : "v"(res_b), "v"(res_a), "s"(end_a));
+        deliver(end_a | end_b, give_m, pos, (uint32_t)res_k);
+        idle_s |= end_a | end_b | big_m;                  // done lanes go idle
+        st.x = ps7 * PRNB_FMA(d, inv2.w, q);
+        // an idle lane rests at k3 = 6 with the reciprocals of a walk's first two groups (the reads below fetch them again
+        // every pass): a pull then brings only the entry
+        const int k3n = k3 + 8;
         asm("v_cndmask_b32 %0, %1, 6, %2" : "=v"(k3) : "v"(k3n), "s"(idle_s));
-        st.w = r4;
-        inv = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(&inv_k[k3 - 2], 16));   // 1/(k+1..k+4), k = k3 - 3
+        st.w = r8;
+        inv = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(&inv_k[k3 - 2], 16));    // 1/(k+1..k+4), k = k3 - 3
+        inv2 = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(&inv_k[k3 + 2], 16));   // 1/(k+5..k+8)
         if (BIG) __builtin_amdgcn_s_setprio(0);
     };
 

@@ -27,6 +27,7 @@
 #include <new>
 #include <vector>
 
+#include <hip/hip_ext.h>
 #include "../../include/prosstt_amd.h"
 #include "prnb_device.h"
 #include "k3_stream.h"
@@ -842,20 +843,22 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
         if ((rc = next_event_pair(c, &ev_start, &ev_stop))) return rc;
     }
     const dim3 grid((unsigned)(geo.groups * geo.tiles_g)), block(k3::kBlock);
-    if (ev_start) HIP_TRY(hipEventRecord(ev_start, c->stream));    // the dominant kernel is timed alone
     // full-length strips and more counts than the last-level cache (256 MB) takes: k3_stream.h, BIG
     const bool big = geo.strip_cells >= k3::kStripCells / 2 && (double)N * (double)ld_out * 4.0 >= 1073741824.0;
+    // The dominant kernel is timed alone (PROSSTT_AMD_TIME_KERNEL): the two events ride on the kernel's OWN dispatch packet
+    // (hipExtLaunchKernelGGL: its start and end timestamps), not as records in front of and behind it -- two more packets
+    // on the queue, each a barrier: 6 us of gap on either side of the kernel (tools/gap_trace.py), which would be in
+    // every timed step of bench.py.
 #define K3_LAUNCH(V, B)                                                                                          \
-    k3::sample_counts_stream_kernel<V, B><<<grid, block, 0, c->stream>>>(                                        \
-        A.means, G, cellinfo, A.ga, A.gbm1, A.gphi, N, k0, k1, d_out, ld_out, (int32_t)geo.strips,             \
-        (int32_t)geo.strip_cells, heavy)
+    hipExtLaunchKernelGGL((k3::sample_counts_stream_kernel<V, B>), grid, block, 0, c->stream, ev_start, ev_stop, 0,  \
+        A.means, G, (const k3::CellInfo*)cellinfo, (const float*)A.ga, (const float*)A.gbm1, (const float*)A.gphi, N, k0, k1, \
+        d_out, ld_out, (int32_t)geo.strips, (int32_t)geo.strip_cells, heavy)
     if (vec && big) K3_LAUNCH(true, true);
     else if (vec) K3_LAUNCH(true, false);
     else if (big) K3_LAUNCH(false, true);
     else K3_LAUNCH(false, false);
 #undef K3_LAUNCH
     HIP_TRY(hipGetLastError());
-    if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, c->stream));
     // every wave takes whole regions of the list; as many blocks as the device holds at once (6 per CU: 1536 --
     // 1024, 2048 and 3072 blocks are 7-18 us slower at C3)
     k3::sample_counts_heavy_kernel<<<dim3((unsigned)c->heavy_grid), dim3(k3::kHeavyBlock), 0, c->stream>>>(

@@ -1,6 +1,7 @@
 """
 -m gpu: whole matrices, not samples of them.
-  * C3 (50 000 x 20 000 = 1e9 counts, the headline workload), C4 (200 000 x 20 000) and C2 (5 000 x 5 000) compared with the
+  * C3 (50 000 x 20 000 = 1e9 counts, the headline workload), T32 (north_star's target shape: C4's 32-branch tree at C3's size,
+    its cells presented grouped by mean-tensor row as simulation.draw_counts presents them), C4 (200 000 x 20 000) and C2 (5 000 x 5 000) compared with the
     scalar C model count for count: every class of sample, every late result and list entry of the full launch (the model runs on all host cores,
     block by block, so the host never holds more than one block of expected counts);
   * C5 at its full 1 000 000 cells x 30 000 genes on ONE GPU, the way eight GPUs would split it: the
@@ -13,7 +14,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _whole_matrix_vs_model(name, n_cells, block):
+def _whole_matrix_vs_model(name, n_cells, block, grouped=False):
+    """grouped: the cells presented grouped by their row of the mean tensor, keyed by their position in the plan (what
+    simulation.draw_counts does); everything below then runs on the matrix in that order."""
     import torch
     from prosstt_amd import device, workloads
     from oracle import nb_model
@@ -22,12 +25,16 @@ def _whole_matrix_vs_model(name, n_cells, block):
     pt, br, sc, rows = work.plan(n_cells)
     assert len(rows) == n_cells == work.cfg["N"]
     means = work.tree.device_means()
-    X = ctx.sample_counts(means, rows, sc, work.alpha, work.beta, seed=777)
+    cell = np.arange(n_cells, dtype=np.int64)
+    if grouped:
+        cell = device.plan_order(rows, means.shape[0]).astype(np.int64)
+        rows, sc = rows[cell], sc[cell]
+    X = ctx.sample_counts(means, rows, sc, work.alpha, work.beta, seed=777, cell_index=cell if grouped else None)
     host_means = means.cpu().numpy()
     differing = 0
     for lo in range(0, n_cells, block):
         sl = slice(lo, min(lo + block, n_cells))
-        want = nb_model.sample_counts(host_means, rows[sl], sc[sl], work.alpha, work.beta, 777, cell_offset=lo)
+        want = nb_model.sample_counts(host_means, rows[sl], sc[sl], work.alpha, work.beta, 777, cell_index=cell[sl])
         got = X[sl].cpu().numpy()
         differing += int((got != want).sum())
     assert differing == 0, "%d of %d counts differ from the model" % (differing, X.numel())
@@ -98,6 +105,12 @@ def test_c3_entire_matrix_equals_the_model():
 
 def test_c2_entire_matrix_equals_the_model():
     _whole_matrix_vs_model("C2", 5000, 5000)
+
+
+def test_t32_entire_matrix_equals_the_model_cells_grouped_by_row():
+    """north_star's own target shape: the 32-branch tree at 50 000 x 20 000 (C4's tree, the headline's size), presented
+    the way the drop-in API presents it."""
+    _whole_matrix_vs_model("T32", 50000, 5000, grouped=True)
 
 
 def test_c4_entire_matrix_equals_the_model():

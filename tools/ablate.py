@@ -281,6 +281,24 @@ VARIANTS["cold_trace"] = [
 ]
 
 
+# round 5 (real variants, on cells presented grouped by mean-tensor row): no mean load when the cell two ahead sits on the row
+# of the cell one ahead; stage 3 waits for other stack depths (its passes now take eight terms)
+VARIANTS.update({
+    "skipload": [("        const Seg nn = load_seg(row2);\n", "        Seg nn = nxt;\n        if (row2 != row1) nn = load_seg(row2);\n"),
+                 ("        row2 = row3;\n        s = s_next;", "        row1 = row2;\n        row2 = row3;\n        s = s_next;"),
+                 ("    uint64_t row2 = cinfo[2].row_bytes;\n", "    uint64_t row2 = cinfo[2].row_bytes, row1 = cinfo[1].row_bytes;\n")],
+    "run16b": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 16;")],
+    "run24": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 24;")],
+    "run40b": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 40;"), ("constexpr int kS2Cap = 96;", "constexpr int kS2Cap = 104;")],
+    "run44": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 44;"), ("constexpr int kS2Cap = 96;", "constexpr int kS2Cap = 108;")],
+    "run48b": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 48;"), ("constexpr int kS2Cap = 96;", "constexpr int kS2Cap = 112;")],
+    "run48_bail10": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 48;"), ("constexpr int kS2Cap = 96;", "constexpr int kS2Cap = 112;"), ("constexpr int kBail = 6;", "constexpr int kBail = 10;")],
+    "run40_bail10": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 40;"), ("constexpr int kS2Cap = 96;", "constexpr int kS2Cap = 104;"), ("constexpr int kBail = 6;", "constexpr int kBail = 10;")],
+    "bail10b": [("constexpr int kBail = 6;", "constexpr int kBail = 10;")],
+    "bail3b": [("constexpr int kBail = 6;", "constexpr int kBail = 3;")],
+})
+
+
 def build(name):
     work = os.path.join(OUT, "src_" + name)
     shutil.rmtree(work, ignore_errors=True)
