@@ -71,7 +71,7 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def profiled_traffic():
+def profiled_traffic(suffix=""):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS
     command (profiles/rNN_summary.txt, written by tools/profile_bench.sh: separate --pmc runs for
     FETCH_SIZE and WRITE_SIZE).  Units and corrections as MI355X_MICROARCH.md prescribes: both
@@ -81,7 +81,9 @@ def profiled_traffic():
     the committed one was taken on other kernel sources."""
     import glob
     import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.txt")))
+    # profiles/rNN_summary.txt: the default run (the headline workload); profiles/rNN_t32_summary.txt (suffix "_t32"): T32's
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_summary.txt"))
+                   if re.fullmatch(r"r\d+%s_summary\.txt" % re.escape(suffix), os.path.basename(f)))
     if not files:
         return None, "no profile committed"
     text = open(files[-1]).read()
@@ -691,6 +693,7 @@ def assemble_line(args, job, main_case, strong, end_to_end, extras_error):
             "value": tc["value"], "unit": "cells*genes/s", "ms_per_step": tc["ms_per_step"], "kernel_ms": tc["kernel_ms"],
             "frac": tb / (tc["kernel_ms"] * 1e-3) / HBM_PEAK, "frac_whole_step": tb / (tc["ms_per_step"] * 1e-3) / HBM_PEAK,
             "algorithmic_bytes_per_launch": tb, "steps": args.steps,
+            "traffic": profiled_traffic("_t32")[0], "traffic_source": profiled_traffic("_t32")[1],
             "sum_counts_over_sum_means": round(tc["ratio"], 5), "lineage_attempts": tc["work"].info["attempts"]}
     if world > 1:
         line["scaling_note"] = ("value is the WEAK figure (the C3 cell count on every GPU): value(N) / value(1) is the "

@@ -1,13 +1,15 @@
 #!/bin/bash
 # Runs on the GPU box: rocprofv3 kernel trace + PMC passes of the default bench command.
-# usage: tools/profile_bench.sh <tag>     (summaries land in gpurun_out/prof_<tag>/)
-TAG=${1:-r04}
+# usage: [BENCH_EXTRA="--config T32"] tools/profile_bench.sh <tag>     (summaries land in gpurun_out/prof_<tag>/)
+# The default set is taken WITHOUT the extra case on north_star's shape (--no-target-shape): the kernel stats then hold the
+# headline workload's dispatches only; the T32 set is its own run (BENCH_EXTRA="--config T32").
+TAG=${1:-r05}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 cd $R
-ARGS="bench.py --steps 10 --warmup 2 --cpu-cells 0 --no-end-to-end"
+ARGS="bench.py --steps 10 --warmup 2 --cpu-cells 0 --no-end-to-end --no-target-shape $BENCH_EXTRA"
 PMC="$ARGS --ramp-ms 0"     # counter passes: no clock ramp (instruction and byte counts do not depend on the clock; 18 dispatches per kernel instead of 250)
 python3 $ARGS > $O/bench_unprofiled.json 2> $O/bench_unprofiled.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $ARGS > $O/bench_trace.json 2> $O/trace.err
