@@ -650,7 +650,9 @@ def assemble_line(args, job, main_case, strong, end_to_end, extras_error):
     achieved = abytes / (kms * 1e-3)
     ms_per_step = main_case["ms_per_step"]
     default_shape = args.config == "C3" and args.cells_per_gpu is None and args.scaling == "weak" and world == 1
-    traffic, traffic_src = profiled_traffic() if default_shape else (None, "profiles are of the default 1-GPU C3 run")
+    t32_shape = args.config == "T32" and args.cells_per_gpu is None and args.scaling == "weak" and world == 1
+    traffic, traffic_src = profiled_traffic() if default_shape else (
+        profiled_traffic("_t32") if t32_shape else (None, "profiles are of the default 1-GPU C3 run and of --config T32"))
     line = {
         "metric": "simulated cells*genes per second (count sampling: sample_density -> draw_counts)",
         "value": main_case["value"], "unit": "cells*genes/s", "n_gpus": world, "steps": args.steps,

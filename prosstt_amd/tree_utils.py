@@ -107,10 +107,26 @@ def sanitize_velocity(velocity, minimum_velocity=0.1):
 def _density_from_velocity(velocity):
     """Cell density along the tree from pseudotime velocities: where cells move fast, few are
     seen (tree_utils.py:207-242).  Over all branches together the density is the velocity
-    mirrored inside its own range, ``vmax + vmin - v``, normalised to sum to one over the tree."""
+    mirrored inside its own range and normalised to sum to one over the tree.
+
+    Bit for bit the reference's numbers (``np.random.choice`` builds its cdf from them, so the cells of a density
+    plan hang on the last bit): the velocities are first divided by their total -- in place, the caller's arrays
+    are normalised as the reference normalises them --, mirrored as ``(-v + max) + min`` in that order, and both
+    totals are accumulated branch by branch (fixture g11, compared exactly)."""
     keys = list(velocity)
     flat = np.concatenate([np.asarray(velocity[k], dtype=float) for k in keys])
-    mirrored = (flat.max() + flat.min()) - flat
-    mirrored = mirrored / mirrored.sum()
     cuts = np.cumsum([len(velocity[k]) for k in keys])[:-1]
+
+    def branchwise_total(values):
+        total = 0
+        for piece in np.split(values, cuts):
+            total += np.sum(piece)
+        return total
+
+    speed = branchwise_total(flat)
+    scaled = flat / speed
+    mirrored = (-scaled + flat.max() / speed) + flat.min() / speed
+    mirrored = mirrored / branchwise_total(mirrored)
+    for k, piece in zip(keys, np.split(scaled, cuts)):
+        velocity[k] = piece
     return dict(zip(keys, np.split(mirrored, cuts)))

@@ -386,8 +386,8 @@ def test_velocity_and_newick_against_reference_fixtures():
                 assert min(v.min() for v in vel.values()) < 0
             t.set_velocity(vel)
             for b in t.branches:
-                np.testing.assert_allclose(t.density[b], g["vel_%s_%s_density_%s" % (tname, vname, b)],
-                                           rtol=1e-13, atol=0)
+                # bit for bit: np.random.choice builds its cdf from these numbers (the cells of a plan hang on the last bit)
+                np.testing.assert_array_equal(t.density[b], g["vel_%s_%s_density_%s" % (tname, vname, b)])
     for name in ("bif", "deep", "single"):
         nodes = [_newick.Node(str(n), float(l)) for n, l in zip(g["nw_%s_names" % name], g["nw_%s_lengths" % name])]
         for node, parent in zip(nodes, g["nw_%s_parents" % name]):
