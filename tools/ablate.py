@@ -299,6 +299,17 @@ VARIANTS.update({
 })
 
 
+# round 5 (timing only): what does a scalar / a vector instruction more per pass of stage 1 cost?
+_S8 = ' '.join(['"s_add_u32 %0, %0, 1\\n\\t"'] * 8)
+_V4 = ' '.join(['"v_add_u32 %0, %0, %0\\n\\t"'] * 4)
+VARIANTS.update({
+    "salu8": [("        const prnb::Words W = philox_count_row(ph, quad_hi, quad_lo, k0, k1);",
+               "        { uint32_t dummy_ = (uint32_t)cl; asm volatile(" + _S8 + " : \"+s\"(dummy_)); }\n        const prnb::Words W = philox_count_row(ph, quad_hi, quad_lo, k0, k1);")],
+    "valu4": [("        const prnb::Words W = philox_count_row(ph, quad_hi, quad_lo, k0, k1);",
+               "        { uint32_t dummy_ = (uint32_t)lane; asm volatile(" + _V4 + " : \"+v\"(dummy_)); }\n        const prnb::Words W = philox_count_row(ph, quad_hi, quad_lo, k0, k1);")],
+})
+
+
 def build(name):
     work = os.path.join(OUT, "src_" + name)
     shutil.rmtree(work, ignore_errors=True)
