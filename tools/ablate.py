@@ -34,7 +34,7 @@ STORE_2 = """            if (BIG) __builtin_amdgcn_raw_buffer_store_b128(row4, o
             else __builtin_amdgcn_raw_buffer_store_b128(row4, out_rsrc, store_voff, flush_off, 2 /* nt */);"""
 STORE_OFF = (STORE_2, STORE_2.replace("store_voff", "0x80000000u"))   # every lane out of range: dropped
 
-K3H_LAUNCH = """    k3::sample_counts_heavy_kernel<<<dim3((unsigned)c->heavy_grid), dim3(k3::kHeavyBlock), 0, c->stream>>>(
+K3H_LAUNCH = """    k3::sample_counts_heavy_kernel<<<dim3(heavy_blocks), dim3(k3::kHeavyBlock), 0, c->stream>>>(
         heavy, (uint32_t)geo.regions, (int32_t)geo.strips, (int32_t)geo.strip_cells, A.means, rows, G, A.row_of_cell,
         A.scal, A.ga, A.gbm1, N, k0, k1, cell_offset, d_cell_index, d_out, ld_out);
 """
@@ -63,9 +63,12 @@ VARIANTS = {
     # K3h without the redo walks / without the gamma-Poisson samples
     "k3h_noredo": [("            light = P.valid && P.light;\n", "            light = false;\n")],
     "k3h_noheavy": [("            heavy = P.valid && !P.light;\n", "            heavy = false;\n")],
-    "k3h_grid1024": [("k3::sample_counts_heavy_kernel<<<dim3((unsigned)c->heavy_grid),", "k3::sample_counts_heavy_kernel<<<dim3(1024),")],
-    "k3h_grid2048": [("k3::sample_counts_heavy_kernel<<<dim3((unsigned)c->heavy_grid),", "k3::sample_counts_heavy_kernel<<<dim3(2048),")],
-    "k3h_grid3072": [("k3::sample_counts_heavy_kernel<<<dim3((unsigned)c->heavy_grid),", "k3::sample_counts_heavy_kernel<<<dim3(3072),")],
+    "k3h_grid1024": [("k3::sample_counts_heavy_kernel<<<dim3(heavy_blocks),", "k3::sample_counts_heavy_kernel<<<dim3(1024),")],
+    "k3h_grid2048": [("k3::sample_counts_heavy_kernel<<<dim3(heavy_blocks),", "k3::sample_counts_heavy_kernel<<<dim3(2048),")],
+    "k3h_grid3072": [("k3::sample_counts_heavy_kernel<<<dim3(heavy_blocks),", "k3::sample_counts_heavy_kernel<<<dim3(3072),")],
+    "k3h_grid256": [("k3::sample_counts_heavy_kernel<<<dim3(heavy_blocks),", "k3::sample_counts_heavy_kernel<<<dim3(256),")],
+    "k3h_grid512": [("k3::sample_counts_heavy_kernel<<<dim3(heavy_blocks),", "k3::sample_counts_heavy_kernel<<<dim3(512),")],
+    "k3h_grid768": [("k3::sample_counts_heavy_kernel<<<dim3(heavy_blocks),", "k3::sample_counts_heavy_kernel<<<dim3(768),")],
     "k3h_none": [("            light = P.valid && P.light;\n", "            light = false;\n"), ("            heavy = P.valid && !P.light;\n", "            heavy = false;\n")],
     "k3h_gamma1": [("                    ok = last;\n                    if (!ok) {", "                    ok = true;\n                    if (!ok) {")],
     "k3h_pois1": [("                    again = j + 1 < 2 * prnb::kMaxTries;", "                    again = false;")],
@@ -109,10 +112,10 @@ VARIANTS = {
     # round 4: K3h on a second stream with no dependency on the stream kernel (it reads the PREVIOUS call's list: timing only) --
     # the upper bound of what overlapping the two kernels can give
     "k3h_overlap": [
-        ("    k3::sample_counts_heavy_kernel<<<dim3((unsigned)c->heavy_grid), dim3(k3::kHeavyBlock), 0, c->stream>>>(",
+        ("    k3::sample_counts_heavy_kernel<<<dim3(heavy_blocks), dim3(k3::kHeavyBlock), 0, c->stream>>>(",
          "    static hipStream_t s2 = nullptr; static hipEvent_t e2 = nullptr;\n"
          "    if (!s2) { HIP_TRY(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&e2, hipEventDisableTiming)); }\n"
-         "    k3::sample_counts_heavy_kernel<<<dim3((unsigned)c->heavy_grid), dim3(k3::kHeavyBlock), 0, s2>>>("),
+         "    k3::sample_counts_heavy_kernel<<<dim3(heavy_blocks), dim3(k3::kHeavyBlock), 0, s2>>>("),
         ("    c->list = heavy.list;\n", "    HIP_TRY(hipEventRecord(e2, s2)); HIP_TRY(hipStreamWaitEvent(c->stream, e2, 0));\n    c->list = heavy.list;\n"),
     ],
     # round 4 (real variant): the next cell's record loaded mid-pass into the registers this pass has finished with (no scalar rotation)
