@@ -35,6 +35,12 @@
 #include "numpy_stream.h"
 
 #define PA_EXPORT extern "C" __attribute__((visibility("default")))
+// Nothing throws across the C ABI: every exported function is a function-try-block that ends in PA_CATCH (the host side
+// uses std::vector: an allocation failure becomes PROSSTT_AMD_ENOMEM, not an exception in a ctypes caller).
+#define PA_CATCH                                                                                       \
+    catch (const std::bad_alloc&) { return fail(PROSSTT_AMD_ENOMEM, "out of host memory"); }          \
+    catch (const std::exception& e) { return fail(PROSSTT_AMD_EINVAL, "unexpected exception: %s", e.what()); } \
+    catch (...) { return fail(PROSSTT_AMD_EINVAL, "unexpected exception"); }
 
 // ------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
@@ -546,7 +552,7 @@ __global__ __launch_bounds__(256) void row_flags_kernel(const float* __restrict_
 PA_EXPORT int prosstt_amd_version(void) { return PROSSTT_AMD_VERSION; }
 PA_EXPORT const char* prosstt_amd_last_error(void) { return g_err; }
 
-PA_EXPORT int prosstt_amd_device_count(int* count)
+PA_EXPORT int prosstt_amd_device_count(int* count) try
 {
     if (!count) return fail(PROSSTT_AMD_EINVAL, "count is NULL");
     *count = 0;
@@ -557,8 +563,9 @@ PA_EXPORT int prosstt_amd_device_count(int* count)
     }
     return 0;
 }
+PA_CATCH
 
-PA_EXPORT int prosstt_amd_ctx_create(int device, void* stream, prosstt_amd_ctx** out)
+PA_EXPORT int prosstt_amd_ctx_create(int device, void* stream, prosstt_amd_ctx** out) try
 {
     if (!out) return fail(PROSSTT_AMD_EINVAL, "out is NULL");
     *out = nullptr;
@@ -592,8 +599,9 @@ PA_EXPORT int prosstt_amd_ctx_create(int device, void* stream, prosstt_amd_ctx**
     *out = c;
     return 0;
 }
+PA_CATCH
 
-PA_EXPORT int prosstt_amd_ctx_destroy(prosstt_amd_ctx* c)
+PA_EXPORT int prosstt_amd_ctx_destroy(prosstt_amd_ctx* c) try
 {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
@@ -606,15 +614,17 @@ PA_EXPORT int prosstt_amd_ctx_destroy(prosstt_amd_ctx* c)
     delete c;
     return 0;
 }
+PA_CATCH
 
-PA_EXPORT int prosstt_amd_ctx_synchronize(prosstt_amd_ctx* c)
+PA_EXPORT int prosstt_amd_ctx_synchronize(prosstt_amd_ctx* c) try
 {
     if (!c) return fail(PROSSTT_AMD_EINVAL, "ctx is NULL");
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
+PA_CATCH
 
-PA_EXPORT int prosstt_amd_last_kernel_ms(prosstt_amd_ctx* c, float* ms)
+PA_EXPORT int prosstt_amd_last_kernel_ms(prosstt_amd_ctx* c, float* ms) try
 {
     if (!c || !ms) return fail(PROSSTT_AMD_EINVAL, "NULL argument");
     if (c->events_used == 0)
@@ -630,6 +640,7 @@ PA_EXPORT int prosstt_amd_last_kernel_ms(prosstt_amd_ctx* c, float* ms)
     c->events_used = 0;
     return 0;
 }
+PA_CATCH
 
 // Common front end of sample_counts / nb_params: validates, stages host inputs,
 // converts the binary64 per-cell / per-gene parameters into the workspace.
@@ -772,7 +783,7 @@ static int domain_verdict(prosstt_amd_ctx* c, int64_t rows, int* verdict)
     return 0;
 }
 
-PA_EXPORT int prosstt_amd_domain_status(prosstt_amd_ctx* c, int32_t* status)
+PA_EXPORT int prosstt_amd_domain_status(prosstt_amd_ctx* c, int32_t* status) try
 {
     if (!c) return fail(PROSSTT_AMD_EINVAL, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
@@ -781,8 +792,9 @@ PA_EXPORT int prosstt_amd_domain_status(prosstt_amd_ctx* c, int32_t* status)
     if (status) *status = verdict;
     return (rc == PROSSTT_AMD_EHIP) ? rc : 0;     // the verdict travels in *status; the message is in last_error
 }
+PA_CATCH
 
-PA_EXPORT int prosstt_amd_plan_order(const int32_t* row_of_cell, int64_t N, int64_t rows, int32_t* order)
+PA_EXPORT int prosstt_amd_plan_order(const int32_t* row_of_cell, int64_t N, int64_t rows, int32_t* order) try
 {
     if (N < 0 || rows < 0 || N > 0x7fffffffll) return fail(PROSSTT_AMD_EINVAL, "bad size");
     if (N > 0 && (!row_of_cell || !order)) return fail(PROSSTT_AMD_EINVAL, "NULL argument");
@@ -796,12 +808,13 @@ PA_EXPORT int prosstt_amd_plan_order(const int32_t* row_of_cell, int64_t N, int6
     for (int64_t n = 0; n < N; ++n) order[first[(size_t)row_of_cell[n]]++] = (int32_t)n;
     return 0;
 }
+PA_CATCH
 
 PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, int64_t rows, int32_t G,
                                         const int32_t* row_of_cell, const double* scaling,
                                         const double* alpha, const double* beta, int64_t N,
                                         uint64_t seed, uint64_t cell_offset, const int64_t* cell_index,
-                                        int32_t* out, int64_t ld_out, uint32_t flags)
+                                        int32_t* out, int64_t ld_out, uint32_t flags) try
 {
     Staging st;
     SamplerArgs A{};
@@ -891,6 +904,7 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
     }
     return 0;
 }
+PA_CATCH
 
 // The samples the streaming kernel of the LAST sample_counts call on this ctx left to K3h (the gamma-Poisson
 // class, walks too close to a threshold, counts above 255), decoded to (cell, gene) pairs: `cells[i]` is the
@@ -898,7 +912,7 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
 // (of a region that was too small: the entries that fitted) and `*overflowed` whether there was such a region
 // (K3h redoes those regions sample by sample).  Valid until the next call on the ctx grows its workspace.
 PA_EXPORT int prosstt_amd_last_list(prosstt_amd_ctx* c, int64_t* cells, int32_t* genes, int64_t cap,
-                                    int64_t* total, int32_t* overflowed)
+                                    int64_t* total, int32_t* overflowed) try
 {
     if (!c || !total) return fail(PROSSTT_AMD_EINVAL, "NULL argument");
     if (cap > 0 && (!cells || !genes)) return fail(PROSSTT_AMD_EINVAL, "NULL output array");
@@ -928,11 +942,12 @@ PA_EXPORT int prosstt_amd_last_list(prosstt_amd_ctx* c, int64_t* cells, int32_t*
     }
     return 0;
 }
+PA_CATCH
 
 PA_EXPORT int prosstt_amd_nb_params(prosstt_amd_ctx* c, const float* means, int64_t rows, int32_t G,
                                     const int32_t* row_of_cell, const double* scaling,
                                     const double* alpha, const double* beta, int64_t N, float* mu,
-                                    float* p, float* r, int32_t* path, uint32_t flags)
+                                    float* p, float* r, int32_t* path, uint32_t flags) try
 {
     Staging st;
     SamplerArgs A{};
@@ -956,9 +971,10 @@ PA_EXPORT int prosstt_amd_nb_params(prosstt_amd_ctx* c, const float* means, int6
     if (flags & (PROSSTT_AMD_HOST_OUTPUT | PROSSTT_AMD_HOST_INPUTS)) HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
+PA_CATCH
 
 PA_EXPORT int prosstt_amd_hw_math(prosstt_amd_ctx* c, int32_t op, uint32_t first_bits, uint64_t count, float* out,
-                                  uint32_t flags)
+                                  uint32_t flags) try
 {
     if (!c || !out) return fail(PROSSTT_AMD_EINVAL, "NULL argument");
     if (op < 0 || op > 2) return fail(PROSSTT_AMD_EINVAL, "op must be 0 (rcp), 1 (log2) or 2 (exp2 of -x)");
@@ -982,11 +998,12 @@ PA_EXPORT int prosstt_amd_hw_math(prosstt_amd_ctx* c, int32_t op, uint32_t first
     }
     return 0;
 }
+PA_CATCH
 
 PA_EXPORT int prosstt_amd_numpy_programs(uint32_t* mt_words, int32_t* mt_next, int32_t* has_gauss, double* gauss,
                                          int32_t attempts, int32_t T, int32_t K, double* start, double* vel0, double* eta,
                                          double* noise, uint32_t* after_words, int32_t* after_next,
-                                         int32_t* after_has_gauss, double* after_gauss)
+                                         int32_t* after_has_gauss, double* after_gauss) try
 {
     if (!mt_words || !mt_next || !has_gauss || !gauss || !start || !vel0 || !eta || !after_words || !after_next ||
         !after_has_gauss || !after_gauss || (T > 1 && !noise))
@@ -1005,6 +1022,7 @@ PA_EXPORT int prosstt_amd_numpy_programs(uint32_t* mt_words, int32_t* mt_next, i
     *gauss = g.spare;
     return 0;
 }
+PA_CATCH
 
 // centre the first `steps` rows of a [*][K] program matrix over time (scipy.stats.pearsonr's xm = x - mean)
 static void centred(const double* src, int steps, int K, double* dst)
@@ -1023,7 +1041,7 @@ static void centred(const double* src, int steps, int K, double* dst)
 PA_EXPORT int prosstt_amd_lineage_attempt_batch(prosstt_amd_ctx* c, const double* programs, int32_t B, int32_t T,
                                                 int32_t K, const double* H, int64_t G, int32_t n_sib,
                                                 const double* const* sib_programs, const int32_t* sib_T,
-                                                double* out_max, int64_t* out_anticorr)
+                                                double* out_max, int64_t* out_anticorr) try
 {
     if (!c || !programs || !H || !out_max) return fail(PROSSTT_AMD_EINVAL, "NULL argument");
     if (B <= 0 || T <= 0 || K <= 0 || G <= 0 || n_sib < 0) return fail(PROSSTT_AMD_EINVAL, "bad size");
@@ -1088,18 +1106,20 @@ PA_EXPORT int prosstt_amd_lineage_attempt_batch(prosstt_amd_ctx* c, const double
     }
     return 0;
 }
+PA_CATCH
 
 PA_EXPORT int prosstt_amd_lineage_attempt(prosstt_amd_ctx* c, const double* programs, int32_t T, int32_t K,
                                           const double* H, int64_t G, int32_t n_sib,
                                           const double* const* sib_programs, const int32_t* sib_T,
-                                          double* out_max, int64_t* out_anticorr)
+                                          double* out_max, int64_t* out_anticorr) try
 {
     return prosstt_amd_lineage_attempt_batch(c, programs, 1, T, K, H, G, n_sib, sib_programs, sib_T, out_max,
                                              out_anticorr);
 }
+PA_CATCH
 
 PA_EXPORT int prosstt_amd_lineage_walk_batch(prosstt_amd_ctx* c, uint64_t seed, uint64_t first_stream_id, int32_t B,
-                                             int32_t T, int32_t K, double* programs_out)
+                                             int32_t T, int32_t K, double* programs_out) try
 {
     if (!c || !programs_out) return fail(PROSSTT_AMD_EINVAL, "NULL argument");
     if (B <= 0 || B > 65535 || T <= 0 || K <= 0) return fail(PROSSTT_AMD_EINVAL, "bad size");
@@ -1115,15 +1135,17 @@ PA_EXPORT int prosstt_amd_lineage_walk_batch(prosstt_amd_ctx* c, uint64_t seed, 
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
+PA_CATCH
 
 PA_EXPORT int prosstt_amd_lineage_walk(prosstt_amd_ctx* c, uint64_t seed, uint64_t stream_id, int32_t T,
-                                       int32_t K, double* programs_out)
+                                       int32_t K, double* programs_out) try
 {
     return prosstt_amd_lineage_walk_batch(c, seed, stream_id, 1, T, K, programs_out);
 }
+PA_CATCH
 
 PA_EXPORT int prosstt_amd_lineage_commit(prosstt_amd_ctx* c, const double* programs, int32_t T, int32_t K,
-                                         const double* H, int64_t G, double* rel_out, double* gene_max)
+                                         const double* H, int64_t G, double* rel_out, double* gene_max) try
 {
     if (!c || !programs || !H) return fail(PROSSTT_AMD_EINVAL, "NULL argument");
     if (T <= 0 || K <= 0 || G <= 0) return fail(PROSSTT_AMD_EINVAL, "bad size");
@@ -1147,9 +1169,10 @@ PA_EXPORT int prosstt_amd_lineage_commit(prosstt_amd_ctx* c, const double* progr
     HIP_TRY(hipStreamSynchronize(c->stream));   // `programs` is a pageable host buffer the caller may reuse
     return 0;
 }
+PA_CATCH
 
 PA_EXPORT int prosstt_amd_gene_max(prosstt_amd_ctx* c, const double* rel, int64_t rows, int64_t G,
-                                   double* gene_max)
+                                   double* gene_max) try
 {
     if (!c || !rel || !gene_max) return fail(PROSSTT_AMD_EINVAL, "NULL argument");
     if (rows < 0 || G < 0) return fail(PROSSTT_AMD_EINVAL, "negative size");
@@ -1162,9 +1185,10 @@ PA_EXPORT int prosstt_amd_gene_max(prosstt_amd_ctx* c, const double* rel, int64_
     HIP_TRY(hipGetLastError());
     return 0;
 }
+PA_CATCH
 
 PA_EXPORT int prosstt_amd_means_from_rel(prosstt_amd_ctx* c, const double* rel, const double* base,
-                                         int64_t rows, int64_t G, float* means_out)
+                                         int64_t rows, int64_t G, float* means_out) try
 {
     if (!c || !rel || !base || !means_out) return fail(PROSSTT_AMD_EINVAL, "NULL argument");
     if (rows < 0 || G < 0) return fail(PROSSTT_AMD_EINVAL, "negative size");
@@ -1176,3 +1200,4 @@ PA_EXPORT int prosstt_amd_means_from_rel(prosstt_amd_ctx* c, const double* rel, 
     HIP_TRY(hipGetLastError());
     return 0;
 }
+PA_CATCH
