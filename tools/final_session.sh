@@ -19,6 +19,11 @@ KBENCH_SORT=1 bash tools/stage_budget.sh ${TAG}_t32 T32 > /dev/null 2>&1; tail -
 for c in C3 T32 C4; do timeout 900 python3 tools/list_stats.py $c 2>&1 | grep -v amdgpu | tail -3; done | tee $O/list_stats.txt
 KBENCH_SORT=1 KBENCH_BURST=20 rocprofv3 --kernel-trace --output-format csv -d $O/trace_gap -- python3 tools/kbench_ab.py C3 4 shipped > /dev/null 2>&1; python3 tools/gap_trace.py $O/trace_gap | tee $O/gaps_C3.txt; rm -rf $O/trace_gap
 timeout 300 python3 tools/cold_probe.py 2>&1 | grep -v amdgpu > $O/cold_probe.txt
+# the RCCL side of bench.py on what one GPU allows: a one-rank process group on nccl (init, barrier, the MAX all-reduce of the timing)
+PROSSTT_BENCH_FORCE_DIST=1 timeout 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 5 --warmup 2 --cpu-cells 0 --no-end-to-end --no-target-shape 2> $O/bench_nccl_1rank.err | tail -1 > $O/bench_nccl_1rank.json
+python3 -c "
+import json; d=json.load(open('$O/bench_nccl_1rank.json')); print('nccl, 1 rank:', d['n_gpus'], d['value'], d['roofline']['frac'])"
+for t in c4:"--config C4" c2:"--config C2" c5share:"--config C5 --cells-per-gpu 125000"; do BENCH_EXTRA="${t#*:}" bash tools/profile_bench.sh ${TAG}_${t%%:*} > /dev/null 2>&1; grep "bench_unprofiled.json" gpurun_out/prof_${TAG}_${t%%:*}/summary.txt | cut -c1-200; done
 python3 -c "
 import json
 d=json.load(open('$O/bench_default.json')); print('default:', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['frac_whole_step'], d.get('end_to_end_ms'), d['ms_per_step_cold'], d['north_star_shape']['frac'], d['north_star_shape']['frac_whole_step'])
