@@ -3,7 +3,8 @@
 fixed cases of test_gpu_sampler.py pick by hand is drawn here: ragged N and G (one cell, one gene, G % 4 != 0,
 strips and tiles one short of / one past a boundary), padded output rows (ld_out > G), arbitrary global cell
 ids, dense and sparse gamma-Poisson genes (list regions that overflow next to regions that do not), long
-inversion walks, library-size factors over six orders of magnitude, degenerate genes.
+inversion walks, library-size factors over six orders of magnitude, degenerate genes; and the same cells presented in
+another order (grouped by mean-tensor row, or shuffled) give the same counts.
 """
 import numpy as np
 import pytest
@@ -65,6 +66,13 @@ def test_random_case_equals_the_model(seed):
         assert bool((buf[:, G:] == -7).all()), "the padding of the output rows was written"
         want = nb_model.sample_counts(means, roc, sc, al, be, draw_seed)
     np.testing.assert_array_equal(got.cpu().numpy(), want)
+    if seed % 2 == 0:
+        # the same cells PRESENTED in another order (grouped by mean-tensor row as simulation.draw_counts presents them, or
+        # shuffled), each keyed by its own global id: row i of the result is the cell presented i-th, count for count
+        ids = (np.arange(N, dtype=np.int64) + offset) if mode == 0 else (ids if mode == 1 else np.arange(N, dtype=np.int64))
+        order = device.plan_order(roc, means.shape[0]) if seed % 4 == 0 else rng.permutation(N).astype(np.int32)
+        again = ctx.sample_counts(means, roc[order], sc[order], al, be, seed=draw_seed, cell_index=ids[order], check_domain=False)
+        np.testing.assert_array_equal(again.cpu().numpy(), want[order])
 
 
 @pytest.mark.parametrize("seed", range(40))
