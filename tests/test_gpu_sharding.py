@@ -46,3 +46,20 @@ def test_sample_density_sharded_single_process_equals_sample_density():
     full = parallel.gather_rows(counts, idx, 700)
     import torch
     assert torch.equal(full, X)
+
+
+def test_sample_and_gather_single_process_equals_sample_density():
+    """parallel.sample_and_gather without a process group: the pipeline's chunked sampling into final rows, both orders."""
+    import torch
+    from prosstt_amd import parallel, simulation as sim, workloads
+    work = workloads.build("C2", G=512)
+    np.random.seed(5)
+    X, pt, br, sc = sim.sample_density(work.tree, 700, alpha=work.alpha, beta=work.beta, seed=9, out="torch")
+    np.random.seed(5)
+    full, cell_of_row, pt2, br2, sc2 = parallel.sample_and_gather(work.tree, 700, alpha=work.alpha, beta=work.beta, seed=9, chunk_cells=128)
+    np.testing.assert_array_equal(pt, pt2)
+    np.testing.assert_array_equal(np.sort(cell_of_row), np.arange(700))
+    assert torch.equal(full, X[torch.as_tensor(cell_of_row, device=X.device)])
+    np.random.seed(5)
+    planned, none, _, _, _ = parallel.sample_and_gather(work.tree, 700, alpha=work.alpha, beta=work.beta, seed=9, chunk_cells=300, order="plan")
+    assert none is None and torch.equal(planned, X)
