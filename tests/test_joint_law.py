@@ -114,3 +114,22 @@ def test_32_branch_matrix_is_jointly_independent():
     print("\n" + report(scores, "device, T32 matrix, %d x %d" % X.shape))
     for key, (tscore, detail) in scores.items():
         assert abs(tscore) < SIGMA, "%s: %+.2f sigma (%s)" % (key, tscore, detail)
+
+
+@pytest.mark.gpu
+def test_c4_matrix_is_jointly_independent():
+    """And at 4e9 counts (C4: the 32-branch tree, 200 000 x 20 000), the cells presented grouped by mean-tensor row as
+    the drop-in API presents them -- neighbouring rows of the device matrix then share their parameters, which is where
+    a dependence between neighbouring cell counters would show most."""
+    from prosstt_amd import device, workloads
+    ctx = device.get_context()
+    work = workloads.build("C4")
+    pt, br, sc, rows = work.plan()
+    means = work.tree.device_means()
+    order = device.plan_order(rows, means.shape[0])
+    rows, sc = rows[order], sc[order]
+    X = ctx.sample_counts(means, rows, sc, work.alpha, work.beta, seed=4004, cell_index=order.astype(np.int64))
+    scores = _scores_of(X, means, rows, sc, work.alpha, work.beta, chunk=2048)
+    print("\n" + report(scores, "device, C4 matrix (cells grouped by row), %d x %d" % X.shape))
+    for key, (tscore, detail) in scores.items():
+        assert abs(tscore) < SIGMA, "%s: %+.2f sigma (%s)" % (key, tscore, detail)
