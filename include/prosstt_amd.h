@@ -73,7 +73,7 @@ int prosstt_amd_last_kernel_ms(prosstt_amd_ctx* ctx, float* ms);
  *   scipy.stats.nbinom(n=r, p=1-p).rvs()        simulation.py:647-648
  * out[n*ld_out + g] ~ NB(mean m, variance alpha*m^2 + beta*m),
  *   m = means[row_of_cell[n]*G + g] * scaling[n],
- * drawn by the PRNB-5 counter-based sampler keyed by
+ * drawn by the PRNB-6 counter-based sampler keyed by
  * (seed, global cell id, g); the global id of cell n is cell_index[n] when
  * cell_index is given, cell_offset + n otherwise.
  *   means        [rows][G] binary32, row-major: the (branch, time, gene) mean tensor
@@ -140,7 +140,7 @@ int prosstt_amd_nb_params(prosstt_amd_ctx* ctx, const float* means, int64_t rows
                           int32_t* path, uint32_t flags);
 
 /*
- * The three hardware functions that the sampler's definition (PRNB-5) takes from gfx950,
+ * The three hardware functions that the sampler's definition (PRNB-6) takes from gfx950,
  * tabulated by the device itself over a range of binary32 bit patterns:
  *   out[i] = f(as_float(first_bits + i)),  i < count;   op 0: f = v_rcp_f32(x), 1: v_log_f32(x), 2: v_exp_f32(-x)
  * -- the side input of the scalar model that checks the sampler bit for bit (the test-side model reads these values

@@ -3,7 +3,7 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library; prosstt_amd never does.
  *
- * Scalar C model of the *device* count sampler ("PRNB-5"): the
+ * Scalar C model of the *device* count sampler ("PRNB-6"): the
  * fused  gather * scale -> get_pr_umi -> negative-binomial draw  that replaces
  *   simulation.draw_counts           /root/reference/prosstt/simulation.py:602-651
  *   count_model.get_pr_umi           /root/reference/prosstt/count_model.py:131-161
@@ -11,7 +11,7 @@
  *
  * The reference draws from numpy's sequential MT19937 stream, which no
  * parallel device can reproduce (SURVEY.md section 0 "RNG reality check"); the count
- * law, not the stream, is the contract.  PRNB-5 is a counter-based sampler of
+ * law, not the stream, is the contract.  PRNB-6 is a counter-based sampler of
  * the SAME law  NB(n = r, p = 1-p)  with  theta = a*m + b - 1,  r = m/theta,
  * p = theta/(1+theta)  (the algebraic form of get_pr_umi), defined so that
  * every sample is a pure function of (M, s, a, b, seed, cell, gene):
@@ -46,9 +46,9 @@
 #define PRNB_CLONES
 #endif
 
-/* ---- sampler constants (part of the PRNB-5 definition) ------------------ */
-#define PRNB_LIGHT_T2     27.4112f     /* inversion iff theta <= 16 and t2 = -log2 P(X=0) < 27.4112 (19/ln 2): P0 * 2^32 >= 24 */
-#define PRNB_LIGHT_THETA  16.0f        /* tail ratio theta/(1+theta) <= 16/17 */
+/* ---- sampler constants (part of the PRNB-6 definition) ------------------ */
+#define PRNB_LIGHT_T2     27.4112f     /* inversion iff theta <= 24 and t2 = -log2 P(X=0) < 27.4112 (19/ln 2): P0 * 2^32 >= 24 */
+#define PRNB_LIGHT_THETA  24.0f        /* tail ratio theta/(1+theta) <= 24/25 (PRNB-6; 16 in PRNB-6) */
 #define PRNB_THETA_MIN    1.1920929e-7f  /* 2^-23: 1 + theta > 1 in binary32; below this NB == Poisson to 1e-7 of the variance */
 #define PRNB_THETA_MAX    1.0e18f
 #define PRNB_R_MIN        9.094947e-13f  /* 2^-40: P(X>0) < 2^-32, return 0 */

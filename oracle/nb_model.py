@@ -93,7 +93,7 @@ class philox_rounds_for_draws:
 
 MATH = dict(rcp=0, log=1, log1p=2, exp=3, cos2pi=4, unif=5, log1pmx=6)
 
-# ---- the hardware-function tables of PRNB-5 (see nb_model.c: hw_rcp / hw_log2 / hw_exp2neg) -------------------
+# ---- the hardware-function tables of PRNB-6 (see nb_model.c: hw_rcp / hw_log2 / hw_exp2neg) -------------------
 # bit-pattern ranges the tables cover: every argument the sampler can present lies inside
 ONE, TWO, THIRTY_TWO, TWO_M24 = 0x3F800000, 0x40000000, 0x42000000, 0x33800000
 HW_RANGES = dict(rcp=(ONE, TWO - ONE),                       # mantissas: v_rcp_f32 over [1, 2)

@@ -2,10 +2,10 @@
 // on its own strip of the count matrix, with LDS stacks between the stages so that every
 // stage executes with (nearly) all 64 lanes busy.
 //
-// The scalar algorithm (PRNB-5, prnb_device.h) has very different costs per sample:
+// The scalar algorithm (PRNB-6, prnb_device.h) has very different costs per sample:
 //   ~65 % of the samples of the headline workload are zeros that a 6-instruction bound
 //         settles (exp(-m * phi_gene) <= P(X = 0), prnb::zero_test_factor);
-//   the rest need P(X = 0) itself (two reciprocals, a log2 and an exp2 of the hardware: PRNB-5), and
+//   the rest need P(X = 0) itself (two reciprocals, a log2 and an exp2 of the hardware: PRNB-6), and
 //   ~33 % then walk the pmf for k >= 1 (data-dependent length, half of them end at k <= 2);
 //   ~0.1 % need gamma-Poisson.
 // Run lane-per-sample, every wave pays for its slowest lane in every one of these.  Here
@@ -29,7 +29,7 @@
 //   its lanes hold to its own region of a global list -- no atomics: one counter for all waves
 //   serialises them); sample_counts_heavy_kernel (k3_heavy.h) draws them afterwards.
 //
-// P(X = 0) is PRNB-5's: the hardware's v_rcp/v_log/v_exp ARE the definition (prnb_device.h: hw_p0), so
+// P(X = 0) is PRNB-6's: the hardware's v_rcp/v_log/v_exp ARE the definition (prnb_device.h: hw_p0), so
 // stage 2 needs no error margins and no sample is given up because it came close to a threshold (PRNB-4
 // defined P(X = 0) in polynomial arithmetic and paid for margins, a give-up list and K3h redo walks: -5 % of the
 // kernel and -0.03 ms of K3h when removed, profiles/r04_ablation.txt).
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
         }
     };
     // ---- stage 3: four pmf steps for every busy lane; idle lanes pull from S2 ------------------
-    // PRNB-5's walk (the chop-down of prnb_device.h): the terms are subtracted from a binary32 remainder, the count
+    // PRNB-6's walk (the chop-down of prnb_device.h): the terms are subtracted from a binary32 remainder, the count
     // is the first k whose subtraction leaves it negative; when a group of four ends without that
     // and its last term is under 1 (the pmf has fallen under 2^-32) the count is the group's last k.
     // A walk enters at k = 3 and advances by 4: the four reciprocals 1/(k+1)..1/(k+4) are one aligned
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
     };
 
     // ---- stage 2: P(X = 0), class test, then the terms k = 0, 1, 2, for up to 64 entries of S1 -------
-    // PRNB-5's parameters (prnb::hw_p0) and first group.  Samples of the gamma-Poisson class go to K3h's list.
+    // PRNB-6's parameters (prnb::hw_p0) and first group.  Samples of the gamma-Poisson class go to K3h's list.
     uint32_t lane16p = (uint32_t)lane * 16u + 16u;
     asm volatile("" : "+v"(lane16p));          // (kept as one register: top - lane16p is one instruction)
     // full = the stack holds at least 64 entries (every pass of the strip loop; the drain's may not)
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
         const prnb::HwP0 h = prnb::hw_p0(m, theta);
         const float qq = theta * h.iu;
         const float mpp = m * h.iu;
-        // inversion class: theta <= 16 and t2 < 19 / ln 2 (NaN: not); every other valid sample is K3h's
+        // inversion class: theta <= 24 and t2 < 19 / ln 2 (NaN: not); every other valid sample is K3h's
         const unsigned long long light_m = K3_MASK(theta <= prnb::kLightTheta) & K3_MASK(h.t2 < prnb::kLightT2);
         const float ps0 = prnb::hw_exp2(-h.t2) * 4294967296.0f;       // pmf scaled by 2^32 (exact scaling)
         // the terms: P(k+1) = P(k) * (q + (mp - q)/(k+1)), the ratio by one fma from the 1/k table (k = 0: P(0) * mp)

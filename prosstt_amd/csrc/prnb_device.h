@@ -1,4 +1,4 @@
-// PRNB-5 count sampler, device side (gfx950).  DESIGN.md section 4 defines it; this header holds
+// PRNB-6 count sampler, device side (gfx950).  DESIGN.md section 4 defines it; this header holds
 // its building blocks -- the counter generator, the functions of the definition, the
 // parameters of a sample, the inversion walk -- that the kernels (k3_stream.h, k3_heavy.h,
 // nb_params_kernel) are made of.  Replaces, per (cell, gene):
@@ -21,14 +21,15 @@
 
 namespace prnb {
 
-constexpr float kLightT2 = 27.4112f;   // inversion iff theta <= 16 and t2 = -log2 P(X=0) < 27.4112 (= 19 / ln 2): P0 * 2^32 >= 24
-constexpr float kLightTheta = 16.0f;   // tail ratio <= 16/17
+constexpr float kLightT2 = 27.4112f;   // inversion iff theta <= 24 and t2 = -log2 P(X=0) < 27.4112 (= 19 / ln 2): P0 * 2^32 >= 24
+constexpr float kLightTheta = 24.0f;   // tail ratio <= 24/25 (PRNB-6; 16 until round 5: the samples between are cheaper as walks than as
+                                       // gamma-Poisson draws -- K3h -35 % on a 32-branch tree for +0.4 % of the stream kernel, profiles/r05_ablation.txt section 7)
 constexpr float kThetaMin = 1.1920929e-7f;   // 2^-23: 1 + theta > 1 in binary32 (below this NB == Poisson to 1e-7 of the variance)
 constexpr float kThetaMax = 1.0e18f;
 constexpr float kRMin = 9.094947e-13f;       // 2^-40
 // The inversion walk ends at k = kWalkEnd at the latest: the group k = 1019..1022 is the last one, and when it ends
-// without a negative remainder the count is 1022 (in the inversion class the mean is below 108 and the tail ratio at
-// most 16/17: P(X > 1022) < 1e-25).  The 1/k table holds 1/k for 1 <= k < kKTab (the K3h walk reads two groups ahead).
+// without a negative remainder the count is 1022 (in the inversion class the mean is below 142 and the tail ratio at
+// most 24/25: P(X > 1022) < 1e-12, scipy's nbinom.sf at the class corner).  The 1/k table holds 1/k for 1 <= k < kKTab (the K3h walk reads two groups ahead).
 constexpr int kWalkEnd = 1022;
 constexpr int kKTab = 1032;
 constexpr float kPoisInv = 10.0f;
@@ -270,7 +271,7 @@ struct Params {
     float t2;      // -log2 P(X = 0) = m * (HW_LOG2(1 + theta) * HW_RCP((1 + theta) - 1))
     float inv_th;  // det_rcp(theta): r = m * inv_th (gamma-Poisson class)
     bool valid;    // m > 0 and a*m + b - 1 > 0
-    bool light;    // inversion class: theta <= 16 and t2 < kLightT2
+    bool light;    // inversion class: theta <= kLightTheta and t2 < kLightT2
 };
 
 // Per-gene factor of the streaming kernel's zero test.  With theta = a*m + b - 1 >= b - 1 =: c
@@ -278,14 +279,14 @@ struct Params {
 // x = m * phi, phi = f(c), bounds it from above; phi = 1 (f <= 1 for every theta > 0) when that
 // argument does not apply.  A sample of the gamma-Poisson class must never pass the zero test
 // (it draws from other counter domains): t > 19 implies x > 18.9, where the test's cubic is
-// negative; theta > 16 implies the same once the gene's theta stays under 16 for every x <= 1.7 --
+// negative; theta > 24 implies the same once the gene's theta stays under 24 for every x <= 1.7 --
 // a gene for which it does not gets a huge phi, so that all of its samples take the exact path.
 __device__ __forceinline__ float zero_test_factor(float a, float bm1)
 {
     float phi = 1.0f;
     if (a >= 0.0f && bm1 >= 2.44140625e-4f) phi = det_log1p(bm1) * det_rcp(bm1);
     const float th_edge = PRNB_FMA(a, 1.7f * det_rcp(phi), bm1);      // theta at x = 1.7
-    if (!(__builtin_fmaxf(th_edge, bm1) <= 15.9f)) phi = 3.0e38f;      // also NaN
+    if (!(__builtin_fmaxf(th_edge, bm1) <= kLightTheta - 0.1f)) phi = 3.0e38f;      // also NaN
     return phi;
 }
 

@@ -553,7 +553,7 @@ def draw_counts(tree, pseudotime, branches, scalings, alpha, beta, *, seed=None,
     One launch of the fused HIP sampler: gather the cell's row of the mean tensor,
     scale it, form the negative-binomial parameters of ``count_model.get_pr_umi`` and
     draw.  Counts follow the reference's law, NB(n = r, p = 1 - p); the random
-    stream is the counter-based PRNB-5, not numpy's MT19937,
+    stream is the counter-based PRNB-6, not numpy's MT19937,
     so individual values differ from the reference at equal numpy seed.
 
     New keyword-only options

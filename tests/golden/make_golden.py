@@ -231,9 +231,11 @@ def g7_nb_tables():
             (100.0, 0.05, 1.5), (100.0, 1.2, 4.0), (400.0, 0.2, 2.0), (3000.0, 0.25, 2.0),
             (3.0, 5.0, 2.0), (20.0, 0.0, 1.0 + 1e-8), (0.7, 0.0, 1.0 + 1e-8), (2.0, 0.0, 7.0),
             (8.0, 3.0, 1.0), (50.0, 1e-4, 1.2),
-            # the inversion class reaches beyond m = 19 where the NB is overdispersed (-log P0 <= 19, theta <= 16)
+            # the inversion class reaches beyond m = 19 where the NB is overdispersed (-log P0 <= 19, theta <= 16 in PRNB-5)
             (60.0, 0.2, 2.0), (75.0, 0.1, 3.0), (80.0, 0.1, 3.0), (106.0, 0.0, 17.0), (40.0, 0.37, 2.0),
-            (44.0, 0.37, 2.0), (25.0, 0.02, 1.3)]
+            (44.0, 0.37, 2.0), (25.0, 0.02, 1.3),
+            # PRNB-6: the inversion class up to theta <= 24 -- its new corner (long walks), the middle of the new range, just outside by -log P0
+            (135.0, 0.163, 2.0), (100.0, 0.2, 2.0), (140.0, 0.157, 2.0), (60.0, 0.38, 1.2)]
     kmax = 4096
     k = np.arange(kmax)
     pmf = np.zeros((len(grid), kmax))

@@ -75,10 +75,10 @@ def test_both_kernels_agree_on_a_heavy_workload():
     ctx = device.get_context()
     rng = np.random.default_rng(8)
     rows, G, N = 40, 1300, 700
-    means = np.exp(rng.normal(3.5, 1.5, (rows, G))).astype(np.float32)
+    means = np.exp(rng.normal(4.0, 1.5, (rows, G))).astype(np.float32)
     roc = rng.integers(0, rows, N).astype(np.int32)
     sc = np.exp(rng.normal(0, 0.7, N))
-    al = np.exp(rng.normal(np.log(0.4), 0.8, G))
+    al = np.exp(rng.normal(np.log(0.6), 0.8, G))
     be = np.exp(rng.normal(0, 0.6, G)) + 1
     a = ctx.sample_counts(means, roc, sc, al, be, seed=5)
     from oracle import nb_model

@@ -1,5 +1,5 @@
 """
--m gpu: the three hardware functions of the sampler's definition (PRNB-5: v_rcp_f32, v_log_f32, v_exp_f32) as the
+-m gpu: the three hardware functions of the sampler's definition (PRNB-6: v_rcp_f32, v_log_f32, v_exp_f32) as the
 scalar model sees them.  The model (oracle/nb_model.c) reads their values from tables written by the product's probe
 kernel (prosstt_amd_hw_math); two of its lookups rest on properties of the hardware that are checked here over
 EVERY argument the sampler can present:
@@ -42,8 +42,8 @@ def test_accuracy_and_model_lookup():
     assert nb_model.hw_mode()
     ctx = device.get_context()
     rng = np.random.default_rng(5)
-    # log2 over (1, 17], the quotient log2(u)/(u - 1), exp2(-t2) over [0, 27.4112): relative to binary64
-    u = np.concatenate([1.0 + np.exp(rng.uniform(np.log(2.0 ** -23), np.log(16.0), 400000)), [1.0 + 2.0 ** -23, 17.0]]).astype(np.float32)
+    # log2 over (1, 25], the quotient log2(u)/(u - 1), exp2(-t2) over [0, 27.4112): relative to binary64
+    u = np.concatenate([1.0 + np.exp(rng.uniform(np.log(2.0 ** -23), np.log(24.0), 400000)), [1.0 + 2.0 ** -23, 17.0, 25.0]]).astype(np.float32)
     lg = nb_model.hw_math("log2", u)
     ref = np.log2(u.astype(np.float64))
     assert np.max(np.abs(lg - ref) / np.abs(ref)) < 2e-7

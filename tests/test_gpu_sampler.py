@@ -1,7 +1,7 @@
 """
 -m gpu: the HIP count sampler (K3) against the oracle, through the C ABI.
 
- * counts: BIT-EXACT against oracle/nb_model.c (the scalar C model of PRNB-5, reading the device's own tables of v_rcp/v_log/v_exp) on the
+ * counts: BIT-EXACT against oracle/nb_model.c (the scalar C model of PRNB-6, reading the device's own tables of v_rcp/v_log/v_exp) on the
    same seeded inputs -- integer work, no tolerance;
  * (mu, p, r): bit-exact against the model AND within rtol 1e-6 of the reference's
    float64 get_pr_umi (count_model.py:156-158) -- the stated fp32 tolerance;
@@ -91,16 +91,16 @@ def test_edge_parameters_bit_exact(ctx):
 
 
 def test_inversion_class_limit_and_invalid_inputs_bit_exact(ctx, monkeypatch):
-    """The inversion class is `theta <= 16 and -log P0 <= 19`; everything else -- including
-    non-positive, infinite and NaN means, alpha < 0, beta < 1, beta - 1 > 16 -- takes the
-    gamma-Poisson kernel or is a 0 by definition (genes whose theta can pass 16 at small means
+    """The inversion class is `theta <= 24 and -log P0 <= 19`; everything else -- including
+    non-positive, infinite and NaN means, alpha < 0, beta < 1, beta - 1 > 24 -- takes the
+    gamma-Poisson kernel or is a 0 by definition (genes whose theta can pass 24 at small means
     skip the zero test: prnb::zero_test_factor).  Unchecked mode, bit-exact
     against the model; the path codes of nb_params agree with the model's too."""
     from oracle import nb_model
     rng = np.random.default_rng(77)
     alphas = np.array([0.0, 1e-4, 0.2, 0.79, 0.8, 1.0, 3.0, 50.0, -0.1, -2.0, np.nan, 0.3])
-    betas = np.array([1.0, 1 + 1e-8, 0.5, 2.0, 3.0, 16.9, 17.0, 17.1, 40.0, 1.5, np.nan])
-    G = len(alphas) * len(betas)                       # 132: ragged against the 256-gene tile, G % 4 == 0
+    betas = np.array([1.0, 1 + 1e-8, 0.5, 2.0, 3.0, 16.9, 17.0, 17.1, 24.9, 25.0, 25.1, 40.0, 1.5, np.nan])
+    G = len(alphas) * len(betas)                       # 168: ragged against the 256-gene tile, G % 4 == 0
     al, be = [x.ravel() for x in np.meshgrid(alphas, betas, indexing="ij")]
     rows = 24
     means = np.exp(rng.normal(0.5, 2.0, (rows, G))).astype(np.float32)
@@ -149,7 +149,7 @@ def test_many_gamma_poisson_samples_overflow_the_list(ctx):
 
 
 def test_long_inversion_walks_bit_exact(ctx):
-    """Means of 20-100 with theta <= 16 are drawn by inversion (walks of a hundred terms and more,
+    """Means of 20-100 with theta <= 24 are drawn by inversion (walks of a hundred terms and more,
     results far later than their row's store): bit-exact, and the class is the model's."""
     from oracle import nb_model
     rng = np.random.default_rng(8)
@@ -229,26 +229,29 @@ def test_deferred_domain_check_and_cached_row_flags(ctx):
         ctx.sample_counts(means, roc, sc, al, be, seed=3, check_domain=True)
 
 
-def test_corner_of_the_inversion_class_long_walks(ctx):
-    """5e7 samples at the corner of the inversion class -- theta about 14.8, mean about 101, tail ratio 0.937: the
-    longest walks the class has (hundreds of terms; round 3's definition let such walks run past the 1/k table).
-    Counts equal the model's one for one; nothing above the walk's end; first two moments hold."""
+@pytest.mark.parametrize("m0,theta0", [(101.0, 14.8), (136.0, 23.2)])
+def test_corner_of_the_inversion_class_long_walks(ctx, m0, theta0):
+    """5e7 samples at the corner of the inversion class -- PRNB-6's (theta about 23.2, mean about 136, tail ratio 0.959)
+    and PRNB-6's (theta about 14.8, mean about 101): the longest walks the class has (hundreds of terms; round 3's
+    definition let such walks run past the 1/k table).  Counts equal the model's one for one; nothing above the
+    walk's end; first two moments hold."""
     from oracle import nb_model
     rng = np.random.default_rng(8)
     G, N = 20000, 2500
-    means = (101.0 * np.exp(rng.normal(0, 0.03, (4, G)))).astype(np.float32)
+    means = (m0 * np.exp(rng.normal(0, 0.03, (4, G)))).astype(np.float32)
     roc = rng.integers(0, 4, N).astype(np.int32)
     sc = np.exp(rng.normal(0, 0.02, N))
-    al = np.full(G, 13.8 / 101.0)
+    al = np.full(G, (theta0 - 1.0) / m0)
     be = np.full(G, 2.0)
     got = ctx.sample_counts(means, roc, sc, al, be, seed=2024).cpu().numpy()
     want = nb_model.sample_counts(means, roc, sc, al, be, 2024)
     np.testing.assert_array_equal(got, want)
     path = nb_model.nb_params(means[:, :64], roc[:50], sc[:50], al[:64], be[:64])[3]
-    assert (path == 1).mean() > 0.5                      # the inversion class, mostly (t is just under 19 around m = 101)
+    assert (path == 1).mean() > 0.5                      # the inversion class, mostly (t is just under 19 around the mean)
     mu = means[roc].astype(np.float64) * sc[:, None]
     var = al * mu * mu + be * mu
     assert abs(got.sum() / mu.sum() - 1) < 5 * np.sqrt(var.sum()) / mu.sum()
+    assert abs(((got - mu) ** 2).sum() / var.sum() - 1) < 0.01
     assert got.max() < 3000 and got.min() >= 0
 
 

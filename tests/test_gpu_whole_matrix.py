@@ -64,8 +64,8 @@ def _whole_matrix_vs_model(name, n_cells, block, grouped=False):
         # alike (mean 1, variance 2 + kappa4/v^2)
         big = mu >= 0.05
         r = mu / theta
-        # the gamma-Poisson class on its own (theta > 16 or -log P(0) > 19: 0.1-0.4 % of the samples, drawn by K3h)
-        hv = (theta > 16.0) | (r * torch.log1p(theta) > 19.0)
+        # the gamma-Poisson class on its own (theta > 24 or -log P(0) > 19: 0.1-0.2 % of the samples, drawn by K3h)
+        hv = (theta > 24.0) | (r * torch.log1p(theta) > 19.0)
         h_n += float(hv.sum()); h_x += float(x[hv].sum()); h_mu += float(mu[hv].sum()); h_v += float(v[hv].sum())
         h_chi += float(((x - mu) ** 2 / v)[hv].sum()); h_chi_var += float((2.0 + k4 / (v * v))[hv].sum())
         h_zero += float((x[hv] == 0).sum())

@@ -1,5 +1,5 @@
 """
-CPU tests of oracle/nb_model.c, the scalar C model of the device count sampler (PRNB-5; here on its libm stand-ins for the three hardware functions unless a GPU is present):
+CPU tests of oracle/nb_model.c, the scalar C model of the device count sampler (PRNB-6; here on its libm stand-ins for the three hardware functions unless a GPU is present):
 known-answer vectors of Philox4x32-10 and -7, accuracy of the deterministic binary32 math, and the
 LAW of the sampler against the reference's distribution (scipy.stats.nbinom tables of fixture
 g7 and the oracle's numpy path).  The HIP kernel is then held bit-exact to this model (-m gpu).
@@ -161,17 +161,18 @@ def test_degenerate_parameters():
 
 
 def test_inversion_class_rule():
-    """PRNB-5: inversion iff theta = a*m + b - 1 <= 16 and t2 = -log2 P(X=0) = m*log2(1+theta)/theta < 27.4112 (t < 19)
-    (P0 * 2^32 >= 24, tail ratio <= 16/17); m <= 0 or theta <= 0 is the degenerate path.  Both classes
+    """PRNB-6: inversion iff theta = a*m + b - 1 <= 24 and t2 = -log2 P(X=0) = m*log2(1+theta)/theta < 27.4112 (t < 19)
+    (P0 * 2^32 >= 24, tail ratio <= 24/25); m <= 0 or theta <= 0 is the degenerate path.  Both classes
     follow the same law, so the split must not show in the moments."""
-    means = np.array([[0.5, 18.9, 30.0, 60.0, 6.0, 8.0, 3.0, 3.0, 25.0, 2.0, 2.0, 0.0, 75.0, 80.0, 25.0, 19.5]], np.float32)
-    alpha = np.array([0.2, 0.2, 0.2, 0.2, 2.0, 2.0, 0.0, 0.0, -0.5, 0.3, np.nan, 0.2, 0.1, 0.1, 0.0, 0.0])
-    beta = np.array([2.0, 2.0, 2.0, 2.0, 2.0, 2.0, 17.0, 17.5, 30.0, 1.0, 2.0, 2.0, 3.0, 3.0, 1.0 + 1e-8, 1.0 + 1e-8])
+    means = np.array([[0.5, 18.9, 30.0, 60.0, 6.0, 8.0, 12.5, 3.0, 3.0, 3.0, 25.0, 2.0, 2.0, 0.0, 75.0, 80.0, 25.0, 19.5]], np.float32)
+    alpha = np.array([0.2, 0.2, 0.2, 0.2, 2.0, 2.0, 2.0, 0.0, 0.0, 0.0, -0.5, 0.3, np.nan, 0.2, 0.1, 0.1, 0.0, 0.0])
+    beta = np.array([2.0, 2.0, 2.0, 2.0, 2.0, 2.0, 2.0, 17.5, 25.0, 25.5, 38.0, 1.0, 2.0, 2.0, 3.0, 3.0, 1.0 + 1e-8, 1.0 + 1e-8])
     path = nm.nb_params(means, np.zeros(1, np.int32), np.ones(1), alpha, beta)[3][0]
-    #         m=.5 18.9 30 60 (t=.4, 8.9, 8.9, 12.2) | a=2: theta=13, 17 | b-1 = 16, 16.5 | a<0: theta=16.5 | b=1: theta=.6
+    #         m=.5 18.9 30 60 (t=.4, 8.9, 8.9, 12.2) | a=2: theta=13, 17, 26 | b-1 = 16.5, 24, 24.5 | a<0: theta=24.5 | b=1: theta=.6
     #         | NaN | m=0 | t=18.6, 19.2 | Poisson limit: t = m = 25 / 19.5
-    assert path.tolist() == [1, 1, 1, 1, 1, 2, 1, 2, 2, 1, 0, 0, 1, 2, 2, 2]
-    for m, a, b in ((7.4, 2.0, 2.0), (7.6, 2.0, 2.0), (75.0, 0.1, 3.0), (80.0, 0.1, 3.0), (60.0, 0.2, 2.0)):
+    assert path.tolist() == [1, 1, 1, 1, 1, 1, 2, 1, 1, 2, 2, 1, 0, 0, 1, 2, 2, 2]
+    for m, a, b in ((7.4, 2.0, 2.0), (7.6, 2.0, 2.0), (11.4, 2.0, 2.0), (11.6, 2.0, 2.0), (75.0, 0.1, 3.0), (80.0, 0.1, 3.0),
+                    (60.0, 0.2, 2.0), (135.0, 0.163, 2.0), (140.0, 0.157, 2.0)):
         x = nm.sample_iid(m, a, b, 400000, seed=5)
         var = a * m * m + b * m
         assert abs(x.mean() - m) < 5 * np.sqrt(var / x.size)

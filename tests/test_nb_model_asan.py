@@ -1,8 +1,8 @@
 """
 CPU: the scalar model of the count sampler under AddressSanitizer / UBSan at the corner of the inversion class
-(theta = 16, -log P(X = 0) just under 19: means around 107, tail ratio 16/17), where walks are longest.  Round 3's
+(theta = 24, -log P(X = 0) just under 19: means around 141, tail ratio 24/25; PRNB-5's corner at theta = 16 as well), where walks are longest.  Round 3's
 definition let a walk run past its 1/k table there (a read beyond the table in the model, beyond the LDS copy on the
-device); PRNB-5 ends every walk at k = 1022 and the table covers it.  The driver below is compiled together with
+device); PRNB-5 / PRNB-6 end every walk at k = 1022 and the table covers it.  The driver below is compiled together with
 oracle/nb_model.c (no GPU: the libm stand-ins of the three hardware functions).
 """
 import os
@@ -25,7 +25,8 @@ int main(void)
     int32_t* out = malloc(sizeof(int32_t) * n);
     /* (m, alpha, beta): theta = alpha*m + beta - 1 */
     const double cases[][3] = {{101.0, 0.1366, 2.0}, {100.0, 0.14, 2.0}, {107.0, 0.1402, 2.0}, {106.9, 0.0, 17.0},
-                               {60.0, 0.25, 2.0}, {18.9, 0.0, 1.00000001}, {90.0, 0.1, 3.0}};
+                               {60.0, 0.25, 2.0}, {18.9, 0.0, 1.00000001}, {90.0, 0.1, 3.0},
+                               {141.0, 0.1631, 2.0}, {135.0, 0.163, 2.0}, {141.5, 0.0, 25.0}, {120.0, 0.19, 2.0}};
     long worst = 0;
     for (unsigned c = 0; c < sizeof(cases) / sizeof(cases[0]); ++c) {
         prnb_sample_iid((float)cases[c][0], cases[c][1], cases[c][2], 77 + c, 1000000ull * c, c, n, out);

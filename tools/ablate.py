@@ -313,6 +313,15 @@ VARIANTS.update({
 })
 
 
+# round 5 (timing only: another DEFINITION -- the model is not changed along): the inversion class up to theta 24 / 32 instead of 16
+VARIANTS.update({
+    "light24": [("constexpr float kLightTheta = 16.0f;", "constexpr float kLightTheta = 24.0f;"),
+                ("    if (!(__builtin_fmaxf(th_edge, bm1) <= 15.9f)) phi = 3.0e38f;", "    if (!(__builtin_fmaxf(th_edge, bm1) <= 23.9f)) phi = 3.0e38f;")],
+    "light32": [("constexpr float kLightTheta = 16.0f;", "constexpr float kLightTheta = 32.0f;"),
+                ("    if (!(__builtin_fmaxf(th_edge, bm1) <= 15.9f)) phi = 3.0e38f;", "    if (!(__builtin_fmaxf(th_edge, bm1) <= 31.9f)) phi = 3.0e38f;")],
+})
+
+
 def build(name):
     work = os.path.join(OUT, "src_" + name)
     shutil.rmtree(work, ignore_errors=True)

@@ -42,9 +42,9 @@ def main():
         theta = np.asarray(work.alpha, dtype=np.float64)[hg] * m + np.asarray(work.beta, dtype=np.float64)[hg] - 1.0
         r = m / theta
         cnt = count[heavy]
-        print("   gamma-Poisson class: theta > 16: %.1f %%; shape r = m/theta < 1: %.1f %%; m percentiles 10/50/90 = %.1f/%.1f/%.1f; "
+        print("   gamma-Poisson class: theta > 24: %.1f %%; shape r = m/theta < 1: %.1f %%; m percentiles 10/50/90 = %.1f/%.1f/%.1f; "
               "theta 10/50/90 = %.1f/%.1f/%.1f; counts: 0: %.1f %%, < 10: %.1f %%, mean %.1f"
-              % (100.0 * (theta > 16).mean(), 100.0 * (r < 1).mean(), *np.percentile(m, [10, 50, 90]), *np.percentile(theta, [10, 50, 90]),
+              % (100.0 * (theta > 24).mean(), 100.0 * (r < 1).mean(), *np.percentile(m, [10, 50, 90]), *np.percentile(theta, [10, 50, 90]),
                  100.0 * (cnt == 0).mean(), 100.0 * (cnt < 10).mean(), cnt.mean()))
 
 
