@@ -292,7 +292,11 @@ VARIANTS.update({
                  ("    uint64_t row2 = cinfo[2].row_bytes;\n", "    uint64_t row2 = cinfo[2].row_bytes, row1 = cinfo[1].row_bytes;\n")],
     "run16b": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 16;")],
     "run24": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 24;")],
-    "run40b": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 40;"), ("constexpr int kS2Cap = 96;", "constexpr int kS2Cap = 104;")],
+    "run32c": [("constexpr int kS2Run = 40;", "constexpr int kS2Run = 32;")],
+    "run48c": [("constexpr int kS2Run = 40;", "constexpr int kS2Run = 48;"), ("constexpr int kS2Cap = 104;", "constexpr int kS2Cap = 112;")],
+    "bail4": [("constexpr int kBail = 6;", "constexpr int kBail = 4;")],
+    "bail8": [("constexpr int kBail = 6;", "constexpr int kBail = 8;")],
+    "bail12": [("constexpr int kBail = 6;", "constexpr int kBail = 12;")],
     "run44": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 44;"), ("constexpr int kS2Cap = 96;", "constexpr int kS2Cap = 108;")],
     "run48b": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 48;"), ("constexpr int kS2Cap = 96;", "constexpr int kS2Cap = 112;")],
     "run48_bail10": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 48;"), ("constexpr int kS2Cap = 96;", "constexpr int kS2Cap = 112;"), ("constexpr int kBail = 6;", "constexpr int kBail = 10;")],
