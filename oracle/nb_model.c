@@ -48,7 +48,7 @@
 
 /* ---- sampler constants (part of the PRNB-6 definition) ------------------ */
 #define PRNB_LIGHT_T2     27.4112f     /* inversion iff theta <= 24 and t2 = -log2 P(X=0) < 27.4112 (19/ln 2): P0 * 2^32 >= 24 */
-#define PRNB_LIGHT_THETA  24.0f        /* tail ratio theta/(1+theta) <= 24/25 (PRNB-6; 16 in PRNB-6) */
+#define PRNB_LIGHT_THETA  24.0f        /* tail ratio theta/(1+theta) <= 24/25 (PRNB-6; 16 in PRNB-5) */
 #define PRNB_THETA_MIN    1.1920929e-7f  /* 2^-23: 1 + theta > 1 in binary32; below this NB == Poisson to 1e-7 of the variance */
 #define PRNB_THETA_MAX    1.0e18f
 #define PRNB_R_MIN        9.094947e-13f  /* 2^-40: P(X>0) < 2^-32, return 0 */

@@ -1,5 +1,5 @@
 // K3h: the samples the streaming kernel (k3_stream.h) listed instead of drawing them: the
-// gamma-Poisson class of PRNB-6 (prnb_device.h; theta above 16 or -log2 P(X = 0) of 27.4 or more, one or
+// gamma-Poisson class of PRNB-6 (prnb_device.h; theta above 24 or -log2 P(X = 0) of 27.4 or more, one or
 // two in a thousand of a typical workload), the walks that were still running when their strip was done
 // and the walks that passed k = 254 (both redone here from k = 0).
 // Both halves of the gamma-Poisson path are rejection samplers; run lane-per-sample
