@@ -151,6 +151,17 @@ int prosstt_amd_hw_math(prosstt_amd_ctx* ctx, int32_t op, uint32_t first_bits, u
                         uint32_t flags);
 
 /*
+ * The gather form of the same probe:  out[i] = f(x[i]),  i < count;  op 0..2 as above, 3: v_sqrt_f32(x),
+ * 4: v_rsq_f32(x), 5: v_cos_f32(x) (x in revolutions: cos(2 pi x)).  The gamma-Poisson class of the sampler (PRNB-7)
+ * evaluates its logarithms, square roots, cosines and exponentials by these instructions over arguments no table can
+ * enumerate; the checking model asks the device for them argument by argument, level by level of its evaluation.
+ * Replaces nothing of the reference (numpy's legacy gamma / Poisson behind simulation.py:647-648 call libm).
+ * `x`: DEVICE, or HOST with PROSSTT_AMD_HOST_INPUTS; `out`: DEVICE, or HOST with PROSSTT_AMD_HOST_OUTPUT.
+ */
+int prosstt_amd_hw_math_at(prosstt_amd_ctx* ctx, int32_t op, const float* x, uint64_t count, float* out,
+                           uint32_t flags);
+
+/*
  * Host only (no device, no ctx): the variates of `attempts` consecutive simulation.sim_expr_branch(T, K) calls
  * (simulation.py:21-86; per walk, simulation.diffusion's draws, simulation.py:104-113: uniform(0, 1.5),
  * normal(0, 0.2), uniform(0, 1), normal(0, 2/T) x (T-1)) taken from numpy's legacy global stream (MT19937,

@@ -275,71 +275,166 @@ static inline int32_t chop_down(uint32_t w, float ps, float mp, float q)
     }
 }
 
-/* Poisson(lam) on counter domain 0x80000000+j of (cell, gene). */
-static inline int32_t poisson_draw(float lam, uint32_t c0, uint32_t c1, uint32_t gene,
-                                   uint32_t k0, uint32_t k1)
+/* ---- the gamma-Poisson class: hardware transcendentals by QUERY ------------------------------------------------
+ * PRNB-7 draws this class with the gfx950 instructions v_log_f32, v_exp_f32, v_sqrt_f32, v_rsq_f32, v_cos_f32 (and
+ * v_rcp_f32: the mantissa table above) over arguments no table can enumerate.  The model therefore ASKS the device:
+ * a sample's evaluation runs until it needs values it does not have, registers the (op, x) pairs, and stops; the
+ * resolver below collects the questions of all waiting samples, has the product's probe answer them in one call per
+ * round (prosstt_amd_hw_math_at: y[i] = op(x[i]) on the device under test), appends the answers to each sample's tape
+ * and runs the sample again from the start -- it replays its tape and gets further.  An evaluation is a pure function
+ * of (sample, tape), so the replay asks the same questions in the same order (checked: the tape keeps x beside y).
+ * Without a query function (no GPU) the ops are libm stand-ins: the same law, not the same bits. */
+enum { HWOP_RCP = 0, HWOP_LOG2 = 1, HWOP_EXP2NEG = 2, HWOP_SQRT = 3, HWOP_RSQ = 4, HWOP_COS = 5, HWOP_COUNT = 6 };
+#define HWQ_MAX_ASK 4            /* questions a sample may leave open at once */
+typedef struct { float x, y; } hwq_pair;
+typedef struct {
+    const hwq_pair* tape; int len, pos;          /* answered so far / replay position */
+    int npend; int32_t pend_op[HWQ_MAX_ASK]; float pend_x[HWQ_MAX_ASK];
+} hwq;
+
+typedef void (*prnb_hw_query_fn)(int64_t n, const int32_t* op, const float* x, float* y);
+static prnb_hw_query_fn g_query = 0;
+
+static float hw_standin(int op, float x)
+{
+    switch (op) {
+    case HWOP_RCP: return 1.0f / x;
+    case HWOP_LOG2: return log2f(x);
+    case HWOP_EXP2NEG: return exp2f(-x);
+    case HWOP_SQRT: return sqrtf(x);
+    case HWOP_RSQ: return (float)(1.0 / sqrt((double)x));
+    case HWOP_COS: return (float)cos(6.283185307179586476925 * (double)x);      /* v_cos_f32 takes revolutions */
+    default: return 0.0f;
+    }
+}
+
+/* ask for op(x): *y is valid after the next HWQ_SYNC that does not leave the function */
+static inline void hwq_ask(hwq* Q, int op, float x, float* y)
+{
+    if (!Q) { *y = hw_standin(op, x); return; }
+    if (Q->pos < Q->len) {
+        if (f2u(Q->tape[Q->pos].x) != f2u(x)) {
+            fprintf(stderr, "oracle/nb_model.c: replay diverged (op %d: %a asked, %a on the tape)\n", op, (double)x, (double)Q->tape[Q->pos].x);
+            abort();
+        }
+        *y = Q->tape[Q->pos++].y;
+        return;
+    }
+    if (Q->npend >= HWQ_MAX_ASK) { fprintf(stderr, "oracle/nb_model.c: too many open questions\n"); abort(); }
+    Q->pend_op[Q->npend] = op;
+    Q->pend_x[Q->npend] = x;
+    Q->npend += 1;
+    *y = 0.0f;
+}
+#define HWQ_SYNC(Q) do { if ((Q) && (Q)->npend) return 0; } while (0)
+
+#define LN2_F     0.69314718f
+#define LOG2E_F   1.44269504f
+#define M2LN2_F   (-1.3862944f)
+#define TWO_M32_F 2.3283064365386963e-10f
+
+/* log(1+d) - d: the polynomial where the difference cancels, the hardware's log2 of rho = 1 + d elsewhere */
+static inline int hq_log1pmx(hwq* Q, float d, float rho, float* out)
+{
+    if (d >= -0.29289323f && d < 0.41421354f) { *out = FMA(-0.5f, d * d, log_tail(d)); return 1; }
+    float l;
+    hwq_ask(Q, HWOP_LOG2, rho, &l);
+    HWQ_SYNC(Q);
+    *out = FMA(LN2_F, l, -d);
+    return 1;
+}
+
+/* Poisson(lam) on counter domain 0x80000000+j of (cell, gene).  Returns 1 when *out is final, 0 when it waits. */
+static inline int poisson_draw(hwq* Q, float lam, uint32_t c0, uint32_t c1, uint32_t gene,
+                               uint32_t k0, uint32_t k1, int32_t* out)
 {
     uint32_t w[4];
-    if (!(lam > 0.0f)) return 0;
+    *out = 0;
+    if (!(lam > 0.0f)) return 1;
     if (lam < PRNB_POIS_INV) {
+        float p0;
+        hwq_ask(Q, HWOP_EXP2NEG, lam * LOG2E_F, &p0);
+        HWQ_SYNC(Q);
         philox_count(c0, c1, gene, 0x80000000u, k0, k1, w);
-        return chop_down(w[0], fminf(det_exp(-lam), 0.99999994f) * 4294967296.0f, lam, 0.0f);
+        *out = chop_down(w[0], fminf(p0, 0.99999994f) * 4294967296.0f, lam, 0.0f);
+        return 1;
     }
-    float slam = sqrtf(lam);
+    float slam;
+    hwq_ask(Q, HWOP_SQRT, lam, &slam);
     if (!(lam < PRNB_LAM_BIG)) {               /* rounded normal; never reached with abs_max=5000 */
+        float l, c, s;
         philox_count(c0, c1, gene, 0x80000000u, k0, k1, w);
-        float z = sqrtf(-2.0f * det_log(unif(w[0]))) * det_cos2pi(w[1]);
-        float kf = floorf(FMA(slam, z, lam) + 0.5f);
-        return (int32_t)fminf(fmaxf(kf, 0.0f), 2147483520.0f);
+        hwq_ask(Q, HWOP_LOG2, unif(w[0]), &l);
+        hwq_ask(Q, HWOP_COS, (float)w[1] * TWO_M32_F, &c);
+        HWQ_SYNC(Q);
+        hwq_ask(Q, HWOP_SQRT, M2LN2_F * l, &s);
+        HWQ_SYNC(Q);
+        float kf = floorf(FMA(slam, s * c, lam) + 0.5f);
+        *out = (int32_t)fminf(fmaxf(kf, 0.0f), 2147483520.0f);
+        return 1;
     }
+    HWQ_SYNC(Q);
     /* PTRS, Hoermann 1993 (the algorithm behind numpy's random_poisson for lam >= 10) */
     float bb = FMA(2.53f, slam, 0.931f);
     float aa = FMA(0.02483f, bb, -0.059f);
-    float invalpha = FMA(1.1328f, det_rcp(bb - 3.4f), 1.1239f);
-    float vr = FMA(-3.6224f, det_rcp(bb - 2.0f), 0.9277f);
+    float invalpha = FMA(1.1328f, hw_rcp(bb - 3.4f), 1.1239f);
+    float vr = FMA(-3.6224f, hw_rcp(bb - 2.0f), 0.9277f);
     float kf = floorf(lam);
     for (int j = 0; j < 2 * PRNB_MAX_TRIES; ++j) {
         if ((j & 1) == 0) philox_count(c0, c1, gene, 0x80000000u + (uint32_t)(j >> 1), k0, k1, w);
         float U = unif(w[(j & 1) * 2]) - 0.5f;
         float V = unif(w[(j & 1) * 2 + 1]);
         float us = fmaxf(0.5f - fabsf(U), 5.8207661e-11f);       /* 2^-34 */
-        float rus = det_rcp(us);
+        float rus = hw_rcp(us);
         kf = floorf(FMA(FMA(2.0f * aa, rus, bb), U, lam + 0.43f));
         if (us >= 0.07f && V <= vr) break;
         if (kf < 0.0f || (us < 0.013f && V > us)) { kf = floorf(lam); continue; }
-        float lhs = det_log((V * invalpha) * det_rcp(FMA(aa * rus, rus, bb)));
-        float rhs;
+        float l1, l2, rhs;
+        hwq_ask(Q, HWOP_LOG2, (V * invalpha) * hw_rcp(FMA(aa * rus, rus, bb)), &l1);
         if (kf < 10.0f) {
-            rhs = FMA(kf, det_log(lam), -lam) - LOGFACT[(int)kf];
+            hwq_ask(Q, HWOP_LOG2, lam, &l2);
+            HWQ_SYNC(Q);
+            rhs = FMA(kf, LN2_F * l2, -lam) - LOGFACT[(int)kf];
         } else {
-            float rk = det_rcp(kf);
+            float rk = hw_rcp(kf);
             float d = (lam - kf) * rk;
-            float lp = det_log1pmx(d, lam * rk);
+            float lp;
+            hwq_ask(Q, HWOP_LOG2, 6.2831855f * kf, &l2);
+            if (!hq_log1pmx(Q, d, lam * rk, &lp)) return 0;
+            HWQ_SYNC(Q);
             float st = rk * FMA(-0.0027777778f, rk * rk, 0.083333336f);
-            rhs = FMA(kf, lp, FMA(-0.5f, det_log(6.2831855f * kf), -st));
+            rhs = FMA(kf, lp, FMA(-0.5f, LN2_F * l2, -st));
         }
-        if (lhs <= rhs) break;
+        if (LN2_F * l1 <= rhs) break;
         kf = floorf(lam);
     }
-    return (int32_t)fminf(fmaxf(kf, 0.0f), 2147483520.0f);
+    *out = (int32_t)fminf(fmaxf(kf, 0.0f), 2147483520.0f);
+    return 1;
 }
 
 /* Gamma(r) * theta on counter domain 1+i of (cell, gene): Marsaglia-Tsang 2000,
- * Box-Muller normal, U^(1/r) boost below r = 1. */
-static inline float gamma_scaled(float r, float theta, uint32_t c0, uint32_t c1, uint32_t gene,
-                                 uint32_t k0, uint32_t k1)
+ * Box-Muller normal, U^(1/r) boost below r = 1.  Returns 1 when *lam is final, 0 when it waits. */
+static inline int gamma_scaled(hwq* Q, float r, float theta, uint32_t c0, uint32_t c1, uint32_t gene,
+                               uint32_t k0, uint32_t k1, float* lam)
 {
     uint32_t w[4];
     int boost = r < 1.0f;
     float rr = boost ? r + 1.0f : r;
     float dd = rr - 0.33333334f;
-    float cc = det_rcp(3.0f * sqrtf(dd));
+    float cc;
+    hwq_ask(Q, HWOP_RSQ, 9.0f * dd, &cc);
     float v = 1.0f;
     for (int i = 0; i < PRNB_MAX_TRIES; ++i) {
         /* every attempt is a pure function of (i, parameters); attempt MAX_TRIES-1 is final */
         const int last = (i == PRNB_MAX_TRIES - 1);
+        float l, c, s;
         philox_count(c0, c1, gene, 1u + (uint32_t)i, k0, k1, w);
-        float x = sqrtf(-2.0f * det_log(unif(w[0]))) * det_cos2pi(w[1]);
+        hwq_ask(Q, HWOP_LOG2, unif(w[0]), &l);
+        hwq_ask(Q, HWOP_COS, (float)w[1] * TWO_M32_F, &c);
+        HWQ_SYNC(Q);
+        hwq_ask(Q, HWOP_SQRT, M2LN2_F * l, &s);
+        HWQ_SYNC(Q);
+        float x = s * c;
         float t = cc * x;
         float v1 = 1.0f + t;
         if (!(v1 > 0.0f)) {
@@ -353,32 +448,44 @@ static inline float gamma_scaled(float r, float theta, uint32_t c0, uint32_t c1,
         float x2 = x * x;
         if (u < FMA(-0.0331f, x2 * x2, 1.0f)) break;
         /* log u < x^2/2 + d*(1 - v + log v),  1 - v + log v = 3*log1pmx(t) - 3t^2 - t^3 */
-        float t2 = t * t;
-        float h = FMA(3.0f, det_log1pmx(t, v1), FMA(-t2, t, -3.0f * t2));
-        if (det_log(u) < FMA(dd, h, 0.5f * x2)) break;
+        float t2 = t * t, lu, lp;
+        hwq_ask(Q, HWOP_LOG2, u, &lu);
+        if (!hq_log1pmx(Q, t, v1, &lp)) return 0;
+        HWQ_SYNC(Q);
+        float h = FMA(3.0f, lp, FMA(-t2, t, -3.0f * t2));
+        if (LN2_F * lu < FMA(dd, h, 0.5f * x2)) break;
     }
     float g = dd * v;
-    if (boost) g = g * det_exp(det_log(unif(w[3])) * det_rcp(r));
-    return theta * g;
+    if (boost) {
+        float lb, e;
+        hwq_ask(Q, HWOP_LOG2, unif(w[3]), &lb);
+        HWQ_SYNC(Q);
+        hwq_ask(Q, HWOP_EXP2NEG, -(lb * hw_rcp(r)), &e);       /* u^(1/r) */
+        HWQ_SYNC(Q);
+        g = g * e;
+    }
+    *lam = theta * g;
+    return 1;
 }
 
 typedef struct { float m, theta, p, r; int32_t path; } prnb_detail;
 
-/* One count.  path: 0 = degenerate (returns 0), 1 = NB inversion, 2 = gamma-Poisson. */
-static inline int32_t prnb_one(float M, float s, float a, float bm1, uint32_t k0, uint32_t k1,
-                               uint64_t cell, uint32_t gene, prnb_detail* det)
+/* One count.  path: 0 = degenerate (returns 0), 1 = NB inversion, 2 = gamma-Poisson.  Returns 1 when *count is final,
+ * 0 when the sample (of the gamma-Poisson class, in query mode) waits for hardware values.  draw = 0: parameters and path only. */
+static inline int prnb_one_q(float M, float s, float a, float bm1, uint32_t k0, uint32_t k1,
+                             uint64_t cell, uint32_t gene, prnb_detail* det, hwq* Q, int draw, int32_t* count)
 {
     float m = M * s;
     float theta = FMA(a, m, bm1);
     uint32_t c0 = (uint32_t)cell, c1 = (uint32_t)(cell >> 32);
+    *count = 0;
     if (det) { det->m = m; det->theta = theta; det->p = 0.0f; det->r = 0.0f; det->path = 0; }
-    if (!(m > 0.0f) || !(theta > 0.0f)) return 0;
+    if (!(m > 0.0f) || !(theta > 0.0f)) return 1;
     theta = fminf(fmaxf(theta, PRNB_THETA_MIN), PRNB_THETA_MAX);
     const float u1 = 1.0f + theta;                       /* > 1 */
     const float iu = hw_rcp(u1);
     const float q = theta * iu;
-    const float inv_th = det_rcp(theta);
-    const float r = m * inv_th;
+    const float r = m * hw_rcp(theta);
     if (det) { det->p = q; det->r = r; }
     if (theta <= PRNB_LIGHT_THETA) {
         /* t2 = -log2 P(X = 0) = m * log2(1 + theta)/theta, the quotient taken at the theta' = u1 - 1 that u1 stands for */
@@ -386,14 +493,90 @@ static inline int32_t prnb_one(float M, float s, float a, float bm1, uint32_t k0
         if (t2 < PRNB_LIGHT_T2) {
             uint32_t w[4];
             if (det) det->path = 1;
+            if (!draw) return 1;
             philox_count(c0, c1, gene >> 2, 0u, k0, k1, w);
-            return chop_down(w[gene & 3u], hw_exp2neg(t2) * 4294967296.0f, m * iu, q);
+            *count = chop_down(w[gene & 3u], hw_exp2neg(t2) * 4294967296.0f, m * iu, q);
+            return 1;
         }
     }
     if (det) det->path = 2;
-    if (!(r >= PRNB_R_MIN)) return 0;
-    float lam = gamma_scaled(r, theta, c0, c1, gene, k0, k1);
-    return poisson_draw(lam, c0, c1, gene, k0, k1);
+    if (!draw || !(r >= PRNB_R_MIN)) return 1;
+    float lam;
+    if (!gamma_scaled(Q, r, theta, c0, c1, gene, k0, k1, &lam)) return 0;
+    return poisson_draw(Q, lam, c0, c1, gene, k0, k1, count);
+}
+
+/* ---- the resolver of waiting samples (query mode) ------------------------------------------------------------- */
+typedef struct { int64_t idx; float M, s, a, bm1; uint64_t cell; uint32_t gene; } prnb_waiting;
+typedef struct { prnb_waiting* v; int64_t n, cap; } prnb_wait_list;
+
+static void wait_push(prnb_wait_list* L, prnb_waiting w)
+{
+    if (L->n == L->cap) {
+        L->cap = L->cap ? 2 * L->cap : 1024;
+        L->v = (prnb_waiting*)realloc(L->v, (size_t)L->cap * sizeof(prnb_waiting));
+        if (!L->v) { fprintf(stderr, "oracle/nb_model.c: out of memory\n"); abort(); }
+    }
+    L->v[L->n++] = w;
+}
+
+static int64_t g_query_rounds = 0, g_query_values = 0;     /* statistics of the last resolve (tests) */
+
+/* out[W[i].idx] = the count of waiting sample i, for all n of them */
+static void resolve_waiting(const prnb_waiting* W, int64_t n, uint32_t k0, uint32_t k1, int32_t* out)
+{
+    g_query_rounds = 0;
+    g_query_values = 0;
+    if (n == 0) return;
+    if (!g_query) { fprintf(stderr, "oracle/nb_model.c: samples wait for hardware values but no query function is installed\n"); abort(); }
+    typedef struct { hwq_pair* t; int len, cap; } tape_t;
+    tape_t* tapes = (tape_t*)calloc((size_t)n, sizeof(tape_t));
+    int64_t* active = (int64_t*)malloc((size_t)n * sizeof(int64_t));
+    int32_t* pn = (int32_t*)malloc((size_t)n * sizeof(int32_t));
+    int32_t* pop = (int32_t*)malloc((size_t)n * HWQ_MAX_ASK * sizeof(int32_t));
+    float* px = (float*)malloc((size_t)n * HWQ_MAX_ASK * sizeof(float));
+    float* py = (float*)malloc((size_t)n * HWQ_MAX_ASK * sizeof(float));
+    if (!tapes || !active || !pn || !pop || !px || !py) { fprintf(stderr, "oracle/nb_model.c: out of memory\n"); abort(); }
+    for (int64_t i = 0; i < n; ++i) active[i] = i;
+    int64_t na = n;
+    while (na > 0) {
+#pragma omp parallel for schedule(dynamic, 256)
+        for (int64_t j = 0; j < na; ++j) {
+            const prnb_waiting* w = &W[active[j]];
+            tape_t* T = &tapes[active[j]];
+            hwq Q;
+            Q.tape = T->t; Q.len = T->len; Q.pos = 0; Q.npend = 0;
+            int32_t c;
+            if (prnb_one_q(w->M, w->s, w->a, w->bm1, k0, k1, w->cell, w->gene, 0, &Q, 1, &c)) {
+                out[w->idx] = c;
+                pn[j] = 0;
+            } else {
+                pn[j] = Q.npend;
+                for (int q = 0; q < Q.npend; ++q) { pop[j * HWQ_MAX_ASK + q] = Q.pend_op[q]; px[j * HWQ_MAX_ASK + q] = Q.pend_x[q]; }
+            }
+        }
+        /* compact the questions (in place: the write position never passes the read position), ask, hand out the answers */
+        int64_t nq = 0, nw = 0;
+        for (int64_t j = 0; j < na; ++j)
+            for (int q = 0; q < pn[j]; ++q, ++nq) { pop[nq] = pop[j * HWQ_MAX_ASK + q]; px[nq] = px[j * HWQ_MAX_ASK + q]; }
+        if (nq) g_query(nq, pop, px, py);
+        g_query_rounds += 1;
+        g_query_values += nq;
+        nq = 0;
+        for (int64_t j = 0; j < na; ++j) {
+            if (!pn[j]) { free(tapes[active[j]].t); tapes[active[j]].t = 0; continue; }
+            tape_t* T = &tapes[active[j]];
+            if (T->len + pn[j] > T->cap) {
+                T->cap = T->cap ? 2 * T->cap : 16;
+                T->t = (hwq_pair*)realloc(T->t, (size_t)T->cap * sizeof(hwq_pair));
+                if (!T->t) { fprintf(stderr, "oracle/nb_model.c: out of memory\n"); abort(); }
+            }
+            for (int q = 0; q < pn[j]; ++q, ++nq) { T->t[T->len].x = px[nq]; T->t[T->len].y = py[nq]; T->len += 1; }
+            active[nw++] = active[j];
+        }
+        na = nw;
+    }
+    free(tapes); free(active); free(pn); free(pop); free(px); free(py);
 }
 
 /* ---- exported entry points (ctypes) --------------------------------------- */
@@ -428,8 +611,19 @@ PRNB_EXPORT void prnb_set_hw_tables(const float* rcp_mant, const float* log2_tab
     g_log2_tab = log2_tab; g_log2_first = log2_first; g_log2_count = log2_tab ? log2_count : 0;
     g_exp2_tab = exp2_tab; g_exp2_first = exp2_first; g_exp2_count = exp2_tab ? exp2_count : 0;
 }
-/* 1: the device's tables are installed (bit-exact mode); 0: the libm stand-ins (law tests without a GPU) */
-PRNB_EXPORT int prnb_hw_mode(void) { return g_rcp_mant && g_log2_tab && g_exp2_tab; }
+/* Install (NULL: remove) the function that answers the gamma-Poisson class's questions: y[i] = op[i](x[i]) for n
+ * (op, x) pairs, ops as in the HWOP_ enum (= the op codes of prosstt_amd_hw_math_at).  Called from one thread. */
+PRNB_EXPORT void prnb_set_hw_query(prnb_hw_query_fn fn) { g_query = fn; }
+/* a query function made of the libm stand-ins: the query machinery must then reproduce the direct evaluation bit for
+ * bit (tests/test_nb_model.py: the replay mechanism checked without a GPU) */
+static void query_standins(int64_t n, const int32_t* op, const float* x, float* y)
+{
+    for (int64_t i = 0; i < n; ++i) y[i] = hw_standin(op[i], x[i]);
+}
+PRNB_EXPORT void prnb_set_hw_query_standins(void) { g_query = query_standins; }
+PRNB_EXPORT void prnb_query_stats(int64_t* rounds, int64_t* values) { *rounds = g_query_rounds; *values = g_query_values; }
+/* 1: the device's tables and query function are installed (bit-exact mode); 0: the libm stand-ins (law tests without a GPU) */
+PRNB_EXPORT int prnb_hw_mode(void) { return g_rcp_mant && g_log2_tab && g_exp2_tab && g_query && g_query != query_standins; }
 
 /* the model's view of the hardware functions (tests of the tables): which = 0 HW_RCP(x), 1 HW_LOG2(x), 2 HW_EXP2(-x) */
 PRNB_EXPORT void prnb_hw_math(int which, const float* x, float* y, int64_t n)
@@ -458,6 +652,7 @@ PRNB_EXPORT PRNB_CLONES void prnb_math(int which, const float* x, float* y, int6
 /*
  * Same signature as the product's prosstt_amd_sample_counts (include/prosstt_amd.h)
  * minus flags/stream: counts[n*ld + g] for cell n (global index cell_offset+n), gene g.
+ * In query mode the samples of the gamma-Poisson class are collected and resolved together (resolve_waiting).
  */
 PRNB_EXPORT PRNB_CLONES void prnb_sample_counts(const float* means, int64_t rows, int32_t G,
                                                 const int32_t* row_of_cell, const double* scaling,
@@ -467,15 +662,33 @@ PRNB_EXPORT PRNB_CLONES void prnb_sample_counts(const float* means, int64_t rows
 {
     (void)rows;
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma omp parallel for schedule(static)
-    for (int64_t n = 0; n < N; ++n) {
-        const float* mrow = means + (int64_t)row_of_cell[n] * G;
-        float s = (float)scaling[n];
-        for (int32_t g = 0; g < G; ++g)
-            out[n * ld + g] = prnb_one(mrow[g], s, GENE_A(alpha, g), GENE_BM1(beta, g), k0, k1,
-                                       cell_index ? (uint64_t)cell_index[n] : cell_offset + (uint64_t)n,
-                                       (uint32_t)g, 0);
+    prnb_wait_list all = {0, 0, 0};
+#pragma omp parallel
+    {
+        prnb_wait_list mine = {0, 0, 0};
+        hwq Q;
+#pragma omp for schedule(static) nowait
+        for (int64_t n = 0; n < N; ++n) {
+            const float* mrow = means + (int64_t)row_of_cell[n] * G;
+            float s = (float)scaling[n];
+            const uint64_t cell = cell_index ? (uint64_t)cell_index[n] : cell_offset + (uint64_t)n;
+            for (int32_t g = 0; g < G; ++g) {
+                Q.tape = 0; Q.len = 0; Q.pos = 0; Q.npend = 0;
+                if (!prnb_one_q(mrow[g], s, GENE_A(alpha, g), GENE_BM1(beta, g), k0, k1, cell, (uint32_t)g, 0,
+                                g_query ? &Q : 0, 1, &out[n * ld + g])) {
+                    prnb_waiting w = {n * ld + g, mrow[g], s, GENE_A(alpha, g), GENE_BM1(beta, g), cell, (uint32_t)g};
+                    wait_push(&mine, w);
+                }
+            }
+        }
+#pragma omp critical
+        {
+            for (int64_t i = 0; i < mine.n; ++i) wait_push(&all, mine.v[i]);
+        }
+        free(mine.v);
     }
+    resolve_waiting(all.v, all.n, k0, k1, out);
+    free(all.v);
 }
 
 /* Deterministic intermediates (mu, p, r) exactly as the kernel forms them, plus the path taken. */
@@ -489,8 +702,8 @@ PRNB_EXPORT PRNB_CLONES void prnb_nb_params(const float* means, int64_t rows, in
         const float* mrow = means + (int64_t)row_of_cell[n] * G;
         for (int32_t g = 0; g < G; ++g) {
             prnb_detail d;
-            prnb_one(mrow[g], (float)scaling[n], GENE_A(alpha, g), GENE_BM1(beta, g), 0u, 0u, 0u,
-                     (uint32_t)g, &d);
+            int32_t c;
+            prnb_one_q(mrow[g], (float)scaling[n], GENE_A(alpha, g), GENE_BM1(beta, g), 0u, 0u, 0u, (uint32_t)g, &d, 0, 0, &c);
             mu[n * (int64_t)G + g] = d.m; p[n * (int64_t)G + g] = d.p; r[n * (int64_t)G + g] = d.r;
             if (path) path[n * (int64_t)G + g] = d.path;
         }
@@ -507,16 +720,24 @@ PRNB_EXPORT PRNB_CLONES void prnb_sample_selected(const float* means, int64_t ro
 {
     (void)rows;
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma omp parallel for schedule(static)
+    prnb_wait_list all = {0, 0, 0};
     for (int64_t i = 0; i < count; ++i) {
         const int64_t n = cells[i];
         const int32_t g = genes[i];
         const uint64_t cell = cell_index ? (uint64_t)cell_index[n] : cell_offset + (uint64_t)n;
         prnb_detail d;
-        out_count[i] = prnb_one(means[(int64_t)row_of_cell[n] * G + g], (float)scaling[n], GENE_A(alpha, g), GENE_BM1(beta, g),
-                                k0, k1, cell, (uint32_t)g, &d);
+        hwq Q;
+        Q.tape = 0; Q.len = 0; Q.pos = 0; Q.npend = 0;
+        const float M = means[(int64_t)row_of_cell[n] * G + g];
+        if (!prnb_one_q(M, (float)scaling[n], GENE_A(alpha, g), GENE_BM1(beta, g), k0, k1, cell, (uint32_t)g, &d,
+                        g_query ? &Q : 0, 1, &out_count[i])) {
+            prnb_waiting w = {i, M, (float)scaling[n], GENE_A(alpha, g), GENE_BM1(beta, g), cell, (uint32_t)g};
+            wait_push(&all, w);
+        }
         out_path[i] = d.path;
     }
+    resolve_waiting(all.v, all.n, k0, k1, out_count);
+    free(all.v);
 }
 
 /*
@@ -558,7 +779,22 @@ PRNB_EXPORT PRNB_CLONES void prnb_sample_iid(float m, double a, double b, uint64
                                              int32_t* out)
 {
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const float af = (float)a, bm1 = (float)(b - 1.0);
+    if (!g_query) {
 #pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i < n; ++i)
-        out[i] = prnb_one(m, 1.0f, (float)a, (float)(b - 1.0), k0, k1, first_cell + (uint64_t)i, gene, 0);
+        for (int64_t i = 0; i < n; ++i)
+            prnb_one_q(m, 1.0f, af, bm1, k0, k1, first_cell + (uint64_t)i, gene, 0, 0, 1, &out[i]);
+        return;
+    }
+    prnb_wait_list all = {0, 0, 0};
+    for (int64_t i = 0; i < n; ++i) {
+        hwq Q;
+        Q.tape = 0; Q.len = 0; Q.pos = 0; Q.npend = 0;
+        if (!prnb_one_q(m, 1.0f, af, bm1, k0, k1, first_cell + (uint64_t)i, gene, 0, &Q, 1, &out[i])) {
+            prnb_waiting w = {i, m, 1.0f, af, bm1, first_cell + (uint64_t)i, gene};
+            wait_push(&all, w);
+        }
+    }
+    resolve_waiting(all.v, all.n, k0, k1, out);
+    free(all.v);
 }

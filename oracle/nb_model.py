@@ -44,6 +44,11 @@ def lib():
                                          ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32]
         L.prnb_set_hw_tables.restype = None
         L.prnb_hw_mode.restype = ctypes.c_int
+        L.prnb_set_hw_query.argtypes = [ctypes.c_void_p]
+        L.prnb_set_hw_query.restype = None
+        L.prnb_set_hw_query_standins.restype = None
+        L.prnb_query_stats.argtypes = [ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+        L.prnb_query_stats.restype = None
         L.prnb_hw_math.argtypes = [ctypes.c_int, _f32p, _f32p, ctypes.c_int64]
         L.prnb_hw_math.restype = None
         _i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
@@ -100,6 +105,47 @@ HW_RANGES = dict(rcp=(ONE, TWO - ONE),                       # mantissas: v_rcp_
                  log2=(ONE, THIRTY_TWO - ONE),               # v_log_f32 over [1, 32)
                  exp2neg=(TWO_M24, THIRTY_TWO - TWO_M24))    # v_exp_f32(-x) over [2^-24, 32)
 _HW_TABLES = None      # the installed numpy arrays (kept alive here)
+_HW_QUERY = None       # the installed ctypes callback (kept alive here)
+# op codes of the query (= nb_model.c's HWOP_ enum = prosstt_amd_hw_math_at's op)
+HW_OPS = dict(rcp=0, log2=1, exp2neg=2, sqrt=3, rsq=4, cos=5)
+_QUERY_FN = ctypes.CFUNCTYPE(None, ctypes.c_int64, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_float),
+                             ctypes.POINTER(ctypes.c_float))
+
+
+def install_hw_query(at):
+    """Install the function that answers the gamma-Poisson class's questions (PRNB-7: nb_model.c, hwq_ask).
+    `at(op, x)` returns the float32 array y[i] = HW_op(x[i]) computed ON THE DEVICE by the product's probe
+    (prosstt_amd.device.Context.hw_math_at; op an integer of HW_OPS)."""
+    global _HW_QUERY
+
+    def answer(n, op_p, x_p, y_p):
+        op = np.ctypeslib.as_array(op_p, shape=(n,))
+        x = np.ctypeslib.as_array(x_p, shape=(n,))
+        y = np.ctypeslib.as_array(y_p, shape=(n,))
+        for o in np.unique(op):
+            pick = np.flatnonzero(op == o)
+            y[pick] = at(int(o), np.ascontiguousarray(x[pick]))
+
+    _HW_QUERY = _QUERY_FN(answer)
+    lib().prnb_set_hw_query(ctypes.cast(_HW_QUERY, ctypes.c_void_p))
+
+
+def use_standin_query(on=True):
+    """Test-only: answer the questions with the model's own libm stand-ins THROUGH the query machinery (the result must
+    equal the direct evaluation bit for bit); False removes the query function."""
+    global _HW_QUERY
+    if on:
+        lib().prnb_set_hw_query_standins()
+    else:
+        lib().prnb_set_hw_query(None)
+    _HW_QUERY = None
+
+
+def query_stats():
+    """(rounds, values) of the last resolution of waiting samples."""
+    r, v = ctypes.c_int64(0), ctypes.c_int64(0)
+    lib().prnb_query_stats(ctypes.byref(r), ctypes.byref(v))
+    return r.value, v.value
 
 
 def install_hw_tables(probe):
@@ -126,13 +172,16 @@ def install_hw_tables_from_device():
         return
     from prosstt_amd import device
     ctx = device.get_context()
+    install_hw_query(ctx.hw_math_at)
     install_hw_tables(ctx.hw_math)
 
 
 def remove_hw_tables():
-    global _HW_TABLES
+    global _HW_TABLES, _HW_QUERY
     lib().prnb_set_hw_tables(None, None, 0, 0, None, 0, 0)
+    lib().prnb_set_hw_query(None)
     _HW_TABLES = None
+    _HW_QUERY = None
 
 
 def hw_mode():

@@ -20,7 +20,7 @@ SYMBOLS = [
     "prosstt_amd_version", "prosstt_amd_last_error", "prosstt_amd_device_count",
     "prosstt_amd_ctx_create", "prosstt_amd_ctx_destroy", "prosstt_amd_ctx_synchronize",
     "prosstt_amd_last_kernel_ms", "prosstt_amd_sample_counts", "prosstt_amd_plan_order", "prosstt_amd_last_list", "prosstt_amd_nb_params",
-    "prosstt_amd_hw_math", "prosstt_amd_domain_status", "prosstt_amd_numpy_programs",
+    "prosstt_amd_hw_math", "prosstt_amd_hw_math_at", "prosstt_amd_domain_status", "prosstt_amd_numpy_programs",
     "prosstt_amd_lineage_attempt", "prosstt_amd_lineage_attempt_batch", "prosstt_amd_lineage_walk",
     "prosstt_amd_lineage_walk_batch",
     "prosstt_amd_lineage_commit",
@@ -71,6 +71,7 @@ def load():
         L.prosstt_amd_last_list.argtypes = [vp, vp, vp, i64, ctypes.POINTER(i64), ctypes.POINTER(i32)]
         L.prosstt_amd_nb_params.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp, u32]
         L.prosstt_amd_hw_math.argtypes = [vp, i32, u32, u64, vp, u32]
+        L.prosstt_amd_hw_math_at.argtypes = [vp, i32, vp, u64, vp, u32]
         L.prosstt_amd_domain_status.argtypes = [vp, ctypes.POINTER(i32)]
         L.prosstt_amd_numpy_programs.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
         L.prosstt_amd_lineage_attempt.argtypes = [vp, vp, i32, i32, vp, i64, i32, vp, vp, vp, vp]

@@ -1,15 +1,21 @@
 // K3h: the samples the streaming kernel (k3_stream.h) listed instead of drawing them: the
-// gamma-Poisson class of PRNB-6 (prnb_device.h; theta above 24 or -log2 P(X = 0) of 27.4 or more, one or
-// two in a thousand of a typical workload), the walks that were still running when their strip was done
-// and the walks that passed k = 254 (both redone here from k = 0).
+// gamma-Poisson class of PRNB-7 (prnb_device.h; theta above 24 or -log2 P(X = 0) of 27.4 or more, one to
+// three in a thousand of a typical workload), the walks that were still running when their strip was done
+// (continued here from the state the streaming kernel hands over) and the walks that passed k = 254 (redone here
+// from k = 0: seventy per 10^9 samples).
 // Both halves of the gamma-Poisson path are rejection samplers; run lane-per-sample
 // they would make every wave repeat each half until its unluckiest lane is accepted.  Here
 // every ATTEMPT is a stack entry: a gamma pass runs one Marsaglia-Tsang attempt for 64
 // entries of HG (accepted -> the Poisson stack HP, rejected -> back on HG with the next
 // attempt number), a Poisson pass one PTRS attempt for 64 entries of HP.  Attempts are pure
 // functions of (parameters, seed, cell, gene, attempt), so the order of evaluation cannot
-// change a result, and every pass runs with all lanes doing the same thing.  The redo walks
+// change a result, and every pass runs with all lanes doing the same thing.  The walks
 // keep their state in registers across passes, and idle lanes take the next entries (below).
+//
+// PRNB-7 (round 6): the class's transcendentals are the hardware's -- v_log_f32, v_exp_f32, v_sqrt_f32, v_rsq_f32,
+// v_cos_f32, v_rcp_f32, one instruction each (PRNB-6: polynomial log 25, sqrt 17, cos 29, Newton reciprocal 7
+// instructions; ~665 vector lane-instructions per listed sample) -- and a list entry carries its sample's scaled mean,
+// so that nothing is gathered here but the two per-gene parameters.
 #pragma once
 #include "prnb_device.h"
 #include "k3_stream.h"
@@ -18,19 +24,19 @@ namespace k3 {
 
 constexpr int kHeavyBlock = 256;
 constexpr int kHCap = 128;     // < 64 left over + 64 pushed (new entries, or re-pushed ones after 64 were popped)
+constexpr int kWCap = 96;      // walks waiting for a lane: < 32 left over + 64 pushed by one step of the list traversal (five blocks per CU: 30 496 B)
 
-// Stack entries carry the scaled mean m = M[row, g] * s of their sample (looked up once, when the list
-// entry is read), so that a pass depends on one level of loads (the per-gene parameters), not on a chain
-// row -> mean.
 struct HGEntry { int32_t n, g, attempt; float m; };
 struct HPEntry { int32_t n, g; float lam; int32_t attempt; };
-
-struct HLEntry { int32_t n, g; float m; };         // an inversion walk to redo
+// a walk waiting for a lane: its state {the next term, d = mp - q, q, the remainder}, where it goes, the next term's k
+struct HWId { int32_t n, g; };
 
 struct HeavyLds {
     HGEntry hg[kHCap];
     HPEntry hp[kHCap];
-    HLEntry hl[kHCap];
+    f32x4_t wst[kWCap];
+    HWId wid[kWCap];
+    uint16_t wk[kWCap];
 };
 
 // heavy: what the streaming kernel's waves listed (k3::HeavyList; `regions` of them, laid out by
@@ -51,7 +57,7 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
     for (int k = tid; k < prnb::kKTab; k += kHeavyBlock) inv_k[k] = k ? 1.0f / (float)k : 0.0f;
     __syncthreads();
 
-    int hg_top = 0, hp_top = 0, hl_top = 0;      // wave-uniform
+    int hg_top = 0, hp_top = 0, hw_top = 0;      // wave-uniform
 
     auto cell_id = [&](int32_t n) __attribute__((always_inline)) -> uint64_t {
         return cell_index ? (uint64_t)cell_index[n] : cell_offset + (uint64_t)n;
@@ -77,35 +83,35 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
                 small = true;                      // walked below, all such lanes side by side
             } else if (!(lam < prnb::kLamBig)) {
                 const prnb::Words w = prnb::philox_count<0>(c0, c1, (uint32_t)e.g, 0x80000000u, k0, k1);
-                const float z = prnb::det_sqrt(-2.0f * prnb::det_log(prnb::unif(w.w[0]))) * prnb::det_cos2pi(w.w[1]);
-                const float kf = __builtin_floorf(PRNB_FMA(prnb::det_sqrt(lam), z, lam) + 0.5f);
+                const float z = prnb::hw_normal(w.w[0], w.w[1]);
+                const float kf = __builtin_floorf(PRNB_FMA(prnb::hw_sqrt(lam), z, lam) + 0.5f);
                 x = (int32_t)__builtin_fminf(__builtin_fmaxf(kf, 0.0f), 2147483520.0f);
             } else {
                 const int j = e.attempt;
                 const prnb::Words w =
                     prnb::philox_count<0>(c0, c1, (uint32_t)e.g, 0x80000000u + (uint32_t)(j >> 1), k0, k1);
-                const float slam = prnb::det_sqrt(lam);
+                const float slam = prnb::hw_sqrt(lam);
                 const float bb = PRNB_FMA(2.53f, slam, 0.931f);
                 const float aa = PRNB_FMA(0.02483f, bb, -0.059f);
                 const float U = prnb::unif((j & 1) ? w.w[2] : w.w[0]) - 0.5f;
                 const float V = prnb::unif((j & 1) ? w.w[3] : w.w[1]);
                 const float us = __builtin_fmaxf(0.5f - __builtin_fabsf(U), 5.8207661e-11f);
-                const float rus = prnb::det_rcp(us);
+                const float rus = prnb::hw_rcp(us);
                 float kf = __builtin_floorf(PRNB_FMA(PRNB_FMA(2.0f * aa, rus, bb), U, lam + 0.43f));
-                const float vr = PRNB_FMA(-3.6224f, prnb::det_rcp(bb - 2.0f), 0.9277f);
+                const float vr = PRNB_FMA(-3.6224f, prnb::hw_rcp(bb - 2.0f), 0.9277f);
                 bool accept = (us >= 0.07f) && (V <= vr);
                 if (!accept && !(kf < 0.0f || (us < 0.013f && V > us))) {
-                    const float invalpha = PRNB_FMA(1.1328f, prnb::det_rcp(bb - 3.4f), 1.1239f);
-                    const float lhs = prnb::det_log((V * invalpha) * prnb::det_rcp(PRNB_FMA(aa * rus, rus, bb)));
+                    const float invalpha = PRNB_FMA(1.1328f, prnb::hw_rcp(bb - 3.4f), 1.1239f);
+                    const float lhs = prnb::kLn2 * prnb::hw_log2((V * invalpha) * prnb::hw_rcp(PRNB_FMA(aa * rus, rus, bb)));
                     float rhs;
                     if (kf < 10.0f) {
-                        rhs = PRNB_FMA(kf, prnb::det_log(lam), -lam) - prnb::logfact_small((int)kf);
+                        rhs = PRNB_FMA(kf, prnb::kLn2 * prnb::hw_log2(lam), -lam) - prnb::logfact_small((int)kf);
                     } else {
-                        const float rk = prnb::det_rcp(kf);
+                        const float rk = prnb::hw_rcp(kf);
                         const float d = (lam - kf) * rk;
-                        const float lp = prnb::det_log1pmx(d, lam * rk);
+                        const float lp = prnb::hw_log1pmx(d, lam * rk);
                         const float st = rk * PRNB_FMA(-0.0027777778f, rk * rk, 0.083333336f);
-                        rhs = PRNB_FMA(kf, lp, PRNB_FMA(-0.5f, prnb::det_log(6.2831855f * kf), -st));
+                        rhs = PRNB_FMA(kf, lp, PRNB_FMA(-0.5f, prnb::kLn2 * prnb::hw_log2(6.2831855f * kf), -st));
                     }
                     accept = lhs <= rhs;
                 }
@@ -121,7 +127,7 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
             const uint64_t cell = cell_id(e.n);
             const prnb::Words w = prnb::philox_count<0>((uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)e.g, 0x80000000u, k0, k1);
             const float lam = small ? e.lam : 1.0f;
-            const int32_t xs = prnb::chop_down_wave(small, w.w[0], prnb::det_exp(-lam), lam, 0.0f, inv_k);
+            const int32_t xs = prnb::chop_down_wave(small, w.w[0], prnb::hw_exp2(-(lam * prnb::kLog2e)), lam, 0.0f, inv_k);
             if (small) x = xs;
         }
         if (lane < cnt && !again && x != 0) out[(int64_t)e.n * ld + e.g] = x;
@@ -151,12 +157,12 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
                 const bool boost = r < 1.0f;
                 const float rr = boost ? r + 1.0f : r;
                 const float dd = rr - 0.33333334f;
-                const float cc = prnb::det_rcp(3.0f * prnb::det_sqrt(dd));
+                const float cc = prnb::hw_rsq(9.0f * dd);
                 const int i = e.attempt;
                 const bool last = (i == prnb::kMaxTries - 1);
                 const prnb::Words w = prnb::philox_count<0>((uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)e.g,
                                                           1u + (uint32_t)i, k0, k1);
-                const float x = prnb::det_sqrt(-2.0f * prnb::det_log(prnb::unif(w.w[0]))) * prnb::det_cos2pi(w.w[1]);
+                const float x = prnb::hw_normal(w.w[0], w.w[1]);
                 const float t = cc * x;
                 const float v1 = 1.0f + t;
                 float v = 1.0f;
@@ -172,14 +178,14 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
                         ok = u < PRNB_FMA(-0.0331f, x2 * x2, 1.0f);
                         if (!ok) {
                             const float t2 = t * t;
-                            const float h = PRNB_FMA(3.0f, prnb::det_log1pmx(t, v1), PRNB_FMA(-t2, t, -3.0f * t2));
-                            ok = prnb::det_log(u) < PRNB_FMA(dd, h, 0.5f * x2);
+                            const float h = PRNB_FMA(3.0f, prnb::hw_log1pmx(t, v1), PRNB_FMA(-t2, t, -3.0f * t2));
+                            ok = prnb::kLn2 * prnb::hw_log2(u) < PRNB_FMA(dd, h, 0.5f * x2);
                         }
                     }
                 }
                 if (ok) {
                     float g = dd * v;
-                    if (boost) g = g * prnb::det_exp(prnb::det_log(prnb::unif(w.w[3])) * prnb::det_rcp(r));
+                    if (boost) g = g * prnb::hw_exp2(prnb::hw_log2(prnb::unif(w.w[3])) * prnb::hw_rcp(r));
                     lam = P.theta * g;
                     accepted = true;
                 } else {
@@ -204,51 +210,29 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
         while (hp_top >= 64) poisson_pass();
     };
 
-    // ---- inversion walks the streaming kernel left (unfinished at the end of their strip, or past k = 254), from
-    // k = 0 again, every lane walking its own pmf eight terms per pass.  Walks
-    // differ in length by two orders of magnitude (the unfinished ones are the longest of their strip), so a
-    // lane's walk lives in registers across passes and an idle lane takes the next entry of the redo stack:
-    // a pass runs with more than half of the lanes walking, and new walks start at least 32 at a time.
+    // ---- inversion walks: the ones the streaming kernel had not finished when their strip ended arrive with their
+    // state and go on from it; a walk past k = 254 and the samples of an overflowed region start at k = 0 (walk_from_start).
+    // Every lane walks its own pmf eight terms per pass; walks differ in length by two orders of magnitude, so a lane's
+    // walk lives in registers across passes and an idle lane takes the next entry of the stack: a pass runs with more
+    // than half of the lanes walking, and new walks start at least 32 at a time.
     int32_t wk = -1;                                  // next term of this lane's walk; -1: idle
     float wps = 0.0f, wrem = 0.0f, wd = 0.0f, wq = 0.0f;         // the next term, the remainder, mp - q, q
     int32_t wn = 0, wg = 0;
-    auto light_start = [&]() __attribute__((always_inline)) {
-        // idle lanes take entries: parameters, P(X = 0) and the terms k = 0, 1, 2 (the chop-down's first
-        // group); a walk that does not end there goes on in light_walk
+    auto walk_take = [&]() __attribute__((always_inline)) {
         const unsigned long long idle_m = __builtin_amdgcn_ballot_w64(wk < 0);
         const int rank = lane_rank(idle_m);
-        const bool take = wk < 0 && rank < hl_top;
-        HLEntry e;
-        e.n = 0; e.g = 0; e.m = 1.0f;
-        if (take) e = L.hl[hl_top - 1 - rank];
-        const int idle = __popcll(idle_m);
-        hl_top -= idle < hl_top ? idle : hl_top;
-        const prnb::Params P = prnb::make_params_m(e.m, ga[e.g], gbm1[e.g]);
-        const uint64_t cell = cell_id(e.n);
-        const prnb::Words w = prnb::philox_count<0>((uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)e.g >> 2, 0u, k0, k1);
-        const uint32_t sel = (uint32_t)e.g & 3u;
-        const uint32_t wj = sel == 0u ? w.w[0] : (sel == 1u ? w.w[1] : (sel == 2u ? w.w[2] : w.w[3]));
-        const float mp = P.m * P.iu, q = P.theta * P.iu, d = mp - q;
-        const float ps = prnb::hw_exp2(-P.t2) * 4294967296.0f;
-        const float r0 = (float)wj - ps;
-        const float p1 = ps * mp;
-        const float r1 = r0 - p1;
-        const float p2 = p1 * PRNB_FMA(d, inv_k[2], q);
-        const float r2 = r1 - p2;
-        const bool done = (r0 < 0.0f) || (r1 < 0.0f) || (r2 < 0.0f) || (p2 < 1.0f);
-        const int32_t x = (r0 < 0.0f) ? 0 : ((r1 < 0.0f) ? 1 : 2);
-        if (take) {
-            if (done) {
-                if (x != 0) out[(int64_t)e.n * ld + e.g] = x;
-            } else {
-                wk = 3;
-                wps = p2 * PRNB_FMA(d, inv_k[3], q);
-                wrem = r2;
-                wd = d; wq = q; wn = e.n; wg = e.g;
-            }
+        if (wk < 0 && rank < hw_top) {
+            const int at = hw_top - 1 - rank;
+            const f32x4_t s = L.wst[at];
+            const HWId id = L.wid[at];
+            wk = (int32_t)L.wk[at];
+            wps = s.x; wd = s.y; wq = s.z; wrem = s.w;
+            wn = id.n; wg = id.g;
         }
+        const int idle = __popcll(idle_m);
+        hw_top -= idle < hw_top ? idle : hw_top;
     };
-    auto light_walk = [&]() __attribute__((always_inline)) {
+    auto walk_pass = [&]() __attribute__((always_inline)) {
         // two groups of four terms for every walking lane (an idle lane computes on zeros).  Most passes of a
         // strip's longest walks end nowhere: one wave-level test then skips everything but the arithmetic.
         const bool busy = wk >= 0;
@@ -288,49 +272,81 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
             wrem = b4;
         }
     };
-    auto light_service = [&](bool drain) __attribute__((always_inline)) {
+    auto walk_service = [&](bool drain) __attribute__((always_inline)) {
         for (;;) {
             const int busy = __popcll(__builtin_amdgcn_ballot_w64(wk >= 0));
-            if (busy <= 32 && (drain ? hl_top > 0 : hl_top >= 32)) light_start();
-            else if (drain ? busy > 0 : busy > 32) light_walk();
+            if (busy <= 32 && (drain ? hw_top > 0 : hw_top >= 32)) walk_take();
+            else if (drain ? busy > 0 : busy > 32) walk_pass();
             else break;
         }
     };
+    // push walk states of the lanes in `push` (wave-level call)
+    auto walk_push = [&](bool push, int32_t n, int32_t g, int32_t k, f32x4_t s) __attribute__((always_inline)) {
+        const unsigned long long mw = __builtin_amdgcn_ballot_w64(push);
+        if (push) {
+            const int at = hw_top + lane_rank(mw);
+            L.wst[at] = s;
+            HWId id;
+            id.n = n; id.g = g;
+            L.wid[at] = id;
+            L.wk[at] = (uint16_t)k;
+        }
+        hw_top += __popcll(mw);
+        if (hw_top >= 32) walk_service(false);
+    };
 
-    // ---- 64 list entries per wave and step, sorted onto the gamma stack and the redo stack ---------
-    auto feed = [&](bool has, int32_t n, int32_t g) __attribute__((always_inline)) {
-        bool heavy = false, light = false;
-        float m = 0.0f;
+    // ---- a sample from its start (rare: a walk past k = 254, or any sample of an overflowed region): the mean is
+    // gathered, the class decided; the gamma-Poisson class goes on HG, an inversion walk is taken through its first
+    // group (k = 0, 1, 2) and, when that does not decide it, pushed as a walk state at k = 3
+    auto from_start = [&](bool has, int32_t n, int32_t g) __attribute__((always_inline)) {
+        bool heavy_c = false, light = false;
+        prnb::Params P;
+        P.m = 1.0f; P.theta = 1.0f; P.iu = 0.5f; P.t2 = 1.0f; P.inv_th = 1.0f; P.valid = false; P.light = false;
         if (has) {
             int32_t row = row_of_cell[n];
             row = row < 0 ? 0 : (row >= rows ? (int32_t)(rows - 1) : row);     // as the preparation kernel: never a wild read
-            const prnb::Params P = prnb::make_params(means[(int64_t)row * G + g], scal[n], ga[g], gbm1[g]);
-            m = P.m;
+            P = prnb::make_params(means[(int64_t)row * G + g], scal[n], ga[g], gbm1[g]);
             light = P.valid && P.light;
-            heavy = P.valid && !P.light;
+            heavy_c = P.valid && !P.light;
         }
-        const unsigned long long mh = __builtin_amdgcn_ballot_w64(heavy);
-        if (heavy) {
+        const unsigned long long mh = __builtin_amdgcn_ballot_w64(heavy_c);
+        if (heavy_c) {
             HGEntry e;
-            e.n = n; e.g = g; e.attempt = 0; e.m = m;
+            e.n = n; e.g = g; e.attempt = 0; e.m = P.m;
             L.hg[hg_top + lane_rank(mh)] = e;
         }
         hg_top += __popcll(mh);
-        const unsigned long long ml = __builtin_amdgcn_ballot_w64(light);
-        if (light) {
-            HLEntry e;
-            e.n = n; e.g = g; e.m = m;
-            L.hl[hl_top + lane_rank(ml)] = e;
+        bool push = false;
+        f32x4_t s = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (__builtin_amdgcn_ballot_w64(light) != 0ull) {
+            const uint64_t cell = cell_id(has ? n : 0);
+            const prnb::Words w = prnb::philox_count<0>((uint32_t)cell, (uint32_t)(cell >> 32), (uint32_t)g >> 2, 0u, k0, k1);
+            const uint32_t sel = (uint32_t)g & 3u;
+            const uint32_t wj = sel == 0u ? w.w[0] : (sel == 1u ? w.w[1] : (sel == 2u ? w.w[2] : w.w[3]));
+            const float mp = P.m * P.iu, q = P.theta * P.iu, d = mp - q;
+            const float ps = prnb::hw_exp2(-P.t2) * 4294967296.0f;
+            const float r0 = (float)wj - ps;
+            const float p1 = ps * mp;
+            const float r1 = r0 - p1;
+            const float p2 = p1 * PRNB_FMA(d, inv_k[2], q);
+            const float r2 = r1 - p2;
+            const bool done = (r0 < 0.0f) || (r1 < 0.0f) || (r2 < 0.0f) || (p2 < 1.0f);
+            const int32_t x = (r0 < 0.0f) ? 0 : ((r1 < 0.0f) ? 1 : 2);
+            if (light && done && x != 0) out[(int64_t)n * ld + g] = x;
+            push = light && !done;
+            s.x = p2 * PRNB_FMA(d, inv_k[3], q);
+            s.y = d; s.z = q; s.w = r2;
         }
-        hl_top += __popcll(ml);
+        walk_push(push, n, g, 3, s);
         while (hg_top >= 64) gamma_pass();
-        if (hl_top >= 64) light_service(false);
     };
+
+    // ---- the list, four regions per wave and step ---------------------------------------------------
     const int64_t wave_id = (int64_t)blockIdx.x * (kHeavyBlock / 64) + wv;
     const int64_t waves = (int64_t)gridDim.x * (kHeavyBlock / 64);
     {
-        // four regions per step, 16 lanes each: a region holds ~30 entries on the headline workload, and
-        // every step is a chain of dependent loads (count -> entry -> row -> mean)
+        // four regions per step, 16 lanes each: a region holds ~30 entries on the headline workload; a step depends on
+        // ONE level of loads (the count and the first 16 entries are read side by side; an entry carries its mean)
         const int32_t groups = (strips + 3) / 4;
         const int sub = lane >> 4, sl = lane & 15;
         // a wave's regions lie `waves` apart: the listed samples cluster in a few gene tiles (regions are laid out
@@ -338,18 +354,42 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
         for (int64_t r0 = wave_id; r0 < (int64_t)regions; r0 += waves * 4) {
             const int64_t r = r0 + (int64_t)sub * waves;
             const bool in = r < (int64_t)regions;
-            // the first 16 entries are read beside the count, not behind it (a region's words exist whatever it holds)
-            const uint32_t cnt_all = in ? heavy.count[r] : 0u;
-            uint32_t p = in ? heavy.list[(uint64_t)r * heavy.cap + (uint32_t)sl] : 0u;
+            // the first 16 entries and the walk states are read beside the count, not behind it (a region's words exist
+            // whatever they hold)
+            const uint32_t cnt_word = in ? heavy.count[r] : 0u;
+            uint2 p = in ? heavy.list[(uint64_t)r * heavy.cap + (uint32_t)sl] : make_uint2(0u, 0u);
+            f32x4_t bst = {0.0f, 0.0f, 0.0f, 0.0f};
+            uint32_t bid = 0u;
+            if (in) {
+                bst = heavy.bail_st[(uint64_t)r * kBailSlots + (uint32_t)sl];
+                bid = heavy.bail_id[(uint64_t)r * kBailSlots + (uint32_t)sl];
+            }
+            const uint32_t cnt_all = cnt_word & 0xffffu, n_bail = cnt_word >> 16;
             const int32_t blk = (int32_t)(r >> 2);
             const int32_t tile_g = blk / groups;
             const int64_t n0 = (int64_t)((blk - tile_g * groups) * 4 + (int32_t)(r & 3)) * strip_cells;
             const bool over = cnt_all > heavy.cap;       // the region was too small: redone as a whole below
             const uint32_t cnt = over ? 0u : cnt_all;
+            // the unfinished walks of the region's strip: continued from their state
+            walk_push((uint32_t)sl < n_bail, (int32_t)(n0 + ((bid & 0xffffu) >> 8)), tile_g * kTileG + (int32_t)(bid & 255u),
+                      (int32_t)(bid >> 16) - 3, bst);
             for (uint32_t i0 = 0u; __builtin_amdgcn_ballot_w64(i0 < cnt) != 0ull; i0 += 16u) {
                 const bool has = i0 + (uint32_t)sl < cnt;
-                if (i0 != 0u) p = has ? heavy.list[(uint64_t)r * heavy.cap + i0 + (uint32_t)sl] : 0u;
-                feed(has, (int32_t)(n0 + (p >> 8)), tile_g * kTileG + (int32_t)(p & 255u));
+                if (i0 != 0u) p = has ? heavy.list[(uint64_t)r * heavy.cap + i0 + (uint32_t)sl] : make_uint2(0u, 0u);
+                const int32_t n = (int32_t)(n0 + (p.x >> 8)), g = tile_g * kTileG + (int32_t)(p.x & 255u);
+                const float m = __uint_as_float(p.y);
+                // an entry with its mean is of the gamma-Poisson class (the streaming kernel decided that)
+                const bool heavy_c = has && m >= 0.0f;
+                const unsigned long long mh = __builtin_amdgcn_ballot_w64(heavy_c);
+                if (heavy_c) {
+                    HGEntry e;
+                    e.n = n; e.g = g; e.attempt = 0; e.m = m;
+                    L.hg[hg_top + lane_rank(mh)] = e;
+                }
+                hg_top += __popcll(mh);
+                while (hg_top >= 64) gamma_pass();
+                const bool redo = has && !(m >= 0.0f);
+                if (__builtin_amdgcn_ballot_w64(redo) != 0ull) from_start(redo, n, g);
             }
             // every sample of an overflowed region (strip_cells x 256 of the matrix) goes through the classification
             // here, 64 at a time: slow (the streaming kernel's own results are recomputed), but any parameter set
@@ -364,12 +404,12 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
                 for (int32_t c = 0; c < strip_cells && nb + c < N; ++c)
                     for (int j = 0; j < 4; ++j) {
                         const int32_t g = tg * kTileG + j * 64 + lane;
-                        feed(g < G, (int32_t)(nb + c), g);
+                        from_start(g < G, (int32_t)(nb + c), g);
                     }
             }
         }
     }
-    light_service(true);
+    walk_service(true);
     while (hg_top > 0) gamma_pass();
     while (hp_top > 0) poisson_pass();
 
@@ -378,15 +418,17 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
     // The preparation kernel has done the per-cell and per-gene parts and raised check_words[check_request] iff some gene
     // has alpha < 0 or beta < 1: only then can alpha*m + beta < 1 happen with every mean positive, and only then is the
     // whole matrix looked at here -- m = M*s <= 0 (or NaN) or alpha*m + beta - 1 < 0 anywhere sets the verdict word.  It
-    // rides in this kernel so that a checked call launches nothing more than an unchecked one.
+    // rides in this kernel so that a checked call launches nothing more than an unchecked one.  (A block takes whole
+    // cells and walks their genes: no division per sample.)
     if (check_words && check_words[check_request] != 0 && check_words[check_bad_row] == 0) {
-        const int64_t total = N * (int64_t)G;
         bool bad = false;
-        for (int64_t i = (int64_t)blockIdx.x * kHeavyBlock + tid; i < total; i += (int64_t)gridDim.x * kHeavyBlock) {
-            const int64_t n = i / G;
-            const int32_t g = (int32_t)(i - n * G);
-            const float m = means[(int64_t)row_of_cell[n] * G + g] * scal[n];
-            bad = bad || !(m > 0.0f) || (PRNB_FMA(ga[g], m, gbm1[g]) < 0.0f);
+        for (int64_t n = blockIdx.x; n < N; n += gridDim.x) {
+            const float s = scal[n];
+            const float* mrow = means + (int64_t)row_of_cell[n] * G;
+            for (int32_t g = tid; g < G; g += kHeavyBlock) {
+                const float m = mrow[g] * s;
+                bad = bad || !(m > 0.0f) || (PRNB_FMA(ga[g], m, gbm1[g]) < 0.0f);
+            }
         }
         if (bad) check_words[check_verdict] = 1;
     }

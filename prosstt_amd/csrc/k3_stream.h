@@ -58,7 +58,9 @@ constexpr int kS2Cap = 104;        // < 40 left over + 64 pushed by one stage-2 
 constexpr int kS2Run = 40;         // stage 3 runs while S2 holds at least this many entries (with eight terms per pass: 32 +0.9 %, 24 +4 %, 16 +7 %, 44 and 48 +0.7 %: profiles/r05_ablation.txt)
 static_assert(kS2Cap >= kS2Run - 1 + 64 && kS1Cap >= 63 + 128, "a stack must take one more round of pushes");
 constexpr int kRing = 8;           // rows of the strip kept in LDS (8 bits per count) before they are stored; a power of 2
-constexpr int kBail = 6;           // walks left to K3h when a strip has nothing else to do (see the drain)
+constexpr int kBail = 6;           // walks handed to K3h WITH THEIR STATE when a strip has nothing else to do (see the drain)
+constexpr int kBailSlots = 16;     // room for them per wave (kBail <= kBailSlots)
+static_assert(kBail <= kBailSlots, "a wave's unfinished walks must fit its slots");
 constexpr int kLateCap = 64;       // results that missed their row wait here for one burst of stores (a pass delivers at most 64)
 constexpr int kRingMaxK3 = 254;    // a walk whose group k3-3..k3 with k3 = 254 ends undecided goes to K3h: counts fit the ring's 8 bits
 constexpr int kInvTab = 272;       // 1/k for k < 272: the reciprocals a pass at k3 <= 254 reads ahead (k3 + 6 .. k3 + 13)
@@ -115,12 +117,18 @@ struct WaveLds {
 };
 
 // The list of samples left to K3h: wave w of block b owns region r = 4*b + w, entries
-// list[r * cap .. + min(count[r], cap)) = pos (cell-in-strip << 8 | gene-in-tile); a region that was too
-// small (count[r] > cap: more than one sample in 16 listed) is redone by K3h sample by sample, and
-// overflow[0] != 0 says that there was one.
+// list[r * cap .. + min(count[r] & 0xffff, cap)) = {pos (cell-in-strip << 8 | gene-in-tile), the sample's scaled mean m}
+// -- m < 0: "redo this sample from its start" (a walk past k = 254: the stream kernel no longer has its mean); a region
+// that was too small (more than one sample in 16 listed) is redone by K3h sample by sample, and overflow[0] != 0 says
+// that there was one.  The walks a wave had not finished when its strip ended travel WITH THEIR STATE: count[r] >> 16
+// of them in bail_st[r * kBailSlots ..] = {the next term, d, q, the remainder} and bail_id[..] = pos | k3 << 16 (the next
+// term is k = k3 - 3), which K3h continues instead of redoing them from k = 0 (until round 5: 2.8e5 walks of mean
+// length 64-75 per C3 launch).
 static_assert(offsetof(WaveLds, s1) == offsetof(WaveLds, s1_null) + sizeof(S1Entry), "s1[-1] must be the null entry");
 
-struct HeavyList { uint32_t* count; uint32_t* list; uint32_t* overflow; uint32_t cap; };
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+struct HeavyList { uint32_t* count; uint2* list; uint32_t* overflow; uint32_t cap; f32x4_t* bail_st; uint32_t* bail_id; };
+constexpr float kRedoMark = -1.0f;   // list entry: no mean, redo from the start
 
 __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
@@ -190,6 +198,7 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
     int s2_top = 0;                                  // wave-uniform
     constexpr uint32_t kNoHeavy = 0xffffffffu;
     uint32_t hpend = kNoHeavy;                       // pos of the sample this lane holds for the next append to K3h's list
+    float hpend_m = 0.0f;                            // ... and its scaled mean (kRedoMark: a walk past k = 254)
     // stage-3 lane state: st = {the next term (k = k3 - 3), d = mp - q, q, what is left of wf}; pos; k3 = the first of the
     // pass's two groups ends at k3 (6, 14, 22, ...).  WHICH lanes walk is wave-level state on the scalar unit (idle_s: bit = the lane
     // holds no walk): a pass takes every mask it forms AND NOT idle_s, so an idle lane may compute on whatever its
@@ -267,22 +276,22 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
     const uint32_t late_lds = (uint32_t)(uintptr_t)&L.late[0];
     // write the samples the lanes hold for K3h to this wave's region of the list (about ten entries
     // each time on the headline workload: the first lane to meet its second sample triggers it)
-    uint32_t* const my_list = heavy.list + (uint64_t)region * heavy.cap;
+    uint2* const my_list = heavy.list + (uint64_t)region * heavy.cap;
     uint32_t h_cnt = 0u;                              // wave-uniform
     auto flush_heavy = [&]() {
         const unsigned long long mp_ = K3_MASK(hpend != kNoHeavy);
         if (hpend != kNoHeavy) {
             const uint32_t slot = h_cnt + (uint32_t)lane_rank(mp_);
-            if (slot < heavy.cap) my_list[slot] = hpend & 0xffffu;
+            if (slot < heavy.cap) my_list[slot] = make_uint2(hpend & 0xffffu, __float_as_uint(hpend_m));
         }
         h_cnt += (uint32_t)__popcll(mp_);
         hpend = kNoHeavy;
     };
     // Every lane of the wave calls this at the end of a stage-2 or stage-3 pass.  The lanes of `ok_m`
     // deliver count `res` (1..255) of sample `p`: into the row ring while the row is still there, else
-    // (rare) onto the late list; the lanes of `give_m` (rare as well) leave sample `p` to K3h.  One test
-    // covers both rare paths.
-    auto deliver = [&](unsigned long long ok_m, unsigned long long give_m, uint32_t p, uint32_t res) {
+    // (rare) onto the late list; the lanes of `give_m` (rare as well) leave sample `p` of scaled mean `gm` to K3h.  One
+    // test covers both rare paths.
+    auto deliver = [&](unsigned long long ok_m, unsigned long long give_m, uint32_t p, uint32_t res, float gm) {
         const unsigned long long late_m = K3_MASK((int32_t)p <= flushed_pos);
         // slot = cell % kRing, gene-in-tile
         uint32_t ring_at;
@@ -299,7 +308,8 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
             }
             if (give_m != 0ull) {
                 if ((give_m & K3_MASK(hpend != kNoHeavy)) != 0ull) flush_heavy();
-                asm volatile("s_mov_b64 exec, %1\n\tv_mov_b32 %0, %2\n\ts_mov_b64 exec, -1" : "+v"(hpend) : "s"(give_m), "v"(p));
+                asm volatile("s_mov_b64 exec, %2\n\tv_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\ts_mov_b64 exec, -1"
+                             : "+v"(hpend), "+v"(hpend_m) : "s"(give_m), "v"(p), "v"(gm));
             }
         }
     };
@@ -366,7 +376,7 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
         const unsigned long long end_b = (hit_b | tail_b) & ~(idle_s | end_a | big_m);
         int32_t res_k;
         asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(res_k) : "v"(res_b), "v"(res_a), "s"(end_a));
-        deliver(end_a | end_b, give_m, pos, (uint32_t)res_k);
+        deliver(end_a | end_b, give_m, pos, (uint32_t)res_k, kRedoMark);
         idle_s |= end_a | end_b | big_m;                  // done lanes go idle
         st.x = ps7 * PRNB_FMA(d, inv2.w, q);
         // an idle lane rests at k3 = 6 with the reciprocals of a walk's first two groups (the reads below fetch them again
@@ -422,7 +432,7 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
         const uint32_t res = (uint32_t)((2 + ((int32_t)prnb::f2u(r0) >> 31)) + ((int32_t)prnb::f2u(r1) >> 31));
         const unsigned long long walk_m = valid_m & light_m;                  // decided by this kernel
         const unsigned long long end_m = hit_m | tail_m;
-        deliver(walk_m & end_m, valid_m & ~light_m, p2, res);        // (a count of 0 is written as well: the ring slot holds 0 anyway)
+        deliver(walk_m & end_m, valid_m & ~light_m, p2, res, m);     // (a count of 0 is written as well: the ring slot holds 0 anyway)
         const uint32_t taken = kFull ? 1024u : (top - s1_lds < 1024u ? top - s1_lds : 1024u);
         s1_at = top - taken;
         const unsigned long long push_m = walk_m & ~end_m;
@@ -576,14 +586,19 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
     }
     // The last walks of a strip would run with a handful of busy lanes (13 % of the lanes over a quarter of a
     // pass per cell on the headline workload): once nothing waits on S2 and at most kBail lanes still walk,
-    // their samples go on K3h's list instead, which redoes them from the start.
+    // their walks go to K3h with their state -- the next term, d, q, the remainder, k3 --, which continues them.
+    uint32_t n_bail = 0u;                            // wave-uniform
     for (;;) {
         const unsigned long long busy_m = ~idle_s;
         if (s2_top == 0) {
             if (busy_m == 0ull) break;
             if (__popcll(busy_m) <= kBail) {
-                if ((busy_m & __builtin_amdgcn_ballot_w64(hpend != kNoHeavy)) != 0ull) flush_heavy();
-                if ((busy_m >> lane) & 1ull) hpend = pos;
+                if ((busy_m >> lane) & 1ull) {
+                    const uint64_t slot = (uint64_t)region * kBailSlots + (uint32_t)lane_rank(busy_m);
+                    heavy.bail_st[slot] = st;
+                    heavy.bail_id[slot] = (pos & 0xffffu) | ((uint32_t)k3 << 16);
+                }
+                n_bail = (uint32_t)__popcll(busy_m);
                 break;
             }
         }
@@ -593,7 +608,7 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
     flush_late();
     if (__builtin_amdgcn_ballot_w64(hpend != kNoHeavy) != 0ull) flush_heavy();
     if (lane == 0) {
-        heavy.count[region] = h_cnt;                 // above cap: K3h redoes the whole region
+        heavy.count[region] = h_cnt | (n_bail << 16);    // h_cnt above cap: K3h redoes the whole region (h_cnt <= 128 * 256 < 2^16)
         if (h_cnt > heavy.cap) heavy.overflow[0] = 1u;   // (for prosstt_amd_last_list)
     }
 }

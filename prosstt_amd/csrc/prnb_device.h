@@ -1,17 +1,20 @@
-// PRNB-6 count sampler, device side (gfx950).  DESIGN.md section 4 defines it; this header holds
+// PRNB-7 count sampler, device side (gfx950).  DESIGN.md section 4 defines it; this header holds
 // its building blocks -- the counter generator, the functions of the definition, the
 // parameters of a sample, the inversion walk -- that the kernels (k3_stream.h, k3_heavy.h,
 // nb_params_kernel) are made of.  Replaces, per (cell, gene):
 //   count_model.get_pr_umi                 /root/reference/prosstt/count_model.py:131-161
 //   scipy.stats.nbinom(n=r,p=1-p).rvs()    /root/reference/prosstt/simulation.py:647-648
 //
-// Arithmetic of the definition: IEEE binary32 add / mul / fma / sqrt and integer ops (the translation
-// unit is compiled with -ffp-contract=off and every fused multiply-add below is spelled out), plus --
-// for the inversion class only -- three functions of the gfx950 hardware, HW_RCP = v_rcp_f32,
-// HW_LOG2 = v_log_f32, HW_EXP2 = v_exp_f32 (hw_rcp / hw_log2 / hw_exp2 below: one instruction each,
-// deterministic on the chip).  The scalar model that checks the kernels (a test-side C file) takes the values of those three
-// from tables that a three-line probe kernel (hw_math_kernel, prosstt_amd.hip) writes on the device
-// under test; everything else of the model is its own C.  So counts still compare bit for bit.
+// Arithmetic of the definition: IEEE binary32 add / mul / fma and integer ops (the translation
+// unit is compiled with -ffp-contract=off and every fused multiply-add below is spelled out), plus
+// six functions of the gfx950 hardware, one instruction each, deterministic on the chip: HW_RCP = v_rcp_f32,
+// HW_LOG2 = v_log_f32, HW_EXP2 = v_exp_f32 (both classes), HW_SQRT = v_sqrt_f32, HW_RSQ = v_rsq_f32,
+// HW_COS = v_cos_f32 (argument in revolutions) -- the gamma-Poisson class only (PRNB-7; PRNB-6 drew that class in
+// polynomial arithmetic: 665 vector lane-instructions per sample, the kernel furthest below its roof).  The scalar
+// model that checks the kernels (a test-side C file) takes the values of rcp / log2 / exp2 of the inversion class
+// from tables that a probe kernel (hw_math_kernel, prosstt_amd.hip) writes on the device under test, and ASKS the
+// device for the gamma-Poisson class's values argument by argument (hw_math_at_kernel: y[i] = op(x[i])); everything
+// else of the model is its own C.  So counts still compare bit for bit.
 // (PRNB-4 defined P(X = 0) by polynomial log/exp and a Newton reciprocal and let the streaming kernel
 // use the hardware functions inside error margins, with a give-up list for samples near a threshold:
 // a fifth of the kernel's instructions; profiles/r04_ablation.txt.)
@@ -48,6 +51,10 @@ struct Words { uint32_t w[4]; };
 __device__ __forceinline__ float hw_rcp(float x) { return __builtin_amdgcn_rcpf(x); }     // v_rcp_f32
 __device__ __forceinline__ float hw_log2(float x) { return __builtin_amdgcn_logf(x); }    // v_log_f32
 __device__ __forceinline__ float hw_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
+// ... and the three more of the gamma-Poisson class (the model asks the device for their values: hw_math_at_kernel)
+__device__ __forceinline__ float hw_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }   // v_sqrt_f32
+__device__ __forceinline__ float hw_rsq(float x) { return __builtin_amdgcn_rsqf(x); }     // v_rsq_f32
+__device__ __forceinline__ float hw_cos(float x) { return __builtin_amdgcn_cosf(x); }     // v_cos_f32: cos(2 pi x)
 
 // Philox4x32-R (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11).  Rounds
 // from kXor3From on spell the two 3-input xors as one v_bitop3_b32 each (gfx950); callers whose counter is
@@ -190,6 +197,21 @@ __device__ __forceinline__ float det_cos2pi(uint32_t w)
 
 __device__ __forceinline__ float unif(uint32_t w) { return ((float)w + 0.5f) * 2.3283064365386963e-10f; }
 
+// ---- the gamma-Poisson class on the hardware's transcendentals (PRNB-7) ----
+constexpr float kLn2 = 0.69314718f, kLog2e = 1.44269504f, kMinus2Ln2 = -1.3862944f, kTwoM32 = 2.3283064365386963e-10f;
+// a standard normal by Box-Muller: sqrt(-2 ln u) cos(2 pi w / 2^32) in three hardware instructions
+__device__ __forceinline__ float hw_normal(uint32_t wa, uint32_t wb)
+{
+    return hw_sqrt(kMinus2Ln2 * hw_log2(unif(wa))) * hw_cos((float)wb * kTwoM32);
+}
+// log(1+d) - d: the polynomial where the difference cancels, the hardware's log2 of rho = 1 + d elsewhere
+__device__ __forceinline__ float hw_log1pmx(float d, float rho)
+{
+    if (d >= -0.29289323f && d < 0.41421354f)
+        return PRNB_FMA(-0.5f, d * d, log_tail(d));
+    return PRNB_FMA(kLn2, hw_log2(rho), -d);
+}
+
 __device__ __forceinline__ float det_sqrt(float x) { return __builtin_sqrtf(x); }  // IEEE (see Makefile)
 
 // Inversion by chop-down on a binary32 remainder; inv_k = LDS table of 1/k
@@ -269,7 +291,7 @@ struct Params {
     float m, theta;
     float iu;      // HW_RCP(1 + theta):  mp = m * iu,  q = theta * iu
     float t2;      // -log2 P(X = 0) = m * (HW_LOG2(1 + theta) * HW_RCP((1 + theta) - 1))
-    float inv_th;  // det_rcp(theta): r = m * inv_th (gamma-Poisson class)
+    float inv_th;  // HW_RCP(theta): r = m * inv_th (gamma-Poisson class)
     bool valid;    // m > 0 and a*m + b - 1 > 0
     bool light;    // inversion class: theta <= kLightTheta and t2 < kLightT2
 };
@@ -323,7 +345,7 @@ __device__ __forceinline__ Params make_params_m(float m, float a, float bm1)
     P.theta = theta;
     P.iu = h.iu;
     P.t2 = h.t2;
-    P.inv_th = det_rcp(theta);
+    P.inv_th = hw_rcp(theta);
     P.light = (theta <= kLightTheta) && (h.t2 < kLightT2);
     return P;
 }

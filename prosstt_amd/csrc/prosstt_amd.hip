@@ -73,8 +73,9 @@ struct prosstt_amd_ctx {
     std::vector<hipEvent_t> events;  // (start, stop) pairs of kernels launched with TIME_KERNEL
     size_t events_used = 0;
     // the K3h list of the last sample_counts call (inside `ws`; read by prosstt_amd_last_list)
-    uint32_t* list = nullptr;
+    uint2* list = nullptr;
     uint32_t* list_count = nullptr;
+    uint32_t* list_bail_id = nullptr;
     uint64_t list_regions = 0;
     uint32_t list_cap = 0;
     int64_t list_groups = 0, list_strip_cells = 0;
@@ -114,6 +115,7 @@ static int ws_reserve(prosstt_amd_ctx* c, size_t bytes)
     // every user of the workspace overwrites what the last sample_counts call left there: its list is gone
     c->list = nullptr;
     c->list_count = nullptr;
+    c->list_bail_id = nullptr;
     c->list_regions = 0;
     if (bytes <= c->ws_bytes) return 0;
     if (c->ws) {
@@ -234,6 +236,26 @@ __global__ void hw_math_kernel(int32_t op, uint32_t first_bits, uint64_t count, 
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
         const float x = __uint_as_float(first_bits + (uint32_t)i);
         y[i] = op == 0 ? prnb::hw_rcp(x) : (op == 1 ? prnb::hw_log2(x) : prnb::hw_exp2(-x));
+    }
+}
+
+// ... and the gather form: y[i] = op(x[i]) for the caller's arguments -- what the scalar model ASKS while it evaluates the
+// gamma-Poisson class (PRNB-7), whose transcendentals take arguments no table can enumerate.  Ops 0..2 as above, 3
+// v_sqrt_f32(x), 4 v_rsq_f32(x), 5 v_cos_f32(x) (x in revolutions).
+__global__ void hw_math_at_kernel(int32_t op, const float* __restrict__ x, uint64_t count, float* __restrict__ y)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        float r;
+        switch (op) {
+        case 0: r = prnb::hw_rcp(v); break;
+        case 1: r = prnb::hw_log2(v); break;
+        case 2: r = prnb::hw_exp2(-v); break;
+        case 3: r = prnb::hw_sqrt(v); break;
+        case 4: r = prnb::hw_rsq(v); break;
+        default: r = prnb::hw_cos(v); break;
+        }
+        y[i] = r;
     }
 }
 
@@ -658,8 +680,8 @@ struct StreamGeometry {
     int64_t tiles_g, strip_cells, strips, groups;
     uint64_t regions;       // one region of the K3h list per wave
     uint32_t region_cap;    // room for one in 16 of a wave's samples (beyond that K3h redoes the region itself)
-    size_t list_bytes, count_bytes, rows_bytes, info_bytes;
-    size_t total() const { return list_bytes + count_bytes + rows_bytes + info_bytes + 256; }
+    size_t list_bytes, count_bytes, bail_st_bytes, bail_id_bytes, info_bytes;
+    size_t total() const { return list_bytes + count_bytes + bail_st_bytes + bail_id_bytes + info_bytes + 256; }
 };
 
 static StreamGeometry stream_geometry(int64_t N, int32_t G, int64_t rows)
@@ -673,9 +695,10 @@ static StreamGeometry stream_geometry(int64_t N, int32_t G, int64_t rows)
     g.groups = (g.strips + 3) / 4;
     g.regions = (uint64_t)(g.groups * g.tiles_g) * 4u;
     g.region_cap = (uint32_t)g.strip_cells * (kTileG / 16);
-    g.list_bytes = ((g.regions * (size_t)g.region_cap * 4u) + 255) & ~(size_t)255;
+    g.list_bytes = ((g.regions * (size_t)g.region_cap * sizeof(uint2)) + 255) & ~(size_t)255;      // {pos, scaled mean}
     g.count_bytes = ((g.regions * 4u) + 255) & ~(size_t)255;
-    g.rows_bytes = 0;
+    g.bail_st_bytes = ((g.regions * (size_t)k3::kBailSlots * 16u) + 255) & ~(size_t)255;            // walk states handed over
+    g.bail_id_bytes = ((g.regions * (size_t)k3::kBailSlots * 4u) + 255) & ~(size_t)255;
     g.info_bytes = ((size_t)n + 4) * sizeof(k3::CellInfo);
     return g;
 }
@@ -729,7 +752,7 @@ static int sampler_setup(prosstt_amd_ctx* c, Staging& st, const float* means, in
     A->gphi = A->gbm1 + G;
     A->extra = (char*)c->ws + vec_bytes;
     k3::CellInfo* info = nullptr;
-    if (geo) info = (k3::CellInfo*)((char*)A->extra + geo->list_bytes + geo->count_bytes + geo->rows_bytes);
+    if (geo) info = (k3::CellInfo*)((char*)A->extra + geo->list_bytes + geo->count_bytes + geo->bail_st_bytes + geo->bail_id_bytes);
     // a checked call needs the per-row flags of THIS mean tensor: scanned now unless the caller vouches that the tensor
     // the ctx last scanned (same pointer, same shape) has not changed since
     const uint8_t* row_bad = nullptr;
@@ -834,11 +857,13 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
     if (rc) return rc;
     if (N == 0 || G == 0) return 0;
     k3::HeavyList heavy;
-    heavy.list = (uint32_t*)A.extra;
+    heavy.list = (uint2*)A.extra;
     heavy.count = (uint32_t*)((char*)A.extra + geo.list_bytes);
     heavy.overflow = (uint32_t*)(c->scratch + 3);           // zeroed by the preparation kernel
     heavy.cap = geo.region_cap;
-    k3::CellInfo* cellinfo = (k3::CellInfo*)((char*)A.extra + geo.list_bytes + geo.count_bytes + geo.rows_bytes);
+    heavy.bail_st = (k3::f32x4_t*)((char*)A.extra + geo.list_bytes + geo.count_bytes);
+    heavy.bail_id = (uint32_t*)((char*)A.extra + geo.list_bytes + geo.count_bytes + geo.bail_st_bytes);
+    k3::CellInfo* cellinfo = (k3::CellInfo*)((char*)A.extra + geo.list_bytes + geo.count_bytes + geo.bail_st_bytes + geo.bail_id_bytes);
     const int64_t* d_cell_index = A.cell_index;
     int32_t* d_out = out;
     if (flags & PROSSTT_AMD_HOST_OUTPUT) {
@@ -887,6 +912,7 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
     HIP_TRY(hipGetLastError());
     c->list = heavy.list;
     c->list_count = heavy.count;
+    c->list_bail_id = heavy.bail_id;
     c->list_regions = geo.regions;
     c->list_cap = heavy.cap;
     c->list_groups = geo.groups;
@@ -926,18 +952,22 @@ PA_EXPORT int prosstt_amd_last_list(prosstt_amd_ctx* c, int64_t* cells, int32_t*
     int64_t flagw[4];
     HIP_TRY(hipMemcpy(flagw, c->scratch, sizeof(flagw), hipMemcpyDeviceToHost));
     if (overflowed) *overflowed = (int32_t)((uint32_t)flagw[3] != 0u);
-    std::vector<uint32_t> entries(c->list_cap);
+    std::vector<uint2> entries(c->list_cap);
+    uint32_t bail[k3::kBailSlots];
     int64_t written = 0;
     for (uint64_t r = 0; r < c->list_regions; ++r) {
-        const uint32_t n = counts[r] < c->list_cap ? counts[r] : c->list_cap;
-        *total += n;
-        if (n == 0 || written >= cap) continue;
-        HIP_TRY(hipMemcpy(entries.data(), c->list + r * c->list_cap, (size_t)n * 4, hipMemcpyDeviceToHost));
+        const uint32_t listed = counts[r] & 0xffffu, walks = counts[r] >> 16;
+        const uint32_t n = listed < c->list_cap ? listed : c->list_cap;
+        *total += n + walks;
+        if (n + walks == 0 || written >= cap) continue;
+        if (n) HIP_TRY(hipMemcpy(entries.data(), c->list + r * c->list_cap, (size_t)n * sizeof(uint2), hipMemcpyDeviceToHost));
+        if (walks) HIP_TRY(hipMemcpy(bail, c->list_bail_id + r * k3::kBailSlots, (size_t)walks * 4, hipMemcpyDeviceToHost));
         const int64_t blk = (int64_t)(r >> 2), tile_g = blk / c->list_groups;
         const int64_t n0 = ((blk - tile_g * c->list_groups) * 4 + (int64_t)(r & 3)) * c->list_strip_cells;
-        for (uint32_t i = 0; i < n && written < cap; ++i, ++written) {
-            cells[written] = n0 + (entries[i] >> 8);
-            genes[written] = (int32_t)(tile_g * kTileG + (entries[i] & 255u));
+        for (uint32_t i = 0; i < n + walks && written < cap; ++i, ++written) {
+            const uint32_t pos = i < n ? entries[i].x : (bail[i - n] & 0xffffu);
+            cells[written] = n0 + (pos >> 8);
+            genes[written] = (int32_t)(tile_g * kTileG + (pos & 255u));
         }
     }
     return 0;
@@ -996,6 +1026,36 @@ PA_EXPORT int prosstt_amd_hw_math(prosstt_amd_ctx* c, int32_t op, uint32_t first
         HIP_TRY(hipMemcpyAsync(out, d, count * 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
+    return 0;
+}
+PA_CATCH
+
+PA_EXPORT int prosstt_amd_hw_math_at(prosstt_amd_ctx* c, int32_t op, const float* x, uint64_t count, float* out,
+                                     uint32_t flags) try
+{
+    if (!c || !out || !x) return fail(PROSSTT_AMD_EINVAL, "NULL argument");
+    if (op < 0 || op > 5) return fail(PROSSTT_AMD_EINVAL, "op must be 0 (rcp), 1 (log2), 2 (exp2 of -x), 3 (sqrt), 4 (rsq) or 5 (cos of x revolutions)");
+    if (count == 0) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    Staging st;
+    const float* dx = x;
+    float* dy = out;
+    int rc;
+    if (flags & PROSSTT_AMD_HOST_INPUTS) {
+        const void* p = nullptr;
+        if ((rc = st.upload(x, count * 4, &p, c->stream))) return rc;
+        dx = (const float*)p;
+    }
+    if (flags & PROSSTT_AMD_HOST_OUTPUT) {
+        void* p = nullptr;
+        if ((rc = st.alloc(&p, count * 4))) return rc;
+        dy = (float*)p;
+    }
+    const uint64_t blocks = (count + 255) / 256;
+    hw_math_at_kernel<<<dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, c->stream>>>(op, dx, count, dy);
+    HIP_TRY(hipGetLastError());
+    if (flags & PROSSTT_AMD_HOST_OUTPUT) HIP_TRY(hipMemcpyAsync(out, dy, count * 4, hipMemcpyDeviceToHost, c->stream));
+    if (flags & (PROSSTT_AMD_HOST_OUTPUT | PROSSTT_AMD_HOST_INPUTS)) HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
 PA_CATCH

@@ -173,6 +173,20 @@ class Context:
             out.ctypes.data_as(ctypes.c_void_p), _native.HOST_OUTPUT))
         return out
 
+    HW_OPS_AT = dict(rcp=0, log2=1, exp2neg=2, sqrt=3, rsq=4, cos=5)
+
+    def hw_math_at(self, op, x):
+        """float32 host array y[i] = f(x[i]) of one of the hardware functions of the sampler's definition (a name of
+        HW_OPS_AT or its code; 'cos' takes revolutions), computed by the device (prosstt_amd_hw_math_at): what the
+        checking model asks while it evaluates the gamma-Poisson class."""
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.empty(x.size, np.float32)
+        code = self.HW_OPS_AT[op] if isinstance(op, str) else int(op)
+        _native.check(self._lib.prosstt_amd_hw_math_at(
+            self._h, code, x.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(x.size),
+            out.ctypes.data_as(ctypes.c_void_p), _native.HOST_OUTPUT | _native.HOST_INPUTS))
+        return out
+
     def nb_params(self, means, row_of_cell, scaling, alpha, beta):
         """(mu, p, r, path) device tensors (N, G) -- the sampler's deterministic intermediates."""
         torch = _torch()

@@ -48,9 +48,10 @@ def has_gpu():
 @pytest.fixture(scope="session", autouse=True)
 def device_hw_tables():
     """On a GPU box: give the scalar model (oracle/nb_model.c) the device's own tables of the three hardware
-    functions of the sampler's definition (v_rcp_f32, v_log_f32, v_exp_f32 -- written by the product's probe kernel,
-    prosstt_amd_hw_math), so that every comparison of device counts with the model is bit for bit.  Without a GPU
-    the model stays on its libm stand-ins (the same law; no device result is compared then)."""
+    functions of the inversion class (v_rcp_f32, v_log_f32, v_exp_f32 -- written by the product's probe kernel,
+    prosstt_amd_hw_math) and the function that answers the gamma-Poisson class's questions (prosstt_amd_hw_math_at:
+    y[i] = op(x[i]) on the device), so that every comparison of device counts with the model is bit for bit.  Without
+    a GPU the model stays on its libm stand-ins (the same law; no device result is compared then)."""
     if not has_gpu():
         yield False
         return
