@@ -52,7 +52,7 @@
 #define PRNB_THETA_MIN    1.1920929e-7f  /* 2^-23: 1 + theta > 1 in binary32; below this NB == Poisson to 1e-7 of the variance */
 #define PRNB_THETA_MAX    1.0e18f
 #define PRNB_R_MIN        9.094947e-13f  /* 2^-40: P(X>0) < 2^-32, return 0 */
-#define PRNB_WALK_END     1022         /* the group k = 1019..1022 is a walk's last: P(X > 1022) < 1e-25 in the inversion class */
+#define PRNB_WALK_END     1024         /* the group k = 1021..1024 is a walk's last: P(X > 1024) < 1e-12 in the inversion class */
 #define PRNB_KTAB         1032         /* 1/k for 1 <= k < KTAB */
 #define PRNB_POIS_INV     10.0f        /* Poisson: inversion below, PTRS above */
 #define PRNB_LAM_BIG      4194304.0f   /* 2^22: rounded normal above */
@@ -255,7 +255,8 @@ __attribute__((constructor)) static void prnb_init(void)
  * `ps` enters as P(0) * 2^32.  `w` is the 32-bit uniform; the remainder starts as (float)w (round to
  * nearest: 24 significant bits, full resolution below 2^24) and every term is subtracted from it in
  * binary32; the draw is the first k whose subtraction leaves the remainder negative.  Terms come in the
- * groups the device walks in (k = 0..2, then four at a time); when a group ends without a negative
+ * groups the device walks in (k = 0..4 -- stage 2 of the streaming kernel --, then four at a time: PRNB-7; PRNB-6 had
+ * k = 0..2 first, and a third more walks in the kernel's third stage); when a group ends without a negative
  * remainder and its LAST term is below 1 -- the pmf has fallen under 2^-32: mass lost to rounding, < 1e-6 --
  * the draw is that group's last k, as it is when the group is the last one (k = PRNB_WALK_END).
  * The ratio of a term comes by ONE fma from the table's 1/(k+1), the term by ONE multiplication.  The
@@ -269,7 +270,7 @@ static inline int32_t chop_down(uint32_t w, float ps, float mp, float q)
     for (int k = 0; ; ) {
         rem = rem - ps;
         if (rem < 0.0f) return k;
-        if ((k & 3) == 2 && (ps < 1.0f || k >= PRNB_WALK_END)) return k;     /* k = 2, 6, 10, ...: a group's last term */
+        if (k >= 4 && (k & 3) == 0 && (ps < 1.0f || k >= PRNB_WALK_END)) return k;     /* k = 4, 8, 12, ...: a group's last term */
         ps = (k == 0) ? ps * mp : ps * FMA(d, g_inv_k[k + 1], q);
         ++k;
     }

@@ -50,11 +50,12 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
     uint64_t cell_offset, const int64_t* __restrict__ cell_index, int32_t* __restrict__ out, int64_t ld,
     int64_t* __restrict__ check_words, uint32_t check_request, uint32_t check_bad_row, uint32_t check_verdict)
 {
-    __shared__ __attribute__((aligned(16))) float inv_k[prnb::kKTab];       // 1/k, k < kKTab (a walk ends at kWalkEnd)
+    __shared__ __attribute__((aligned(16))) float inv_k_store[prnb::kTabShift + prnb::kKTab];       // 1/k, k < kKTab (a walk ends at kWalkEnd)
+    float* const inv_k = inv_k_store + prnb::kTabShift;                      // &inv_k[6 + 4 j] is 16-byte aligned
     __shared__ HeavyLds lds_all[kHeavyBlock / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     HeavyLds& L = lds_all[wv];
-    for (int k = tid; k < prnb::kKTab; k += kHeavyBlock) inv_k[k] = k ? 1.0f / (float)k : 0.0f;
+    for (int k = tid - prnb::kTabShift; k < prnb::kKTab; k += kHeavyBlock) inv_k[k] = k > 0 ? 1.0f / (float)k : 0.0f;
     __syncthreads();
 
     int hg_top = 0, hp_top = 0, hw_top = 0;      // wave-uniform
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
         // two groups of four terms for every walking lane (an idle lane computes on zeros).  Most passes of a
         // strip's longest walks end nowhere: one wave-level test then skips everything but the arithmetic.
         const bool busy = wk >= 0;
-        const float* tab = &inv_k[busy ? wk + 1 : 0];
+        const float* tab = &inv_k[busy ? wk + 1 : 6];
         const float4 ia = *reinterpret_cast<const float4*>(__builtin_assume_aligned(tab, 16));
         const float4 ib = *reinterpret_cast<const float4*>(__builtin_assume_aligned(tab + 4, 16));
         const float a1 = wrem - wps;
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
             const int32_t at_a = (a1 < 0.0f) ? wk : ((a2 < 0.0f) ? wk + 1 : ((a3 < 0.0f) ? wk + 2 : wk + 3));
             const int32_t at_b = (b1 < 0.0f) ? wk + 4 : ((b2 < 0.0f) ? wk + 5 : ((b3 < 0.0f) ? wk + 6 : wk + 7));
             if (busy && (end_a || end_b)) {
-                out[(int64_t)wn * ld + wg] = end_a ? at_a : at_b;         // (>= 3)
+                out[(int64_t)wn * ld + wg] = end_a ? at_a : at_b;         // (>= 5)
                 wk = -1;
                 wps = 0.0f;
             }
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
 
     // ---- a sample from its start (rare: a walk past k = 254, or any sample of an overflowed region): the mean is
     // gathered, the class decided; the gamma-Poisson class goes on HG, an inversion walk is taken through its first
-    // group (k = 0, 1, 2) and, when that does not decide it, pushed as a walk state at k = 3
+    // group (k = 0 .. 4) and, when that does not decide it, pushed as a walk state at k = 5
     auto from_start = [&](bool has, int32_t n, int32_t g) __attribute__((always_inline)) {
         bool heavy_c = false, light = false;
         prnb::Params P;
@@ -330,39 +331,60 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
             const float r1 = r0 - p1;
             const float p2 = p1 * PRNB_FMA(d, inv_k[2], q);
             const float r2 = r1 - p2;
-            const bool done = (r0 < 0.0f) || (r1 < 0.0f) || (r2 < 0.0f) || (p2 < 1.0f);
-            const int32_t x = (r0 < 0.0f) ? 0 : ((r1 < 0.0f) ? 1 : 2);
+            const float p3 = p2 * PRNB_FMA(d, inv_k[3], q);
+            const float r3 = r2 - p3;
+            const float p4 = p3 * PRNB_FMA(d, inv_k[4], q);
+            const float r4 = r3 - p4;
+            const bool done = (r0 < 0.0f) || (r1 < 0.0f) || (r2 < 0.0f) || (r3 < 0.0f) || (r4 < 0.0f) || (p4 < 1.0f);
+            const int32_t x = (r0 < 0.0f) ? 0 : ((r1 < 0.0f) ? 1 : ((r2 < 0.0f) ? 2 : ((r3 < 0.0f) ? 3 : 4)));
             if (light && done && x != 0) out[(int64_t)n * ld + g] = x;
             push = light && !done;
-            s.x = p2 * PRNB_FMA(d, inv_k[3], q);
-            s.y = d; s.z = q; s.w = r2;
+            s.x = p4 * PRNB_FMA(d, inv_k[5], q);
+            s.y = d; s.z = q; s.w = r4;
         }
-        walk_push(push, n, g, 3, s);
+        walk_push(push, n, g, 5, s);
         while (hg_top >= 64) gamma_pass();
     };
 
-    // ---- the list, four regions per wave and step ---------------------------------------------------
-    const int64_t wave_id = (int64_t)blockIdx.x * (kHeavyBlock / 64) + wv;
-    const int64_t waves = (int64_t)gridDim.x * (kHeavyBlock / 64);
+    // ---- the list -------------------------------------------------------------------------------------
+    // list entries of one region (its cells start at n0, its genes at tile_g * 256), one per lane: an entry with its
+    // mean is of the gamma-Poisson class (the streaming kernel decided that), one without is redone from its start
+    auto take_entries = [&](bool has, uint32_t px, uint32_t py, int64_t n0, int32_t tile_g) __attribute__((always_inline)) {
+        const int32_t n = (int32_t)(n0 + (px >> 8)), g = tile_g * kTileG + (int32_t)(px & 255u);
+        const float m = __uint_as_float(py);
+        const bool heavy_c = has && m >= 0.0f;
+        const unsigned long long mh = __builtin_amdgcn_ballot_w64(heavy_c);
+        if (heavy_c) {
+            HGEntry e;
+            e.n = n; e.g = g; e.attempt = 0; e.m = m;
+            L.hg[hg_top + lane_rank(mh)] = e;
+        }
+        hg_top += __popcll(mh);
+        while (hg_top >= 64) gamma_pass();
+        const bool redo = has && !(m >= 0.0f);
+        if (__builtin_amdgcn_ballot_w64(redo) != 0ull) from_start(redo, n, g);
+    };
+    const int32_t groups = (strips + 3) / 4;
+    const uint32_t wave_id = blockIdx.x * (kHeavyBlock / 64) + (uint32_t)wv, waves = gridDim.x * (kHeavyBlock / 64);
+    // Phase 1: four regions per wave and step, 16 lanes each -- a region's count, its first kDense entries and the walk
+    // states of its strip, read side by side from three compact arrays (one level of loads per step).  A wave's regions
+    // lie `waves` apart: the listed samples cluster in a few gene tiles (regions are laid out tile by tile).
     {
-        // four regions per step, 16 lanes each: a region holds ~30 entries on the headline workload; a step depends on
-        // ONE level of loads (the count and the first 16 entries are read side by side; an entry carries its mean)
-        const int32_t groups = (strips + 3) / 4;
         const int sub = lane >> 4, sl = lane & 15;
-        // a wave's regions lie `waves` apart: the listed samples cluster in a few gene tiles (regions are laid out
-        // tile by tile), and neighbouring regions for one wave would leave most waves waiting for a few
-        for (int64_t r0 = wave_id; r0 < (int64_t)regions; r0 += waves * 4) {
-            const int64_t r = r0 + (int64_t)sub * waves;
+        const uint4* const dense4 = reinterpret_cast<const uint4*>(heavy.dense);      // two entries per lane and load
+        for (uint64_t r0 = wave_id; r0 < (uint64_t)regions; r0 += 4ull * waves) {
+            const int64_t r = (int64_t)r0 + (int64_t)sub * waves;
             const bool in = r < (int64_t)regions;
-            // the first 16 entries and the walk states are read beside the count, not behind it (a region's words exist
-            // whatever they hold)
             const uint32_t cnt_word = in ? heavy.count[r] : 0u;
-            uint2 p = in ? heavy.list[(uint64_t)r * heavy.cap + (uint32_t)sl] : make_uint2(0u, 0u);
+            uint4 d4 = make_uint4(0u, 0u, 0u, 0u);
             f32x4_t bst = {0.0f, 0.0f, 0.0f, 0.0f};
             uint32_t bid = 0u;
             if (in) {
-                bst = heavy.bail_st[(uint64_t)r * kBailSlots + (uint32_t)sl];
-                bid = heavy.bail_id[(uint64_t)r * kBailSlots + (uint32_t)sl];
+                d4 = dense4[(uint64_t)r * (kDense / 2) + (uint32_t)sl];
+                if (sl < kBailSlots) {
+                    bst = heavy.bail_st[(uint64_t)r * kBailSlots + (uint32_t)sl];
+                    bid = heavy.bail_id[(uint64_t)r * kBailSlots + (uint32_t)sl];
+                }
             }
             const uint32_t cnt_all = cnt_word & 0xffffu, n_bail = cnt_word >> 16;
             const int32_t blk = (int32_t)(r >> 2);
@@ -373,24 +395,8 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
             // the unfinished walks of the region's strip: continued from their state
             walk_push((uint32_t)sl < n_bail, (int32_t)(n0 + ((bid & 0xffffu) >> 8)), tile_g * kTileG + (int32_t)(bid & 255u),
                       (int32_t)(bid >> 16) - 3, bst);
-            for (uint32_t i0 = 0u; __builtin_amdgcn_ballot_w64(i0 < cnt) != 0ull; i0 += 16u) {
-                const bool has = i0 + (uint32_t)sl < cnt;
-                if (i0 != 0u) p = has ? heavy.list[(uint64_t)r * heavy.cap + i0 + (uint32_t)sl] : make_uint2(0u, 0u);
-                const int32_t n = (int32_t)(n0 + (p.x >> 8)), g = tile_g * kTileG + (int32_t)(p.x & 255u);
-                const float m = __uint_as_float(p.y);
-                // an entry with its mean is of the gamma-Poisson class (the streaming kernel decided that)
-                const bool heavy_c = has && m >= 0.0f;
-                const unsigned long long mh = __builtin_amdgcn_ballot_w64(heavy_c);
-                if (heavy_c) {
-                    HGEntry e;
-                    e.n = n; e.g = g; e.attempt = 0; e.m = m;
-                    L.hg[hg_top + lane_rank(mh)] = e;
-                }
-                hg_top += __popcll(mh);
-                while (hg_top >= 64) gamma_pass();
-                const bool redo = has && !(m >= 0.0f);
-                if (__builtin_amdgcn_ballot_w64(redo) != 0ull) from_start(redo, n, g);
-            }
+            take_entries(2u * (uint32_t)sl < cnt, d4.x, d4.y, n0, tile_g);
+            take_entries(2u * (uint32_t)sl + 1u < cnt, d4.z, d4.w, n0, tile_g);
             // every sample of an overflowed region (strip_cells x 256 of the matrix) goes through the classification
             // here, 64 at a time: slow (the streaming kernel's own results are recomputed), but any parameter set
             // stays correct and only the regions that overflowed pay
@@ -406,6 +412,50 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
                         const int32_t g = tg * kTileG + j * 64 + lane;
                         from_start(g < G, (int32_t)(nb + c), g);
                     }
+            }
+        }
+    }
+    // Phase 2: what a region lists behind its first kDense entries, in chunks of 64 -- one entry per lane, one coalesced
+    // load per chunk -- and NOT by the region's own wave: chunk c of region r belongs to wave (r + (c + 1) * shift) mod
+    // waves.  A hot gene tile is a run of `4 * groups` neighbouring regions with hundreds of entries each; its chunks
+    // spread evenly over all waves this way (left to their own waves, the waves that own a hot region or two ran three
+    // times as long as the median wave, each through a chain of dependent loads).  A wave finds its chunks by reading the
+    // counts of the regions that can hand it one: 16 chunk numbers x the regions `waves` apart.
+    {
+        constexpr uint32_t kChunk = 64u, kChunks = 16u;      // cap <= kDense + kChunks * kChunk
+        const uint32_t shift = ((4u * (uint32_t)groups) % waves) | 1u;
+        const uint32_t per_chunk = (regions + waves - 1u) / waves;         // regions r = own + j * waves
+        const uint32_t pairs = kChunks * per_chunk;
+        for (uint32_t p0 = 0u; p0 < pairs; p0 += 64u) {
+            const uint32_t p = p0 + (uint32_t)lane;
+            const uint32_t c = p & (kChunks - 1u), j = p / kChunks;
+            const uint32_t own = (wave_id + waves - (((c + 1u) * shift) % waves)) % waves;
+            const uint64_t r = (uint64_t)own + (uint64_t)j * waves;
+            const uint32_t cw = (p < pairs && r < (uint64_t)regions) ? heavy.count[r] & 0xffffu : 0u;
+            const bool work = cw <= heavy.cap && (uint32_t)kDense + c * kChunk < cw;
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(work);
+            // the next chunk's entries are requested before this chunk's are looked at
+            uint2 nx = make_uint2(0u, 0u);
+            auto request = [&](int src) __attribute__((always_inline)) {
+                const uint32_t rr = (uint32_t)__builtin_amdgcn_readlane((int32_t)(uint32_t)r, src);
+                const uint32_t cc = (uint32_t)__builtin_amdgcn_readlane((int32_t)c, src);
+                const uint32_t cn = (uint32_t)__builtin_amdgcn_readlane((int32_t)cw, src);
+                const uint32_t slot = (uint32_t)kDense + cc * kChunk + (uint32_t)lane;
+                nx = slot < cn ? heavy.list[(uint64_t)rr * heavy.cap + slot] : make_uint2(0u, 0u);
+            };
+            if (todo != 0ull) request((int)__builtin_ctzll(todo));
+            while (todo != 0ull) {
+                const int src = (int)__builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                const uint2 e = nx;
+                const uint32_t rr = (uint32_t)__builtin_amdgcn_readlane((int32_t)(uint32_t)r, src);
+                const uint32_t cc = (uint32_t)__builtin_amdgcn_readlane((int32_t)c, src);
+                const uint32_t cn = (uint32_t)__builtin_amdgcn_readlane((int32_t)cw, src);
+                if (todo != 0ull) request((int)__builtin_ctzll(todo));
+                const int32_t blk = (int32_t)(rr >> 2);
+                const int32_t tile_g = blk / groups;
+                const int64_t n0 = (int64_t)((blk - tile_g * groups) * 4 + (int32_t)(rr & 3u)) * strip_cells;
+                take_entries((uint32_t)kDense + cc * kChunk + (uint32_t)lane < cn, e.x, e.y, n0, tile_g);
             }
         }
     }

@@ -59,10 +59,10 @@ constexpr int kS2Run = 40;         // stage 3 runs while S2 holds at least this 
 static_assert(kS2Cap >= kS2Run - 1 + 64 && kS1Cap >= 63 + 128, "a stack must take one more round of pushes");
 constexpr int kRing = 8;           // rows of the strip kept in LDS (8 bits per count) before they are stored; a power of 2
 constexpr int kBail = 6;           // walks handed to K3h WITH THEIR STATE when a strip has nothing else to do (see the drain)
-constexpr int kBailSlots = 16;     // room for them per wave (kBail <= kBailSlots)
+constexpr int kBailSlots = 8;      // room for them per wave (kBail <= kBailSlots <= 16)
 static_assert(kBail <= kBailSlots, "a wave's unfinished walks must fit its slots");
 constexpr int kLateCap = 64;       // results that missed their row wait here for one burst of stores (a pass delivers at most 64)
-constexpr int kRingMaxK3 = 254;    // a walk whose group k3-3..k3 with k3 = 254 ends undecided goes to K3h: counts fit the ring's 8 bits
+constexpr int kRingMaxK3 = 248;    // a walk whose group k3-3..k3 with k3 = 248 ends undecided goes to K3h: counts fit the ring's 8 bits (k3 = 8, 16, ...)
 constexpr int kInvTab = 272;       // 1/k for k < 272: the reciprocals a pass at k3 <= 254 reads ahead (k3 + 6 .. k3 + 13)
 
 // What stage 1 needs to know about a cell, packed by the preparation kernel so that one scalar load
@@ -126,8 +126,15 @@ struct WaveLds {
 // length 64-75 per C3 launch).
 static_assert(offsetof(WaveLds, s1) == offsetof(WaveLds, s1_null) + sizeof(S1Entry), "s1[-1] must be the null entry");
 
+// A region's first kDense entries lie in `dense` (regions x kDense entries, contiguous: 16 MB at C3), only the ones behind
+// them in the region's own kilobytes of `list`: K3h reads a region's count, its dense entries and its walk states side by
+// side from three compact arrays (the list spreads a region over its own page: a TLB miss per region, 12 us of K3h).
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
-struct HeavyList { uint32_t* count; uint2* list; uint32_t* overflow; uint32_t cap; f32x4_t* bail_st; uint32_t* bail_id; };
+constexpr int kDense = 32;
+struct HeavyList {
+    uint32_t* count; uint2* list; uint32_t* overflow; uint32_t cap; f32x4_t* bail_st; uint32_t* bail_id;
+    uint2* dense;
+};
 constexpr float kRedoMark = -1.0f;   // list entry: no mean, redo from the start
 
 __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
@@ -151,9 +158,10 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
 {
     // LDS of a block: 30 304 B.  gfx950 hands it out in 1 280-byte granules, so the five blocks per CU that the kernel's
     // speed rests on (the fifth: -11 %) fit as long as a block stays at or under 32 000 B (measured: 32 352 B gives four).
-    // 1/k for k = -4 .. kInvTab-1: 0 below k = 1 (never used below 1: an idle stage-3 lane rests at k3 = 6)
-    __shared__ __attribute__((aligned(16))) float inv_k_store[4 + kInvTab];
-    float* const inv_k = inv_k_store + 4;
+    // 1/k for k = -2 .. kInvTab-1: 0 below k = 1 (never used below 1: an idle stage-3 lane rests at k3 = 8); a pass reads
+    // 1/(k3-2) .. 1/(k3+5) with k3 = 8, 16, ...: entry 6 is 16-byte aligned (prnb::kTabShift)
+    __shared__ __attribute__((aligned(16))) float inv_k_store[prnb::kTabShift + kInvTab + 2];
+    float* const inv_k = inv_k_store + prnb::kTabShift;
     __shared__ WaveLds lds_all[kBlock / 64];
     // the row rings, [wave][row slot][gene-in-tile] (8 bits per count), each aligned to its own size: a delivery's LDS
     // address is then (pos AND (size - 1)) OR base -- one instruction
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     WaveLds& L = lds_all[wv];
 
-    for (int k = tid - 4; k < kInvTab; k += kBlock) inv_k[k] = k > 0 ? 1.0f / (float)k : 0.0f;
+    for (int k = tid - prnb::kTabShift; k < kInvTab + 2; k += kBlock) inv_k[k] = k > 0 ? 1.0f / (float)k : 0.0f;
     __syncthreads();
 
     // block -> (gene tile, group of 4 strips); adjacent blocks share the gene tile (L2 reuse of
@@ -206,9 +214,9 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     f32x4 st = {0.0f, 0.0f, 0.0f, 0.0f};
     uint32_t pos = 0u;
-    int k3 = 6;
-    f32x4 inv = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(&inv_k[4], 16));   // 1/(k+1) .. 1/(k+4): read one pass ahead
-    f32x4 inv2 = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(&inv_k[8], 16));  // 1/(k+5) .. 1/(k+8)
+    int k3 = 8;
+    f32x4 inv = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(&inv_k[6], 16));   // 1/(k+1) .. 1/(k+4), k = 5: read one pass ahead
+    f32x4 inv2 = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(&inv_k[10], 16));  // 1/(k+5) .. 1/(k+8)
     unsigned long long idle_s = ~0ull;                   // wave-uniform
 
     // S1/S2 entries carry pos = (cell-in-strip << 8) | gene-in-tile, under the bits of 2^23 (kPosMagic, below)
@@ -282,7 +290,10 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
         const unsigned long long mp_ = K3_MASK(hpend != kNoHeavy);
         if (hpend != kNoHeavy) {
             const uint32_t slot = h_cnt + (uint32_t)lane_rank(mp_);
-            if (slot < heavy.cap) my_list[slot] = make_uint2(hpend & 0xffffu, __float_as_uint(hpend_m));
+            if (slot < heavy.cap) {
+                uint2* const dst = slot < (uint32_t)kDense ? heavy.dense + ((uint64_t)region * kDense + slot) : my_list + slot;
+                *dst = make_uint2(hpend & 0xffffu, __float_as_uint(hpend_m));
+            }
         }
         h_cnt += (uint32_t)__popcll(mp_);
         hpend = kNoHeavy;
@@ -382,7 +393,7 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
         // an idle lane rests at k3 = 6 with the reciprocals of a walk's first two groups (the reads below fetch them again
         // every pass): a pull then brings only the entry
         const int k3n = k3 + 8;
-        asm("v_cndmask_b32 %0, %1, 6, %2" : "=v"(k3) : "v"(k3n), "s"(idle_s));
+        asm("v_cndmask_b32 %0, %1, 8, %2" : "=v"(k3) : "v"(k3n), "s"(idle_s));
         st.w = r8;
         inv = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(&inv_k[k3 - 2], 16));    // 1/(k+1..k+4), k = k3 - 3
         inv2 = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(&inv_k[k3 + 2], 16));   // 1/(k+5..k+8)
@@ -426,10 +437,15 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
         const float r1 = r0 - ps1;
         const float ps2 = ps1 * PRNB_FMA(dd, 0.5f, qq);
         const float r2 = r1 - ps2;
-        const unsigned long long hit_m = K3_MASK(r2 < 0.0f);
-        const unsigned long long tail_m = K3_MASK(ps2 < 1.0f);
-        // a hit: 2 less one for each of r0, r1 that is negative; no hit: 2 if the tail test ends the walk here
-        const uint32_t res = (uint32_t)((2 + ((int32_t)prnb::f2u(r0) >> 31)) + ((int32_t)prnb::f2u(r1) >> 31));
+        const float ps3 = ps2 * PRNB_FMA(dd, 0.33333334f, qq);      // (the 1/k table's values)
+        const float r3 = r2 - ps3;
+        const float ps4 = ps3 * PRNB_FMA(dd, 0.25f, qq);
+        const float r4 = r3 - ps4;
+        const unsigned long long hit_m = K3_MASK(r4 < 0.0f);
+        const unsigned long long tail_m = K3_MASK(ps4 < 1.0f);
+        // a hit: 4 less one for each of r0 .. r3 that is negative; no hit: 4 if the tail test ends the walk here
+        const uint32_t res = (uint32_t)(((4 + ((int32_t)prnb::f2u(r0) >> 31)) + ((int32_t)prnb::f2u(r1) >> 31)) +
+                                        (((int32_t)prnb::f2u(r2) >> 31) + ((int32_t)prnb::f2u(r3) >> 31)));
         const unsigned long long walk_m = valid_m & light_m;                  // decided by this kernel
         const unsigned long long end_m = hit_m | tail_m;
         deliver(walk_m & end_m, valid_m & ~light_m, p2, res, m);     // (a count of 0 is written as well: the ring slot holds 0 anyway)
@@ -439,10 +455,10 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
         {
             const uint32_t rank = (uint32_t)lane_rank(push_m);
             f32x4 e2;
-            e2.x = ps2 * PRNB_FMA(dd, 0.33333334f, qq);      // pmf at k = 3 (the 1/k table's 1/3)
+            e2.x = ps4 * PRNB_FMA(dd, 0.2f, qq);             // pmf at k = 5 (the 1/k table's 1/5)
             e2.y = dd;
             e2.z = qq;
-            e2.w = r2;
+            e2.w = r4;
             asm volatile("s_mov_b64 exec, %0\n\tds_write_b128 %1, %2\n\tds_write_b32 %3, %4\n\ts_mov_b64 exec, -1"
                          :: "s"(push_m), "v"((rank << 4) + (s2_lds + ((uint32_t)s2_top << 4))), "v"(e2),
                             "v"((rank << 2) + (s2p_lds + ((uint32_t)s2_top << 2))), "v"(p2) : "memory");

@@ -30,11 +30,14 @@ constexpr float kLightTheta = 24.0f;   // tail ratio <= 24/25 (PRNB-6; 16 until 
 constexpr float kThetaMin = 1.1920929e-7f;   // 2^-23: 1 + theta > 1 in binary32 (below this NB == Poisson to 1e-7 of the variance)
 constexpr float kThetaMax = 1.0e18f;
 constexpr float kRMin = 9.094947e-13f;       // 2^-40
-// The inversion walk ends at k = kWalkEnd at the latest: the group k = 1019..1022 is the last one, and when it ends
-// without a negative remainder the count is 1022 (in the inversion class the mean is below 142 and the tail ratio at
+// The inversion walk ends at k = kWalkEnd at the latest: the group k = 1021..1024 is the last one, and when it ends
+// without a negative remainder the count is 1024 (in the inversion class the mean is below 142 and the tail ratio at
 // most 24/25: P(X > 1022) < 1e-12, scipy's nbinom.sf at the class corner).  The 1/k table holds 1/k for 1 <= k < kKTab (the K3h walk reads two groups ahead).
-constexpr int kWalkEnd = 1022;
-constexpr int kKTab = 1032;
+// Groups: k = 0..4 (stage 2 of the streaming kernel), then four at a time from k = 5 -- so a 16-byte read of 1/(k+1)..1/(k+4)
+// is aligned when the table's entry 6 is (kTabShift).
+constexpr int kWalkEnd = 1024;
+constexpr int kKTab = 1034;
+constexpr int kTabShift = 2;           // inv_k = (16-byte aligned store) + kTabShift: &inv_k[6 + 4 j] is 16-byte aligned
 constexpr float kPoisInv = 10.0f;
 constexpr float kLamBig = 4194304.0f;        // 2^22
 constexpr int kMaxTries = 64;
@@ -215,11 +218,11 @@ __device__ __forceinline__ float hw_log1pmx(float d, float rho)
 __device__ __forceinline__ float det_sqrt(float x) { return __builtin_sqrtf(x); }  // IEEE (see Makefile)
 
 // Inversion by chop-down on a binary32 remainder; inv_k = LDS table of 1/k
-// (16-byte aligned, kKTab entries).
+// (kKTab entries, &inv_k[6] 16-byte aligned: kTabShift).
 // P(k+1) = P(k) * (q + (mp - q)/(k+1)) -- the ratio (mp + k*q)/(k+1) by ONE fma from the table's 1/(k+1); k = 0:
 // P(0) * mp --, carried scaled by 2^32.  The remainder starts as
 // (float)w and every term is subtracted from it; the draw is the first k whose subtraction leaves it
-// negative.  Terms come in groups (k = 0..2, then four at a time: the streaming kernel's passes); when
+// negative.  Terms come in groups (k = 0..4, then four at a time: the streaming kernel's passes); when
 // a group ends without a negative remainder and its last term is below 1 (the pmf has fallen under
 // 2^-32 before w is used up: mass lost to rounding, < 1e-6) the draw is that group's last k, as it is
 // when the group is the last one (k = kWalkEnd).
@@ -234,18 +237,22 @@ __device__ __forceinline__ int32_t chop_down_wave(bool active, uint32_t w, float
     float ps = __builtin_fminf(p0, 0.99999994f) * 4294967296.0f;
     float rem = (float)w;
     const float d = mp - q;
-    // k = 0, 1, 2
+    // k = 0 .. 4
     const float r0 = rem - ps;
     const float p1 = ps * mp;
     const float r1 = r0 - p1;
     const float p2 = p1 * PRNB_FMA(d, inv_k[2], q);
     const float r2 = r1 - p2;
-    int32_t res = (r0 < 0.0f) ? 0 : ((r1 < 0.0f) ? 1 : 2);
-    bool busy = active && !((r0 < 0.0f) || (r1 < 0.0f) || (r2 < 0.0f) || (p2 < 1.0f));
-    ps = p2 * PRNB_FMA(d, inv_k[3], q);
-    rem = r2;
-    const float4* tab = reinterpret_cast<const float4*>(__builtin_assume_aligned(inv_k + 4, 16));
-    int k = 3;
+    const float p3 = p2 * PRNB_FMA(d, inv_k[3], q);
+    const float r3 = r2 - p3;
+    const float p4 = p3 * PRNB_FMA(d, inv_k[4], q);
+    const float r4 = r3 - p4;
+    int32_t res = (r0 < 0.0f) ? 0 : ((r1 < 0.0f) ? 1 : ((r2 < 0.0f) ? 2 : ((r3 < 0.0f) ? 3 : 4)));
+    bool busy = active && !((r0 < 0.0f) || (r1 < 0.0f) || (r2 < 0.0f) || (r3 < 0.0f) || (r4 < 0.0f) || (p4 < 1.0f));
+    ps = p4 * PRNB_FMA(d, inv_k[5], q);
+    rem = r4;
+    const float4* tab = reinterpret_cast<const float4*>(__builtin_assume_aligned(inv_k + 6, 16));
+    int k = 5;
     auto group = [&](const float4 inv) {
         const float a1 = rem - ps;
         const float q2 = ps * PRNB_FMA(d, inv.x, q);
@@ -264,7 +271,7 @@ __device__ __forceinline__ int32_t chop_down_wave(bool active, uint32_t w, float
     // two groups per LDS round trip (k + 3 reaches kWalkEnd in a first group: the second one then runs with
     // busy = false everywhere and reads 1/k up to k = kWalkEnd + 5 < kKTab)
     while (__builtin_amdgcn_ballot_w64(busy) != 0ull) {
-        const float4 ia = tab[(k - 3) >> 2], ib = tab[((k - 3) >> 2) + 1];
+        const float4 ia = tab[(k - 5) >> 2], ib = tab[((k - 5) >> 2) + 1];
         group(ia);
         group(ib);
     }

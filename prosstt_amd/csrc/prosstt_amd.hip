@@ -76,10 +76,11 @@ struct prosstt_amd_ctx {
     uint2* list = nullptr;
     uint32_t* list_count = nullptr;
     uint32_t* list_bail_id = nullptr;
+    uint2* list_dense = nullptr;
     uint64_t list_regions = 0;
     uint32_t list_cap = 0;
     int64_t list_groups = 0, list_strip_cells = 0;
-    int heavy_grid = 1536;       // blocks of K3h that are resident at once on this device (one round: measured best)
+    int heavy_grid = 1280;       // blocks of K3h that are resident at once on this device (5 per CU: its 30 496 B of LDS)
     // domain check: one byte per row of the mean tensor last scanned ("has an entry that is not > 0"), and which tensor that was
     uint8_t* row_bad = nullptr;
     size_t row_bad_cap = 0;
@@ -116,6 +117,7 @@ static int ws_reserve(prosstt_amd_ctx* c, size_t bytes)
     c->list = nullptr;
     c->list_count = nullptr;
     c->list_bail_id = nullptr;
+    c->list_dense = nullptr;
     c->list_regions = 0;
     if (bytes <= c->ws_bytes) return 0;
     if (c->ws) {
@@ -680,8 +682,8 @@ struct StreamGeometry {
     int64_t tiles_g, strip_cells, strips, groups;
     uint64_t regions;       // one region of the K3h list per wave
     uint32_t region_cap;    // room for one in 16 of a wave's samples (beyond that K3h redoes the region itself)
-    size_t list_bytes, count_bytes, bail_st_bytes, bail_id_bytes, info_bytes;
-    size_t total() const { return list_bytes + count_bytes + bail_st_bytes + bail_id_bytes + info_bytes + 256; }
+    size_t list_bytes, count_bytes, bail_st_bytes, bail_id_bytes, dense_bytes, info_bytes;
+    size_t total() const { return list_bytes + count_bytes + bail_st_bytes + bail_id_bytes + dense_bytes + info_bytes + 256; }
 };
 
 static StreamGeometry stream_geometry(int64_t N, int32_t G, int64_t rows)
@@ -695,10 +697,12 @@ static StreamGeometry stream_geometry(int64_t N, int32_t G, int64_t rows)
     g.groups = (g.strips + 3) / 4;
     g.regions = (uint64_t)(g.groups * g.tiles_g) * 4u;
     g.region_cap = (uint32_t)g.strip_cells * (kTileG / 16);
+    if (g.region_cap > 1024u) g.region_cap = 1024u;             // K3h's second phase takes kDense + 16 chunks of 64
     g.list_bytes = ((g.regions * (size_t)g.region_cap * sizeof(uint2)) + 255) & ~(size_t)255;      // {pos, scaled mean}
     g.count_bytes = ((g.regions * 4u) + 255) & ~(size_t)255;
     g.bail_st_bytes = ((g.regions * (size_t)k3::kBailSlots * 16u) + 255) & ~(size_t)255;            // walk states handed over
     g.bail_id_bytes = ((g.regions * (size_t)k3::kBailSlots * 4u) + 255) & ~(size_t)255;
+    g.dense_bytes = ((g.regions * (size_t)k3::kDense * sizeof(uint2)) + 255) & ~(size_t)255;       // a region's first entries
     g.info_bytes = ((size_t)n + 4) * sizeof(k3::CellInfo);
     return g;
 }
@@ -752,7 +756,7 @@ static int sampler_setup(prosstt_amd_ctx* c, Staging& st, const float* means, in
     A->gphi = A->gbm1 + G;
     A->extra = (char*)c->ws + vec_bytes;
     k3::CellInfo* info = nullptr;
-    if (geo) info = (k3::CellInfo*)((char*)A->extra + geo->list_bytes + geo->count_bytes + geo->bail_st_bytes + geo->bail_id_bytes);
+    if (geo) info = (k3::CellInfo*)((char*)A->extra + geo->list_bytes + geo->count_bytes + geo->bail_st_bytes + geo->bail_id_bytes + geo->dense_bytes);
     // a checked call needs the per-row flags of THIS mean tensor: scanned now unless the caller vouches that the tensor
     // the ctx last scanned (same pointer, same shape) has not changed since
     const uint8_t* row_bad = nullptr;
@@ -863,7 +867,8 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
     heavy.cap = geo.region_cap;
     heavy.bail_st = (k3::f32x4_t*)((char*)A.extra + geo.list_bytes + geo.count_bytes);
     heavy.bail_id = (uint32_t*)((char*)A.extra + geo.list_bytes + geo.count_bytes + geo.bail_st_bytes);
-    k3::CellInfo* cellinfo = (k3::CellInfo*)((char*)A.extra + geo.list_bytes + geo.count_bytes + geo.bail_st_bytes + geo.bail_id_bytes);
+    heavy.dense = (uint2*)((char*)A.extra + geo.list_bytes + geo.count_bytes + geo.bail_st_bytes + geo.bail_id_bytes);
+    k3::CellInfo* cellinfo = (k3::CellInfo*)((char*)A.extra + geo.list_bytes + geo.count_bytes + geo.bail_st_bytes + geo.bail_id_bytes + geo.dense_bytes);
     const int64_t* d_cell_index = A.cell_index;
     int32_t* d_out = out;
     if (flags & PROSSTT_AMD_HOST_OUTPUT) {
@@ -913,6 +918,7 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
     c->list = heavy.list;
     c->list_count = heavy.count;
     c->list_bail_id = heavy.bail_id;
+    c->list_dense = heavy.dense;
     c->list_regions = geo.regions;
     c->list_cap = heavy.cap;
     c->list_groups = geo.groups;
@@ -960,7 +966,9 @@ PA_EXPORT int prosstt_amd_last_list(prosstt_amd_ctx* c, int64_t* cells, int32_t*
         const uint32_t n = listed < c->list_cap ? listed : c->list_cap;
         *total += n + walks;
         if (n + walks == 0 || written >= cap) continue;
-        if (n) HIP_TRY(hipMemcpy(entries.data(), c->list + r * c->list_cap, (size_t)n * sizeof(uint2), hipMemcpyDeviceToHost));
+        const uint32_t nd = n < (uint32_t)k3::kDense ? n : (uint32_t)k3::kDense;      // the first entries lie in the dense array
+        if (nd) HIP_TRY(hipMemcpy(entries.data(), c->list_dense + r * k3::kDense, (size_t)nd * sizeof(uint2), hipMemcpyDeviceToHost));
+        if (n > nd) HIP_TRY(hipMemcpy(entries.data() + nd, c->list + r * c->list_cap + nd, (size_t)(n - nd) * sizeof(uint2), hipMemcpyDeviceToHost));
         if (walks) HIP_TRY(hipMemcpy(bail, c->list_bail_id + r * k3::kBailSlots, (size_t)walks * 4, hipMemcpyDeviceToHost));
         const int64_t blk = (int64_t)(r >> 2), tile_g = blk / c->list_groups;
         const int64_t n0 = ((blk - tile_g * c->list_groups) * 4 + (int64_t)(r & 3)) * c->list_strip_cells;

@@ -34,10 +34,6 @@ STORE_2 = """            if (BIG) __builtin_amdgcn_raw_buffer_store_b128(row4, o
             else __builtin_amdgcn_raw_buffer_store_b128(row4, out_rsrc, store_voff, flush_off, 2 /* nt */);"""
 STORE_OFF = (STORE_2, STORE_2.replace("store_voff", "0x80000000u"))   # every lane out of range: dropped
 
-K3H_LAUNCH = """    k3::sample_counts_heavy_kernel<<<dim3(heavy_blocks), dim3(k3::kHeavyBlock), 0, c->stream>>>(
-        heavy, (uint32_t)geo.regions, (int32_t)geo.strips, (int32_t)geo.strip_cells, A.means, rows, G, A.row_of_cell,
-        A.scal, A.ga, A.gbm1, N, k0, k1, cell_offset, d_cell_index, d_out, ld_out);
-"""
 
 SVGPR = ("        const float m4[4] = {cur.x * s, cur.y * s, cur.z * s, cur.w * s};",
          "        float sv_; asm volatile(\"v_mov_b32 %0, %1\" : \"=v\"(sv_) : \"s\"(s));\n"
@@ -60,37 +56,42 @@ VARIANTS = {
                 "            const u32x4_ raw = {0x3ecccccdu, 0x3f8ccccdu, 0x3d4ccccdu, 0x40200000u}; asm volatile(\"\" :: \"s\"(rs), \"v\"(gload_b));")],
     # everything, rows not stored
     "nostore": [STORE_OFF],
-    # K3h without the redo walks / without the gamma-Poisson samples
-    "k3h_noredo": [("            light = P.valid && P.light;\n", "            light = false;\n")],
-    "k3h_noheavy": [("            heavy = P.valid && !P.light;\n", "            heavy = false;\n")],
-    "k3h_grid1024": [("k3::sample_counts_heavy_kernel<<<dim3(heavy_blocks),", "k3::sample_counts_heavy_kernel<<<dim3(1024),")],
-    "k3h_grid2048": [("k3::sample_counts_heavy_kernel<<<dim3(heavy_blocks),", "k3::sample_counts_heavy_kernel<<<dim3(2048),")],
-    "k3h_grid3072": [("k3::sample_counts_heavy_kernel<<<dim3(heavy_blocks),", "k3::sample_counts_heavy_kernel<<<dim3(3072),")],
-    "k3h_grid256": [("k3::sample_counts_heavy_kernel<<<dim3(heavy_blocks),", "k3::sample_counts_heavy_kernel<<<dim3(256),")],
-    "k3h_grid512": [("k3::sample_counts_heavy_kernel<<<dim3(heavy_blocks),", "k3::sample_counts_heavy_kernel<<<dim3(512),")],
-    "k3h_grid768": [("k3::sample_counts_heavy_kernel<<<dim3(heavy_blocks),", "k3::sample_counts_heavy_kernel<<<dim3(768),")],
-    "k3h_none": [("            light = P.valid && P.light;\n", "            light = false;\n"), ("            heavy = P.valid && !P.light;\n", "            heavy = false;\n")],
+    # K3h (round 6 sources) without the handed-over walks / without the gamma-Poisson samples / with an empty list
+    "k3h_nowalk": [("            walk_push((uint32_t)sl < n_bail,", "            walk_push(false && (uint32_t)sl < n_bail,")],
+    "k3h_noheavy": [("        const bool heavy_c = has && m >= 0.0f;", "        const bool heavy_c = false && has && m >= 0.0f;")],
+    "k3h_none": [("            walk_push((uint32_t)sl < n_bail,", "            walk_push(false && (uint32_t)sl < n_bail,"),
+                 ("        const bool heavy_c = has && m >= 0.0f;", "        const bool heavy_c = false && has && m >= 0.0f;")],
+    # K3h leaves at once / after its 1/k table / without looking at the list: what a launch of it costs at least
+    "k3h_exit0": [("    __shared__ HeavyLds lds_all[kHeavyBlock / 64];\n    const int tid = threadIdx.x,", "    __shared__ HeavyLds lds_all[kHeavyBlock / 64];\n    if (N >= 0) return;\n    const int tid = threadIdx.x,")],
+    "k3h_exit1": [("    int hg_top = 0, hp_top = 0, hw_top = 0;      // wave-uniform", "    if (N >= 0) return;\n    int hg_top = 0, hp_top = 0, hw_top = 0;      // wave-uniform")],
+    "k3h_onestep": [("base += 4ull * waves) {", "base += 1ull << 40) {")],
+    # ... the gamma-Poisson entries dropped after the gamma pass
+    "k3h_nopois": [("        while (hp_top >= 64) poisson_pass();\n    };", "        hp_top = 0;\n    };")],
     "k3h_gamma1": [("                    ok = last;\n                    if (!ok) {", "                    ok = true;\n                    if (!ok) {")],
     "k3h_pois1": [("                    again = j + 1 < 2 * prnb::kMaxTries;", "                    again = false;")],
-    # K3h launched twice / three times (idempotent): what a launch costs when its code and data are warm
-    "k3h_twice": [(K3H_LAUNCH, K3H_LAUNCH * 2)],
-    "k3h_thrice": [(K3H_LAUNCH, K3H_LAUNCH * 3)],
-    # K3h: gamma-Poisson entries dropped after the gamma pass
-    "k3h_nopois": [("        while (hp_top >= 64) poisson_pass();", "        hp_top = 0;")],
+    "k3h_grid1024": [("    int heavy_grid = 1536;", "    int heavy_grid = 1024;")],
+    "k3h_grid1280": [("    int heavy_grid = 1536;", "    int heavy_grid = 1280;")],
+    "k3h_grid2560": [("    int heavy_grid = 1536;", "    int heavy_grid = 2560;")],
+    "k3h_grid768": [("    int heavy_grid = 1536;", "    int heavy_grid = 768;")],
+    # K3h launched twice (idempotent): what a launch costs when its code and data are warm
+    "k3h_twice": [("    k3::sample_counts_heavy_kernel<<<dim3(heavy_blocks),", "    for (int rep_ = 0; rep_ < 2; ++rep_) k3::sample_counts_heavy_kernel<<<dim3(heavy_blocks),")],
     # K3h with a device printf of per-phase cycle counts of a few waves (diagnosis; printf costs registers and time)
-    "k3h_trace": [("    int hg_top = 0, hp_top = 0, hl_top = 0;      // wave-uniform",
-                   "    int hg_top = 0, hp_top = 0, hl_top = 0;      // wave-uniform\n    int np_l = 0, np_w = 0, np_g = 0, np_p = 0; long long T0 = clock64(), TW = 0, TL = 0, TG = 0, TP = 0;"),
+    "k3h_trace": [("    int hg_top = 0, hp_top = 0, hw_top = 0;      // wave-uniform",
+                   "    int hg_top = 0, hp_top = 0, hw_top = 0;      // wave-uniform\n    int np_l = 0, np_w = 0, np_g = 0, np_p = 0, n_ent = 0, n_chunks = 0; const long long W0 = wall_clock64(); long long T0 = clock64(), TL = 0, TG = 0, TP = 0;"),
                   ("    auto poisson_pass = [&]() __attribute__((always_inline)) {\n", "    auto poisson_pass = [&]() __attribute__((always_inline)) {\n        ++np_p; const long long tp0 = clock64();\n"),
                   ("        hp_top += __popcll(m);\n    };", "        hp_top += __popcll(m);\n        TP += clock64() - tp0;\n    };"),
                   ("    auto gamma_pass = [&]() __attribute__((always_inline)) {\n", "    auto gamma_pass = [&]() __attribute__((always_inline)) {\n        ++np_g; const long long tg0 = clock64();\n"),
                   ("        hp_top += __popcll(mp);\n        while (hp_top >= 64) poisson_pass();", "        hp_top += __popcll(mp);\n        TG += clock64() - tg0;\n        while (hp_top >= 64) poisson_pass();"),
-                  ("    auto light_service = [&](bool drain) __attribute__((always_inline)) {\n        for (;;) {", "    auto light_service = [&](bool drain) __attribute__((always_inline)) {\n        const long long tl0 = clock64();\n        for (;;) {"),
-                  ("            if (busy <= 32 && (drain ? hl_top > 0 : hl_top >= 32)) light_start();\n            else if (drain ? busy > 0 : busy > 32) light_walk();\n            else break;\n        }",
-                   "            if (busy <= 32 && (drain ? hl_top > 0 : hl_top >= 32)) { light_start(); ++np_l; }\n            else if (drain ? busy > 0 : busy > 32) { light_walk(); ++np_w; }\n            else break;\n        }\n        TL += clock64() - tl0;"),
-                  ("    light_service(true);\n    while (hg_top > 0) gamma_pass();\n    while (hp_top > 0) poisson_pass();",
-                   "    const long long T1 = clock64();\n    light_service(true);\n    while (hg_top > 0) gamma_pass();\n    while (hp_top > 0) poisson_pass();\n"
-                   "    const long long T2 = clock64();\n"
-                   "    if (lane == 0 && (wave_id % 97) == 5) printf(\"K3HTRACE wave %lld total %lld feedloop %lld drain %lld | light %d starts %d walk passes %lld | gamma %d passes %lld | poisson %d passes %lld\\n\", (long long)wave_id, T2 - T0, T1 - T0, T2 - T1, np_l, np_w, TL, np_g, TG, np_p, TP);")],
+                  ("    auto walk_service = [&](bool drain) __attribute__((always_inline)) {\n        for (;;) {", "    auto walk_service = [&](bool drain) __attribute__((always_inline)) {\n        const long long tl0 = clock64();\n        for (;;) {"),
+                  ("            if (busy <= 32 && (drain ? hw_top > 0 : hw_top >= 32)) walk_take();\n            else if (drain ? busy > 0 : busy > 32) walk_pass();\n            else break;\n        }",
+                   "            if (busy <= 32 && (drain ? hw_top > 0 : hw_top >= 32)) { walk_take(); ++np_l; }\n            else if (drain ? busy > 0 : busy > 32) { walk_pass(); ++np_w; }\n            else break;\n        }\n        TL += clock64() - tl0;"),
+                  ("        hg_top += __popcll(mh);\n        while (hg_top >= 64) gamma_pass();\n        const bool redo", "        hg_top += __popcll(mh);\n        n_ent += __popcll(mh);\n        while (hg_top >= 64) gamma_pass();\n        const bool redo"),
+                  ("    // Phase 2: what a region lists behind", "    const long long T1 = clock64();\n    // Phase 2: what a region lists behind"),
+                  ("                const uint2 e = nx;\n", "                const uint2 e = nx;\n                ++n_chunks;\n"),
+                  ("    walk_service(true);\n    while (hg_top > 0) gamma_pass();\n    while (hp_top > 0) poisson_pass();",
+                   "    const long long T2 = clock64();\n    walk_service(true);\n    const long long T3 = clock64();\n    while (hg_top > 0) gamma_pass();\n    while (hp_top > 0) poisson_pass();\n"
+                   "    const long long T4 = clock64(); const long long W1 = wall_clock64();\n"
+                   "    if (lane == 0 && ((blockIdx.x * 4 + wv) % 61) == 5) printf(\"K3HTRACE wave %d wall %lld..%lld | ticks total %lld phase1 %lld phase2 %lld walkdrain %lld gpdrain %lld | entries %d chunks %d | walk %d takes %d passes %lld | gamma %d passes %lld | poisson %d passes %lld\\n\", (int)(blockIdx.x * 4 + wv), W0, W1, T4 - T0, T1 - T0, T2 - T1, T3 - T2, T4 - T3, n_ent, n_chunks, np_l, np_w, TL, np_g, TG, np_p, TP);")],
     # the library default of 10 Philox rounds instead of 7 (timing only: the model is not changed along)
     "philox10": [("constexpr int kCountRounds = 7;", "constexpr int kCountRounds = 10;")],
     # real variants (correct results): tuning constants
@@ -324,6 +325,43 @@ VARIANTS.update({
     "light32": [("constexpr float kLightTheta = 16.0f;", "constexpr float kLightTheta = 32.0f;"),
                 ("    if (!(__builtin_fmaxf(th_edge, bm1) <= 15.9f)) phi = 3.0e38f;", "    if (!(__builtin_fmaxf(th_edge, bm1) <= 31.9f)) phi = 3.0e38f;")],
 })
+
+
+# round 6: the unfinished walks of a strip travel to K3h with their state -- how many may be left when the strip's drain stops
+def _bail(n, slots):
+    return [("constexpr int kBail = 6; ", "constexpr int kBail = %d; " % n), ("constexpr int kBailSlots = 8; ", "constexpr int kBailSlots = %d; " % slots)]
+VARIANTS.update({"r6_bail3": _bail(3, 8), "r6_bail8": _bail(8, 8), "r6_bail12": _bail(12, 16), "r6_bail16": _bail(16, 16)})
+
+
+# round 6 (timing only: the walk's groups would have to move in the definition): stage 2 takes the terms k = 0..4, not 0..2
+VARIANTS["r6_s2_5terms"] = [
+    ("        const unsigned long long hit_m = K3_MASK(r2 < 0.0f);\n        const unsigned long long tail_m = K3_MASK(ps2 < 1.0f);",
+     "        const float ps3 = ps2 * PRNB_FMA(dd, 0.33333334f, qq);\n        const float r3 = r2 - ps3;\n        const float ps4 = ps3 * PRNB_FMA(dd, 0.25f, qq);\n        const float r4 = r3 - ps4;\n"
+     "        const unsigned long long hit_m = K3_MASK(r4 < 0.0f);\n        const unsigned long long tail_m = K3_MASK(ps4 < 1.0f);"),
+    ("        const uint32_t res = (uint32_t)((2 + ((int32_t)prnb::f2u(r0) >> 31)) + ((int32_t)prnb::f2u(r1) >> 31));",
+     "        const uint32_t res = (uint32_t)(((4 + ((int32_t)prnb::f2u(r0) >> 31)) + ((int32_t)prnb::f2u(r1) >> 31)) + (((int32_t)prnb::f2u(r2) >> 31) + ((int32_t)prnb::f2u(r3) >> 31)));"),
+    ("            e2.x = ps2 * PRNB_FMA(dd, 0.33333334f, qq);      // pmf at k = 3 (the 1/k table's 1/3)", "            e2.x = ps4 * PRNB_FMA(dd, 0.2f, qq);"),
+    ("            e2.w = r2;", "            e2.w = r4;"),
+]
+VARIANTS["r6_s2_4terms"] = [
+    ("        const unsigned long long hit_m = K3_MASK(r2 < 0.0f);\n        const unsigned long long tail_m = K3_MASK(ps2 < 1.0f);",
+     "        const float ps3 = ps2 * PRNB_FMA(dd, 0.33333334f, qq);\n        const float r3 = r2 - ps3;\n"
+     "        const unsigned long long hit_m = K3_MASK(r3 < 0.0f);\n        const unsigned long long tail_m = K3_MASK(ps3 < 1.0f);"),
+    ("        const uint32_t res = (uint32_t)((2 + ((int32_t)prnb::f2u(r0) >> 31)) + ((int32_t)prnb::f2u(r1) >> 31));",
+     "        const uint32_t res = (uint32_t)(((3 + ((int32_t)prnb::f2u(r0) >> 31)) + ((int32_t)prnb::f2u(r1) >> 31)) + ((int32_t)prnb::f2u(r2) >> 31));"),
+    ("            e2.x = ps2 * PRNB_FMA(dd, 0.33333334f, qq);      // pmf at k = 3 (the 1/k table's 1/3)", "            e2.x = ps3 * PRNB_FMA(dd, 0.25f, qq);"),
+    ("            e2.w = r2;", "            e2.w = r3;"),
+]
+VARIANTS["r6_s2_7terms"] = [
+    ("        const unsigned long long hit_m = K3_MASK(r2 < 0.0f);\n        const unsigned long long tail_m = K3_MASK(ps2 < 1.0f);",
+     "        const float ps3 = ps2 * PRNB_FMA(dd, 0.33333334f, qq);\n        const float r3 = r2 - ps3;\n        const float ps4 = ps3 * PRNB_FMA(dd, 0.25f, qq);\n        const float r4 = r3 - ps4;\n"
+     "        const float ps5 = ps4 * PRNB_FMA(dd, 0.2f, qq);\n        const float r5 = r4 - ps5;\n        const float ps6 = ps5 * PRNB_FMA(dd, 0.16666667f, qq);\n        const float r6 = r5 - ps6;\n"
+     "        const unsigned long long hit_m = K3_MASK(r6 < 0.0f);\n        const unsigned long long tail_m = K3_MASK(ps6 < 1.0f);"),
+    ("        const uint32_t res = (uint32_t)((2 + ((int32_t)prnb::f2u(r0) >> 31)) + ((int32_t)prnb::f2u(r1) >> 31));",
+     "        const uint32_t res = (uint32_t)((((6 + ((int32_t)prnb::f2u(r0) >> 31)) + ((int32_t)prnb::f2u(r1) >> 31)) + (((int32_t)prnb::f2u(r2) >> 31) + ((int32_t)prnb::f2u(r3) >> 31))) + (((int32_t)prnb::f2u(r4) >> 31) + ((int32_t)prnb::f2u(r5) >> 31)));"),
+    ("            e2.x = ps2 * PRNB_FMA(dd, 0.33333334f, qq);      // pmf at k = 3 (the 1/k table's 1/3)", "            e2.x = ps6 * PRNB_FMA(dd, 0.14285715f, qq);"),
+    ("            e2.w = r2;", "            e2.w = r6;"),
+]
 
 
 def build(name):

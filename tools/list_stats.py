@@ -24,10 +24,10 @@ def main():
     cells, genes, total, over = ctx.last_list(cap=1 << 25)
     path, count = nb_model.sample_selected(means.cpu().numpy(), rows, sc, work.alpha, work.beta, 424242, cells, genes)
     heavy = path == 2
-    big = (path == 1) & (count > 254)
+    big = (path == 1) & (count > 248)
     rest = (path == 1) & ~big
     samples = N * work.tree.G
-    print("%s %d x %d: %d listed (%.3f %% of the samples, overflowed %s): gamma-Poisson %d, walks past k = 254: %d, "
+    print("%s %d x %d: %d listed (%.3f %% of the samples, overflowed %s): gamma-Poisson %d, walks past k = 248: %d, "
           "unfinished at the end of their strip %d (mean count %.1f, max %d); mean count of the matrix %.2f"
           % (cfg, N, work.tree.G, total, 100.0 * total / samples, over, heavy.sum(), big.sum(), rest.sum(),
              count[rest].mean() if rest.any() else 0, count[rest].max() if rest.any() else 0,
