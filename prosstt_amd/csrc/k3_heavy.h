@@ -24,6 +24,7 @@ namespace k3 {
 
 constexpr int kHeavyBlock = 256;
 constexpr int kHCap = 128;     // < 64 left over + 64 pushed (new entries, or re-pushed ones after 64 were popped)
+constexpr uint32_t kWalkerBlocks = 6u;   // of every 16 blocks, the ones that walk (2: 81 / 93 us at C3 / T32, 3: 57 / 71, 4: 50 / 68, 5: 42 / 68, 6: 41 / 68, 8: 38 / 71)
 constexpr int kWCap = 96;      // walks waiting for a lane: < 32 left over + 64 pushed by one step of the list traversal (five blocks per CU: 30 496 B)
 
 struct HGEntry { int32_t n, g, attempt; float m; };
@@ -39,11 +40,12 @@ struct HeavyLds {
     uint16_t wk[kWCap];
 };
 
-// heavy: what the streaming kernel's waves listed (k3::HeavyList; `regions` of them, laid out by
-// its block -> (gene tile, strip group) map).  A region that was too small (count above cap) is redone
-// here sample by sample instead: slow, but any parameter set stays correct.
+// heavy: what the streaming kernel's waves listed (k3::HeavyList): per region (of the streaming kernel's block -> (gene
+// tile, strip group) map) the first kDense entries and the walk states, kSegs dense segments of {cell, gene, m} with what
+// the regions of a hot gene tile list beyond that (dealt out to the waves 64 at a time), and the regions whose list or
+// segment was too small: those are redone here sample by sample instead -- slow, but any parameter set stays correct.
 __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
-    HeavyList heavy, uint32_t regions, int32_t strips, int32_t strip_cells,
+    const HeavyList* __restrict__ heavy_ptr, uint32_t regions, int32_t strips, int32_t strip_cells,
     const float* __restrict__ means, int64_t rows,
     int32_t G, const int32_t* __restrict__ row_of_cell, const float* __restrict__ scal,
     const float* __restrict__ ga, const float* __restrict__ gbm1, int64_t N, uint32_t k0, uint32_t k1,
@@ -53,10 +55,47 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
     __shared__ __attribute__((aligned(16))) float inv_k_store[prnb::kTabShift + prnb::kKTab];       // 1/k, k < kKTab (a walk ends at kWalkEnd)
     float* const inv_k = inv_k_store + prnb::kTabShift;                      // &inv_k[6 + 4 j] is 16-byte aligned
     __shared__ HeavyLds lds_all[kHeavyBlock / 64];
+    const HeavyList heavy = *heavy_ptr;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     HeavyLds& L = lds_all[wv];
     for (int k = tid - prnb::kTabShift; k < prnb::kKTab; k += kHeavyBlock) inv_k[k] = k > 0 ? 1.0f / (float)k : 0.0f;
+    // The segments' fill, in chunks of 64: the exclusive prefix over the kSegs segments
+    __shared__ uint32_t seg_n[kSegs], seg_first[kSegs + 1];
+    if (wv == 0) {
+        uint32_t n = heavy.seg_cnt[lane];
+        n = n < heavy.ent_cap ? n : heavy.ent_cap;
+        uint32_t x = (n + 63u) >> 6;                        // chunks of this segment
+        const uint32_t mine = x;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)x, d, 64);
+            if (lane >= d) x += t;
+        }
+        seg_n[lane] = n;
+        seg_first[lane] = x - mine;
+        if (lane == 63) seg_first[kSegs] = x;
+    }
     __syncthreads();
+    const int32_t groups = (strips + 3) / 4;
+    const uint32_t waves = gridDim.x * (kHeavyBlock / 64);
+    // chunk -> (segment, first entry): the last segment whose first chunk is not behind it (wave-uniform)
+    auto locate = [&](uint32_t chunk, uint32_t& seg, uint32_t& first) __attribute__((always_inline)) {
+        uint32_t lo = 0u;
+#pragma unroll
+        for (uint32_t step = kSegs / 2; step != 0u; step >>= 1)
+            if (seg_first[lo + step] <= chunk) lo += step;
+        seg = lo;
+        first = (chunk - seg_first[lo]) << 6;
+    };
+    // blk / groups for blk < 2^32: the estimate by the rounded-down reciprocal is the quotient or one below it (an integer
+    // division is ~30 instructions on this chip, and the kernel is bound by what it issues)
+    const uint32_t groups_rcp = groups > 1 ? (uint32_t)(0x100000000ull / (uint64_t)(uint32_t)groups) : 0u;
+    auto tile_of = [&](uint32_t blk) __attribute__((always_inline)) -> int32_t {
+        if (groups <= 1) return (int32_t)blk;
+        uint32_t q = __umulhi(blk, groups_rcp);
+        q += (blk - q * (uint32_t)groups >= (uint32_t)groups) ? 1u : 0u;
+        return (int32_t)q;
+    };
 
     int hg_top = 0, hp_top = 0, hw_top = 0;      // wave-uniform
 
@@ -347,116 +386,146 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
     };
 
     // ---- the list -------------------------------------------------------------------------------------
-    // list entries of one region (its cells start at n0, its genes at tile_g * 256), one per lane: an entry with its
-    // mean is of the gamma-Poisson class (the streaming kernel decided that), one without is redone from its start
-    auto take_entries = [&](bool has, uint32_t px, uint32_t py, int64_t n0, int32_t tile_g) __attribute__((always_inline)) {
-        const int32_t n = (int32_t)(n0 + (px >> 8)), g = tile_g * kTileG + (int32_t)(px & 255u);
-        const float m = __uint_as_float(py);
-        const bool heavy_c = has && m >= 0.0f;
-        const unsigned long long mh = __builtin_amdgcn_ballot_w64(heavy_c);
-        if (heavy_c) {
-            HGEntry e;
-            e.n = n; e.g = g; e.attempt = 0; e.m = m;
-            L.hg[hg_top + lane_rank(mh)] = e;
+    const uint32_t wave_id = blockIdx.x * (kHeavyBlock / 64) + (uint32_t)wv;
+    // Six blocks in sixteen (kWalkerBlocks) only walk, the others only draw: the walks differ in length by two orders of magnitude (the
+    // longest of a launch runs forty passes of eight terms, one after the other), so they start at once, on waves that
+    // have nothing else to do, and a walker with a few hundred walks keeps its lanes busy.  (With every wave walking the
+    // fifty walks of its own regions, a wave ran as many passes as its longest walk has groups of eight terms, mostly for
+    // a handful of lanes.)
+    const bool walker = (blockIdx.x & 15u) < kWalkerBlocks;
+    const uint32_t walker_blocks = (gridDim.x >> 4) * kWalkerBlocks + ((gridDim.x & 15u) < kWalkerBlocks ? (gridDim.x & 15u) : kWalkerBlocks);
+    const uint32_t n_redo = heavy.seg_cnt[kSegs + 1] < (uint32_t)kRedoCap ? heavy.seg_cnt[kSegs + 1] : (uint32_t)kRedoCap;
+    auto push_entries = [&](bool has, int32_t n, int32_t g, float m) __attribute__((always_inline)) {
+        const unsigned long long mh = __builtin_amdgcn_ballot_w64(has);
+        if (has) {
+            HGEntry h;
+            h.n = n; h.g = g; h.attempt = 0; h.m = m;
+            L.hg[hg_top + lane_rank(mh)] = h;
         }
         hg_top += __popcll(mh);
         while (hg_top >= 64) gamma_pass();
-        const bool redo = has && !(m >= 0.0f);
-        if (__builtin_amdgcn_ballot_w64(redo) != 0ull) from_start(redo, n, g);
     };
-    const int32_t groups = (strips + 3) / 4;
-    const uint32_t wave_id = blockIdx.x * (kHeavyBlock / 64) + (uint32_t)wv, waves = gridDim.x * (kHeavyBlock / 64);
-    // Phase 1: four regions per wave and step, 16 lanes each -- a region's count, its first kDense entries and the walk
-    // states of its strip, read side by side from three compact arrays (one level of loads per step).  A wave's regions
-    // lie `waves` apart: the listed samples cluster in a few gene tiles (regions are laid out tile by tile).
-    {
-        const int sub = lane >> 4, sl = lane & 15;
-        const uint4* const dense4 = reinterpret_cast<const uint4*>(heavy.dense);      // two entries per lane and load
-        for (uint64_t r0 = wave_id; r0 < (uint64_t)regions; r0 += 4ull * waves) {
-            const int64_t r = (int64_t)r0 + (int64_t)sub * waves;
-            const bool in = r < (int64_t)regions;
-            const uint32_t cnt_word = in ? heavy.count[r] : 0u;
-            uint4 d4 = make_uint4(0u, 0u, 0u, 0u);
-            f32x4_t bst = {0.0f, 0.0f, 0.0f, 0.0f};
-            uint32_t bid = 0u;
-            if (in) {
-                d4 = dense4[(uint64_t)r * (kDense / 2) + (uint32_t)sl];
-                if (sl < kBailSlots) {
-                    bst = heavy.bail_st[(uint64_t)r * kBailSlots + (uint32_t)sl];
-                    bid = heavy.bail_id[(uint64_t)r * kBailSlots + (uint32_t)sl];
+    if (!walker) {
+        const uint32_t blk_rank = blockIdx.x - ((blockIdx.x >> 4) * kWalkerBlocks + ((blockIdx.x & 15u) < kWalkerBlocks ? (blockIdx.x & 15u) : kWalkerBlocks));
+        const uint32_t rank = blk_rank * (kHeavyBlock / 64) + (uint32_t)wv;       // among the drawing waves
+        const uint32_t drawers = (gridDim.x - walker_blocks) * (kHeavyBlock / 64);
+        // The listed samples (every one of the gamma-Poisson class: the streaming kernel decided that).  First the regions'
+        // first kDense entries: four regions per wave and step, 16 lanes each, two entries per lane; a step's loads go out
+        // one step ahead of their use.  A wave's regions lie `drawers` apart: the listed samples cluster in a few gene tiles
+        // (regions are laid out tile by tile).
+        {
+            const int sub = lane >> 4, sl = lane & 15;
+            const uint4* const dense4 = reinterpret_cast<const uint4*>(heavy.dense);
+            struct Step { uint32_t cnt; uint4 d4; };
+            auto load_step = [&](uint64_t r0) __attribute__((always_inline)) -> Step {
+                Step S;
+                S.cnt = 0u; S.d4 = make_uint4(0u, 0u, 0u, 0u);
+                const uint64_t r = r0 + (uint64_t)sub * drawers;
+                if (r < (uint64_t)regions) {
+                    S.cnt = heavy.count[r] & 0xffffu;
+                    S.d4 = dense4[r * (kDense / 2) + (uint32_t)sl];
+                }
+                return S;
+            };
+            Step nxt = load_step(rank);
+            for (uint64_t r0 = rank; r0 < (uint64_t)regions; r0 += 4ull * drawers) {
+                const uint32_t r = (uint32_t)(r0 + (uint64_t)sub * drawers);
+                const Step cur = nxt;
+                nxt = load_step(r0 + 4ull * drawers);
+                const uint32_t cnt = cur.cnt > heavy.cap ? 0u : cur.cnt;       // (above the cap: the region is redone as a whole)
+                const int32_t blk = (int32_t)(r >> 2);
+                const int32_t tile_g = tile_of((uint32_t)blk);
+                const int32_t n0 = ((blk - tile_g * groups) * 4 + (int32_t)(r & 3u)) * strip_cells;
+                push_entries(2u * (uint32_t)sl < cnt, n0 + (int32_t)(cur.d4.x >> 8), tile_g * kTileG + (int32_t)(cur.d4.x & 255u), __uint_as_float(cur.d4.y));
+                push_entries(2u * (uint32_t)sl + 1u < cnt, n0 + (int32_t)(cur.d4.z >> 8), tile_g * kTileG + (int32_t)(cur.d4.z & 255u), __uint_as_float(cur.d4.w));
+            }
+        }
+        // ... then what the regions of a hot gene tile listed beyond that: chunk c of the segments goes to drawing wave c mod
+        // (drawing waves) -- 64 entries per coalesced load, the next chunk's entries requested before this chunk's are looked at.
+        {
+            const uint32_t chunks = seg_first[kSegs];
+            HeavyEntry nx;
+            nx.n = 0; nx.g = 0; nx.m = 0.0f; nx.pad = 0u;
+            bool nx_has = false;
+            auto request = [&](uint32_t chunk) __attribute__((always_inline)) {
+                uint32_t sg, first;
+                locate(chunk, sg, first);
+                nx_has = first + (uint32_t)lane < seg_n[sg];
+                if (nx_has) nx = heavy.ent[(uint64_t)sg * heavy.ent_cap + first + (uint32_t)lane];
+            };
+            if (rank < chunks) request(rank);
+            for (uint32_t chunk = rank; chunk < chunks; chunk += drawers) {
+                const HeavyEntry e = nx;
+                const bool has = nx_has;
+                if (chunk + drawers < chunks) request(chunk + drawers);
+                push_entries(has, e.n, e.g, e.m);
+            }
+        }
+    } else {
+        // The walks: first the ones to redo from their start (a strip kept more than kLongSlots walks past term 252: rare),
+        // then the regions' walk states: a walker takes a run of neighbouring regions, 16 per step, four lanes each.
+        const uint32_t wrank = ((blockIdx.x >> 4) * kWalkerBlocks + (blockIdx.x & 15u)) * (kHeavyBlock / 64) + (uint32_t)wv;
+        const uint32_t walkers = walker_blocks * (kHeavyBlock / 64);
+        for (uint32_t i = wrank * 64u; i < n_redo; i += walkers * 64u) {
+            const bool has = i + (uint32_t)lane < n_redo;
+            const int2 ng = has ? heavy.redo[i + (uint32_t)lane] : make_int2(0, 0);
+            from_start(has, ng.x, ng.y);
+        }
+        const uint32_t per_walker = ((regions + walkers - 1u) / walkers + 15u) & ~15u;
+        const uint32_t r_end = (wrank + 1u) * per_walker < regions ? (wrank + 1u) * per_walker : regions;
+        const uint32_t rl = (uint32_t)lane >> 2, s0 = (uint32_t)lane & 3u;
+        static_assert(kWalkSlots <= 12, "three slots per lane");
+        struct WStep { uint32_t n_walks; f32x4_t st[3]; uint32_t id[3]; };
+        auto load_wstep = [&](uint32_t rb) __attribute__((always_inline)) -> WStep {
+            WStep S;
+            S.n_walks = 0u;
+            const uint32_t r = rb + rl;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { S.st[j] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f}; S.id[j] = 0u; }
+            if (r < r_end) {
+                S.n_walks = heavy.count[r] >> 16;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const uint32_t slot = s0 + 4u * (uint32_t)j;
+                    if (slot < (uint32_t)kWalkSlots) {
+                        S.st[j] = heavy.wst[(uint64_t)r * kWalkSlots + slot];
+                        S.id[j] = heavy.wid[(uint64_t)r * kWalkSlots + slot];
+                    }
                 }
             }
-            const uint32_t cnt_all = cnt_word & 0xffffu, n_bail = cnt_word >> 16;
+            return S;
+        };
+        WStep wn = load_wstep(wrank * per_walker);
+        for (uint32_t rb = wrank * per_walker; rb < r_end; rb += 16u) {
+            const WStep cur = wn;
+            wn = load_wstep(rb + 16u);
+            const uint32_t r = rb + rl;
             const int32_t blk = (int32_t)(r >> 2);
-            const int32_t tile_g = blk / groups;
-            const int64_t n0 = (int64_t)((blk - tile_g * groups) * 4 + (int32_t)(r & 3)) * strip_cells;
-            const bool over = cnt_all > heavy.cap;       // the region was too small: redone as a whole below
-            const uint32_t cnt = over ? 0u : cnt_all;
-            // the unfinished walks of the region's strip: continued from their state
-            walk_push((uint32_t)sl < n_bail, (int32_t)(n0 + ((bid & 0xffffu) >> 8)), tile_g * kTileG + (int32_t)(bid & 255u),
-                      (int32_t)(bid >> 16) - 3, bst);
-            take_entries(2u * (uint32_t)sl < cnt, d4.x, d4.y, n0, tile_g);
-            take_entries(2u * (uint32_t)sl + 1u < cnt, d4.z, d4.w, n0, tile_g);
-            // every sample of an overflowed region (strip_cells x 256 of the matrix) goes through the classification
-            // here, 64 at a time: slow (the streaming kernel's own results are recomputed), but any parameter set
-            // stays correct and only the regions that overflowed pay
-            unsigned long long over_m = __builtin_amdgcn_ballot_w64(over && sl == 0);
-            while (over_m != 0ull) {
-                const int src = (int)__builtin_ctzll(over_m);
-                over_m &= over_m - 1ull;
-                const int32_t tg = __builtin_amdgcn_readlane(tile_g, src);
-                const int64_t nb = ((int64_t)__builtin_amdgcn_readlane((int32_t)(n0 >> 32), src) << 32) |
-                                   (uint32_t)__builtin_amdgcn_readlane((int32_t)n0, src);
-                for (int32_t c = 0; c < strip_cells && nb + c < N; ++c)
-                    for (int j = 0; j < 4; ++j) {
-                        const int32_t g = tg * kTileG + j * 64 + lane;
-                        from_start(g < G, (int32_t)(nb + c), g);
-                    }
+            const int32_t tile_g = tile_of((uint32_t)blk);
+            const int32_t n0 = ((blk - tile_g * groups) * 4 + (int32_t)(r & 3u)) * strip_cells;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const uint32_t slot = s0 + 4u * (uint32_t)j;
+                walk_push(slot < cur.n_walks, n0 + (int32_t)((cur.id[j] & 0xffffu) >> 8), tile_g * kTileG + (int32_t)(cur.id[j] & 255u),
+                          (int32_t)(cur.id[j] >> 16) - 3, cur.st[j]);
             }
         }
     }
-    // Phase 2: what a region lists behind its first kDense entries, in chunks of 64 -- one entry per lane, one coalesced
-    // load per chunk -- and NOT by the region's own wave: chunk c of region r belongs to wave (r + (c + 1) * shift) mod
-    // waves.  A hot gene tile is a run of `4 * groups` neighbouring regions with hundreds of entries each; its chunks
-    // spread evenly over all waves this way (left to their own waves, the waves that own a hot region or two ran three
-    // times as long as the median wave, each through a chain of dependent loads).  A wave finds its chunks by reading the
-    // counts of the regions that can hand it one: 16 chunk numbers x the regions `waves` apart.
+    // Regions whose list or segment was too small: every sample of the region (strip_cells x 256 of the matrix) goes
+    // through the classification here, 64 at a time: slow (the streaming kernel's own results are recomputed), but any
+    // parameter set stays correct and only those regions pay
     {
-        constexpr uint32_t kChunk = 64u, kChunks = 16u;      // cap <= kDense + kChunks * kChunk
-        const uint32_t shift = ((4u * (uint32_t)groups) % waves) | 1u;
-        const uint32_t per_chunk = (regions + waves - 1u) / waves;         // regions r = own + j * waves
-        const uint32_t pairs = kChunks * per_chunk;
-        for (uint32_t p0 = 0u; p0 < pairs; p0 += 64u) {
-            const uint32_t p = p0 + (uint32_t)lane;
-            const uint32_t c = p & (kChunks - 1u), j = p / kChunks;
-            const uint32_t own = (wave_id + waves - (((c + 1u) * shift) % waves)) % waves;
-            const uint64_t r = (uint64_t)own + (uint64_t)j * waves;
-            const uint32_t cw = (p < pairs && r < (uint64_t)regions) ? heavy.count[r] & 0xffffu : 0u;
-            const bool work = cw <= heavy.cap && (uint32_t)kDense + c * kChunk < cw;
-            unsigned long long todo = __builtin_amdgcn_ballot_w64(work);
-            // the next chunk's entries are requested before this chunk's are looked at
-            uint2 nx = make_uint2(0u, 0u);
-            auto request = [&](int src) __attribute__((always_inline)) {
-                const uint32_t rr = (uint32_t)__builtin_amdgcn_readlane((int32_t)(uint32_t)r, src);
-                const uint32_t cc = (uint32_t)__builtin_amdgcn_readlane((int32_t)c, src);
-                const uint32_t cn = (uint32_t)__builtin_amdgcn_readlane((int32_t)cw, src);
-                const uint32_t slot = (uint32_t)kDense + cc * kChunk + (uint32_t)lane;
-                nx = slot < cn ? heavy.list[(uint64_t)rr * heavy.cap + slot] : make_uint2(0u, 0u);
-            };
-            if (todo != 0ull) request((int)__builtin_ctzll(todo));
-            while (todo != 0ull) {
-                const int src = (int)__builtin_ctzll(todo);
-                todo &= todo - 1ull;
-                const uint2 e = nx;
-                const uint32_t rr = (uint32_t)__builtin_amdgcn_readlane((int32_t)(uint32_t)r, src);
-                const uint32_t cc = (uint32_t)__builtin_amdgcn_readlane((int32_t)c, src);
-                const uint32_t cn = (uint32_t)__builtin_amdgcn_readlane((int32_t)cw, src);
-                if (todo != 0ull) request((int)__builtin_ctzll(todo));
-                const int32_t blk = (int32_t)(rr >> 2);
-                const int32_t tile_g = blk / groups;
-                const int64_t n0 = (int64_t)((blk - tile_g * groups) * 4 + (int32_t)(rr & 3u)) * strip_cells;
-                take_entries((uint32_t)kDense + cc * kChunk + (uint32_t)lane < cn, e.x, e.y, n0, tile_g);
-            }
+        const uint32_t n_ovf = heavy.seg_cnt[kSegs];
+        for (uint32_t i = wave_id; i < n_ovf; i += waves) {
+            const uint32_t r = heavy.ovf_regions[i];
+            const int32_t blk = (int32_t)(r >> 2);
+            const int32_t tg = tile_of((uint32_t)blk);
+            const int64_t nb = (int64_t)((blk - tg * groups) * 4 + (int32_t)(r & 3u)) * strip_cells;
+            for (int32_t c = 0; c < strip_cells && nb + c < N; ++c)
+                for (int j = 0; j < 4; ++j) {
+                    const int32_t g = tg * kTileG + j * 64 + lane;
+                    from_start(g < G, (int32_t)(nb + c), g);
+                }
         }
     }
     walk_service(true);

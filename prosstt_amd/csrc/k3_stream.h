@@ -59,10 +59,12 @@ constexpr int kS2Run = 40;         // stage 3 runs while S2 holds at least this 
 static_assert(kS2Cap >= kS2Run - 1 + 64 && kS1Cap >= 63 + 128, "a stack must take one more round of pushes");
 constexpr int kRing = 8;           // rows of the strip kept in LDS (8 bits per count) before they are stored; a power of 2
 constexpr int kBail = 6;           // walks handed to K3h WITH THEIR STATE when a strip has nothing else to do (see the drain)
-constexpr int kBailSlots = 8;      // room for them per wave (kBail <= kBailSlots <= 16)
-static_assert(kBail <= kBailSlots, "a wave's unfinished walks must fit its slots");
+
 constexpr int kLateCap = 64;       // results that missed their row wait here for one burst of stores (a pass delivers at most 64)
-constexpr int kRingMaxK3 = 248;    // a walk whose group k3-3..k3 with k3 = 248 ends undecided goes to K3h: counts fit the ring's 8 bits (k3 = 8, 16, ...)
+constexpr int kRingMaxK3 = 248;    // the last pass of a walk in this kernel is k3 = 248 (terms 245 .. 252: counts fit the ring's 8 bits); a walk still
+                                   // undecided then is redone by K3h
+constexpr int kLongSlots = 4;      // walks past term 252 a strip can keep for the hand-over (seventy per 10^9 samples: a fifth one is listed to be redone)
+constexpr int kListTail = 16;      // uint2 words behind a region's staging list: kLongSlots states of 3 words ({term, d}, {q, remainder}, {pos | k3 << 16, -})
 constexpr int kInvTab = 272;       // 1/k for k < 272: the reciprocals a pass at k3 <= 254 reads ahead (k3 + 6 .. k3 + 13)
 
 // What stage 1 needs to know about a cell, packed by the preparation kernel so that one scalar load
@@ -116,26 +118,39 @@ struct WaveLds {
     uint32_t late[kLateCap];       // (pos << 16) | count of results whose row has left the ring already
 };
 
-// The list of samples left to K3h: wave w of block b owns region r = 4*b + w, entries
-// list[r * cap .. + min(count[r] & 0xffff, cap)) = {pos (cell-in-strip << 8 | gene-in-tile), the sample's scaled mean m}
-// -- m < 0: "redo this sample from its start" (a walk past k = 254: the stream kernel no longer has its mean); a region
-// that was too small (more than one sample in 16 listed) is redone by K3h sample by sample, and overflow[0] != 0 says
-// that there was one.  The walks a wave had not finished when its strip ended travel WITH THEIR STATE: count[r] >> 16
-// of them in bail_st[r * kBailSlots ..] = {the next term, d, q, the remainder} and bail_id[..] = pos | k3 << 16 (the next
-// term is k = k3 - 3), which K3h continues instead of redoing them from k = 0 (until round 5: 2.8e5 walks of mean
-// length 64-75 per C3 launch).
+// The samples left to K3h.  Wave w of block b owns region r = 4*b + w of every per-region array below:
+//   dense[r][kDense]     the first kDense samples it lists, {pos (cell-in-strip << 8 | gene-in-tile), the sample's scaled mean m};
+//   list[r][cap + tail]  the ones behind them, staged: when the strip is done a wave that listed more than kDense reserves room
+//                        in one of kSegs dense segments (ONE atomic add, by the few waves of a hot gene tile only) and copies
+//                        them there as {cell, gene, m}: K3h deals the segments out 64 entries at a time, so the hundreds of
+//                        entries of a hot region spread over all its waves (K3h used to walk them region by region: the waves
+//                        that owned a hot region or two ran three times as long as the median wave);
+//   wst / wid[r][kWalkSlots]  the walks the wave had not finished when its strip ended, WITH THEIR STATE: {the next term, d, q,
+//                        the remainder} and pos | k3 << 16 (the next term is k = k3 - 3), and behind them the walks that ran
+//                        past term 252 during the strip (kept in the tail of `list` until then): K3h continues them instead of
+//                        redoing them from k = 0 (until round 5: 2.8e5 walks of mean length 64-75 per C3 launch);
+//   count[r]             listed | walks << 16.
+// A region whose list was too small (more than one sample in 16 listed), or whose segment is full, is put on ovf_regions and
+// redone by K3h sample by sample; overflow[0] != 0 says that there was one.
 static_assert(offsetof(WaveLds, s1) == offsetof(WaveLds, s1_null) + sizeof(S1Entry), "s1[-1] must be the null entry");
 
-// A region's first kDense entries lie in `dense` (regions x kDense entries, contiguous: 16 MB at C3), only the ones behind
-// them in the region's own kilobytes of `list`: K3h reads a region's count, its dense entries and its walk states side by
-// side from three compact arrays (the list spreads a region over its own page: a TLB miss per region, 12 us of K3h).
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr int kSegs = 64;
 constexpr int kDense = 32;
+constexpr int kWalkSlots = kBail + kLongSlots;
+struct HeavyEntry { int32_t n, g; float m; uint32_t pad; };
 struct HeavyList {
-    uint32_t* count; uint2* list; uint32_t* overflow; uint32_t cap; f32x4_t* bail_st; uint32_t* bail_id;
+    uint2* list; uint32_t cap;
     uint2* dense;
+    uint32_t* count;
+    f32x4_t* wst; uint32_t* wid;
+    uint32_t* overflow;
+    uint32_t* seg_cnt;               // [0, kSegs): entries per segment; [kSegs]: overflowed regions; [kSegs + 1]: walks to redo
+    HeavyEntry* ent; uint32_t ent_cap;          // segment s: ent[s * ent_cap ..]
+    uint32_t* ovf_regions;
+    int2* redo;                      // {cell, gene} of the walks to redo from their start (kRedoCap)
 };
-constexpr float kRedoMark = -1.0f;   // list entry: no mean, redo from the start
+constexpr int kRedoCap = 65536;
 
 __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
@@ -149,13 +164,36 @@ __device__ __forceinline__ int lane_rank(unsigned long long mask)
 // VEC: 16-byte mean loads and row stores (G, ld multiples of 4, both bases aligned).  BIG: the two settings that pay on a
 // problem of full-length strips whose output does not fit the last-level cache and cost 6 % each on a small one (C2:
 // 8-cell strips, 100 MB of counts) -- the raised issue priority of stages 2 and 3, and system scope on the row stores.
+#define K3_GLOBAL(T) __attribute__((address_space(1))) T*
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef int32_t i32x2_t __attribute__((ext_vector_type(2)));
+static_assert(sizeof(HeavyEntry) == sizeof(u32x4_t) && sizeof(int2) == sizeof(i32x2_t), "stored as plain vectors");
 template <bool VEC, bool BIG>
 __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
     const float* __restrict__ means, int32_t G, const CellInfo* __restrict__ cellinfo,
     const float* __restrict__ ga, const float* __restrict__ gbm1, const float* __restrict__ gphi,
     int64_t N, uint32_t k0, uint32_t k1, int32_t* __restrict__ out, int64_t ld, int32_t strips,
-    int32_t strip_cells, HeavyList heavy)
+    int32_t strip_cells, uint2* __restrict__ heavy_list, uint32_t heavy_cap, uint2* __restrict__ heavy_dense,
+    const HeavyList* __restrict__ heavy_ptr)
 {
+    // (K3h's lists are described by a record in device memory, read where it is needed -- in two rare branches and at the
+    // end of the strip --, not by kernel arguments: twenty scalar registers held across the strip loop for nothing spill)
+    // (the pointers of the record are global memory: said so, or the compiler emits flat_* operations, which are not
+    // ordered with this wave's global_* / buffer_* operations -- see flush_late)
+    struct HeavyGlobal {
+        K3_GLOBAL(uint32_t) count; K3_GLOBAL(f32x4_t) wst; K3_GLOBAL(uint32_t) wid; K3_GLOBAL(uint32_t) overflow;
+        K3_GLOBAL(uint32_t) seg_cnt; K3_GLOBAL(u32x4_t) ent; uint32_t ent_cap; K3_GLOBAL(uint32_t) ovf_regions; K3_GLOBAL(i32x2_t) redo;
+    };
+    auto heavy_late = [&]() -> HeavyGlobal {
+        const HeavyList* p = heavy_ptr;
+        asm volatile("" : "+s"(p));
+        const __attribute__((address_space(4))) HeavyList* h = (const __attribute__((address_space(4))) HeavyList*)p;      // constant memory: scalar loads
+        HeavyGlobal g;
+        g.count = (K3_GLOBAL(uint32_t))h->count; g.wst = (K3_GLOBAL(f32x4_t))h->wst; g.wid = (K3_GLOBAL(uint32_t))h->wid;
+        g.overflow = (K3_GLOBAL(uint32_t))h->overflow; g.seg_cnt = (K3_GLOBAL(uint32_t))h->seg_cnt; g.ent = (K3_GLOBAL(u32x4_t))h->ent;
+        g.ent_cap = h->ent_cap; g.ovf_regions = (K3_GLOBAL(uint32_t))h->ovf_regions; g.redo = (K3_GLOBAL(i32x2_t))h->redo;
+        return g;
+    };
     // LDS of a block: 30 304 B.  gfx950 hands it out in 1 280-byte granules, so the five blocks per CU that the kernel's
     // speed rests on (the fifth: -11 %) fit as long as a block stays at or under 32 000 B (measured: 32 352 B gives four).
     // 1/k for k = -2 .. kInvTab-1: 0 below k = 1 (never used below 1: an idle stage-3 lane rests at k3 = 8); a pass reads
@@ -184,7 +222,7 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
     const int64_t n0 = (int64_t)strip * strip_cells;
     const uint32_t region = blockIdx.x * 4u + (uint32_t)wv;
     if (strip >= strips || n0 >= N) {                // whole wave leaves together (no barrier below)
-        if (lane == 0) heavy.count[region] = 0u;
+        if (lane == 0) heavy_late().count[region] = 0u;
         return;
     }
     const int cells = (int)((N - n0 < strip_cells) ? (N - n0) : strip_cells);
@@ -206,7 +244,7 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
     int s2_top = 0;                                  // wave-uniform
     constexpr uint32_t kNoHeavy = 0xffffffffu;
     uint32_t hpend = kNoHeavy;                       // pos of the sample this lane holds for the next append to K3h's list
-    float hpend_m = 0.0f;                            // ... and its scaled mean (kRedoMark: a walk past k = 254)
+    float hpend_m = 0.0f;                            // ... and its scaled mean
     // stage-3 lane state: st = {the next term (k = k3 - 3), d = mp - q, q, what is left of wf}; pos; k3 = the first of the
     // pass's two groups ends at k3 (6, 14, 22, ...).  WHICH lanes walk is wave-level state on the scalar unit (idle_s: bit = the lane
     // holds no walk): a pass takes every mask it forms AND NOT idle_s, so an idle lane may compute on whatever its
@@ -284,14 +322,16 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
     const uint32_t late_lds = (uint32_t)(uintptr_t)&L.late[0];
     // write the samples the lanes hold for K3h to this wave's region of the list (about ten entries
     // each time on the headline workload: the first lane to meet its second sample triggers it)
-    uint2* const my_list = heavy.list + (uint64_t)region * heavy.cap;
+    uint2* const my_list = heavy_list + (uint64_t)region * (heavy_cap + (uint32_t)kListTail);
+    uint2* const my_long = my_list + heavy_cap;      // (global memory, not LDS: the block is at its LDS budget, and this is touched seventy times per 10^9 samples)
+    int n_long = 0;                                   // walks kept behind the staging list (wave-uniform; -1: one found every list full)
     uint32_t h_cnt = 0u;                              // wave-uniform
     auto flush_heavy = [&]() {
         const unsigned long long mp_ = K3_MASK(hpend != kNoHeavy);
         if (hpend != kNoHeavy) {
             const uint32_t slot = h_cnt + (uint32_t)lane_rank(mp_);
-            if (slot < heavy.cap) {
-                uint2* const dst = slot < (uint32_t)kDense ? heavy.dense + ((uint64_t)region * kDense + slot) : my_list + slot;
+            if (slot < heavy_cap) {
+                uint2* const dst = slot < (uint32_t)kDense ? heavy_dense + ((uint64_t)region * kDense + slot) : my_list + slot;
                 *dst = make_uint2(hpend & 0xffffu, __float_as_uint(hpend_m));
             }
         }
@@ -378,23 +418,49 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
         const float r8 = r7 - ps7;
         const unsigned long long hit_a = K3_MASK(r4 < 0.0f), tail_a = K3_MASK(ps3 < 1.0f);
         const unsigned long long hit_b = K3_MASK(r8 < 0.0f), tail_b = K3_MASK(ps7 < 1.0f);
-        const unsigned long long big_m = K3_MASK(k3 >= kRingMaxK3);       // undecided there: the rest of the walk is K3h's (an idle lane rests at 6)
         // the count: the group's last k less one for each of its first three remainders that is negative (no hit: none is)
         const int32_t res_a = (k3 + ((int32_t)prnb::f2u(r1) >> 31) + ((int32_t)prnb::f2u(r2) >> 31)) + ((int32_t)prnb::f2u(r3) >> 31);
         const int32_t res_b = ((k3 + 4) + ((int32_t)prnb::f2u(r5) >> 31) + ((int32_t)prnb::f2u(r6) >> 31)) + ((int32_t)prnb::f2u(r7) >> 31);
         const unsigned long long end_a = (hit_a | tail_a) & ~idle_s;
-        const unsigned long long give_m = big_m & ~end_a & ~idle_s;
-        const unsigned long long end_b = (hit_b | tail_b) & ~(idle_s | end_a | big_m);
+        // a walk still undecided behind term 252 (k3 = 248: seventy per 10^9 samples of the headline workload) leaves this
+        // kernel (the ring holds 8 bits per count, the 1/k table ends at 272): its state waits in LDS for the hand-over
+        // at the end of the strip (below)
+        const unsigned long long big_m = K3_MASK(k3 >= kRingMaxK3) & ~idle_s;
+        const unsigned long long end_b = (hit_b | tail_b) & ~(idle_s | end_a);
+        const unsigned long long long_m = big_m & ~(end_a | end_b);
         int32_t res_k;
         asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(res_k) : "v"(res_b), "v"(res_a), "s"(end_a));
-        deliver(end_a | end_b, give_m, pos, (uint32_t)res_k, kRedoMark);
+        deliver(end_a | end_b, 0ull, pos, (uint32_t)res_k, 0.0f);
         idle_s |= end_a | end_b | big_m;                  // done lanes go idle
         st.x = ps7 * PRNB_FMA(d, inv2.w, q);
         // an idle lane rests at k3 = 6 with the reciprocals of a walk's first two groups (the reads below fetch them again
         // every pass): a pull then brings only the entry
         const int k3n = k3 + 8;
-        asm("v_cndmask_b32 %0, %1, 8, %2" : "=v"(k3) : "v"(k3n), "s"(idle_s));
         st.w = r8;
+        if (long_m != 0ull) {
+            // (rare) keep the state -- the next term is k = k3n - 3 = 253 -- behind the wave's staging list; should a strip have
+            // more than kLongSlots such walks, the others go onto K3h's list of walks to redo from their start; should that be
+            // full as well, the whole region is redone (count -1)
+            const int n_have = n_long < 0 ? kLongSlots : n_long;
+            const int slot = n_have + lane_rank(long_m);
+            const bool mine = (long_m >> lane) & 1ull;
+            bool full = false;
+            if (mine && slot < kLongSlots) {
+                my_long[3 * slot] = make_uint2(__float_as_uint(st.x), __float_as_uint(st.y));
+                my_long[3 * slot + 1] = make_uint2(__float_as_uint(st.z), __float_as_uint(st.w));
+                my_long[3 * slot + 2] = make_uint2((pos & 0xffffu) | ((uint32_t)k3n << 16), 0u);
+            }
+            if (mine && slot >= kLongSlots) {
+                const HeavyGlobal heavy = heavy_late();
+                const uint32_t at = __hip_atomic_fetch_add(heavy.seg_cnt + kSegs + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (at < (uint32_t)kRedoCap) heavy.redo[at] = i32x2_t{(int32_t)(n0 + ((pos & 0xffffu) >> 8)), gbase + (int32_t)(pos & 255u)};
+                else full = true;
+            }
+            const bool any_full = __builtin_amdgcn_ballot_w64(full) != 0ull;
+            const int n_new = n_have + __popcll(long_m);
+            n_long = (n_long < 0 || any_full) ? -1 : (n_new < kLongSlots ? n_new : kLongSlots);
+        }
+        asm("v_cndmask_b32 %0, %1, 8, %2" : "=v"(k3) : "v"(k3n), "s"(idle_s));
         inv = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(&inv_k[k3 - 2], 16));    // 1/(k+1..k+4), k = k3 - 3
         inv2 = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(&inv_k[k3 + 2], 16));   // 1/(k+5..k+8)
         if (BIG) __builtin_amdgcn_s_setprio(0);
@@ -603,29 +669,69 @@ __global__ __launch_bounds__(kBlock, 5) void sample_counts_stream_kernel(
     // The last walks of a strip would run with a handful of busy lanes (13 % of the lanes over a quarter of a
     // pass per cell on the headline workload): once nothing waits on S2 and at most kBail lanes still walk,
     // their walks go to K3h with their state -- the next term, d, q, the remainder, k3 --, which continues them.
-    uint32_t n_bail = 0u;                            // wave-uniform
+    unsigned long long bail_m = 0ull;                // the lanes whose walks travel (wave-uniform)
     for (;;) {
         const unsigned long long busy_m = ~idle_s;
         if (s2_top == 0) {
             if (busy_m == 0ull) break;
-            if (__popcll(busy_m) <= kBail) {
-                if ((busy_m >> lane) & 1ull) {
-                    const uint64_t slot = (uint64_t)region * kBailSlots + (uint32_t)lane_rank(busy_m);
-                    heavy.bail_st[slot] = st;
-                    heavy.bail_id[slot] = (pos & 0xffffu) | ((uint32_t)k3 << 16);
-                }
-                n_bail = (uint32_t)__popcll(busy_m);
-                break;
-            }
+            if (__popcll(busy_m) <= kBail) { bail_m = busy_m; break; }
         }
         stage3_pass();
     }
+    if (__builtin_amdgcn_ballot_w64(hpend != kNoHeavy) != 0ull) flush_heavy();
     for (int cl = (cells > kRing ? cells - kRing : 0); cl < cells; ++cl) flush_row(cl);
     flush_late();
-    if (__builtin_amdgcn_ballot_w64(hpend != kNoHeavy) != 0ull) flush_heavy();
-    if (lane == 0) {
-        heavy.count[region] = h_cnt | (n_bail << 16);    // h_cnt above cap: K3h redoes the whole region (h_cnt <= 128 * 256 < 2^16)
-        if (h_cnt > heavy.cap) heavy.overflow[0] = 1u;   // (for prosstt_amd_last_list)
+    // ---- the hand-over to K3h ----------------------------------------------------------------------------
+    const HeavyGlobal heavy = heavy_late();
+    auto staged = [&](uint32_t i) -> unsigned long long {
+        return __hip_atomic_load(reinterpret_cast<unsigned long long*>(my_list + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    const int n_kept = n_long < 0 ? kLongSlots : n_long;
+    const uint32_t n_still = (uint32_t)__popcll(bail_m);
+    // the walks, with their state: the ones still running, then the ones that ran past term 252 (this wave's own stores
+    // behind its staging list have arrived once vmcnt is 0, and the loads read the device-level cache)
+    if ((bail_m >> lane) & 1ull) {
+        const uint64_t at = (uint64_t)region * kWalkSlots + (uint32_t)lane_rank(bail_m);
+        heavy.wst[at] = st;
+        heavy.wid[at] = (pos & 0xffffu) | ((uint32_t)k3 << 16);
+    }
+    if (n_kept != 0) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0)
+        if (lane < n_kept) {
+            const uint64_t at = (uint64_t)region * kWalkSlots + n_still + (uint32_t)lane;
+            const unsigned long long w0 = staged(heavy_cap + 3u * (uint32_t)lane), w1 = staged(heavy_cap + 3u * (uint32_t)lane + 1u);
+            const f32x4_t stl = {__uint_as_float((uint32_t)w0), __uint_as_float((uint32_t)(w0 >> 32)), __uint_as_float((uint32_t)w1), __uint_as_float((uint32_t)(w1 >> 32))};
+            heavy.wst[at] = stl;
+            heavy.wid[at] = (uint32_t)staged(heavy_cap + 3u * (uint32_t)lane + 2u);
+        }
+    }
+    const bool too_many = h_cnt > heavy_cap || n_long < 0;
+    if (lane == 0) heavy.count[region] = (h_cnt < 0xffffu ? h_cnt : 0xffffu) | ((n_still + (uint32_t)n_kept) << 16);
+    // what was listed behind the first kDense entries (a wave of a hot gene tile): from the staging list to a segment, as
+    // {cell, gene, m}
+    bool spills = too_many;
+    if (!too_many && h_cnt > (uint32_t)kDense) {
+        const uint32_t n_over = h_cnt - (uint32_t)kDense;
+        const uint32_t seg = region & (uint32_t)(kSegs - 1);
+        uint32_t base_e = 0u;
+        if (lane == 0) base_e = __hip_atomic_fetch_add(heavy.seg_cnt + seg, n_over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): the atomic's answer, and this wave's stores to its staging list
+        base_e = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)base_e);
+        spills = base_e + n_over > heavy.ent_cap;
+        for (uint32_t i = (uint32_t)lane; i < n_over; i += 64u) {
+            if (base_e + i < heavy.ent_cap) {
+                const unsigned long long raw = staged((uint32_t)kDense + i);
+                const uint32_t px = (uint32_t)raw;
+                const u32x4_t e = {(uint32_t)(n0 + (px >> 8)), (uint32_t)(gbase + (int32_t)(px & 255u)), (uint32_t)(raw >> 32), 0u};       // HeavyEntry {n, g, m, -}
+                heavy.ent[(uint64_t)seg * heavy.ent_cap + base_e + i] = e;
+            }
+        }
+    }
+    if (spills && lane == 0) {
+        // redone by K3h as a whole (what did reach K3h's lists is drawn twice, to the same counts)
+        const uint32_t at = __hip_atomic_fetch_add(heavy.seg_cnt + kSegs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        heavy.ovf_regions[at] = region;
+        heavy.overflow[0] = 1u;                      // (for prosstt_amd_last_list)
     }
 }
 

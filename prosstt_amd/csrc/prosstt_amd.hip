@@ -73,12 +73,8 @@ struct prosstt_amd_ctx {
     std::vector<hipEvent_t> events;  // (start, stop) pairs of kernels launched with TIME_KERNEL
     size_t events_used = 0;
     // the K3h list of the last sample_counts call (inside `ws`; read by prosstt_amd_last_list)
-    uint2* list = nullptr;
-    uint32_t* list_count = nullptr;
-    uint32_t* list_bail_id = nullptr;
-    uint2* list_dense = nullptr;
+    k3::HeavyList list{};        // (list.seg_cnt == nullptr: none)
     uint64_t list_regions = 0;
-    uint32_t list_cap = 0;
     int64_t list_groups = 0, list_strip_cells = 0;
     int heavy_grid = 1280;       // blocks of K3h that are resident at once on this device (5 per CU: its 30 496 B of LDS)
     // domain check: one byte per row of the mean tensor last scanned ("has an entry that is not > 0"), and which tensor that was
@@ -114,11 +110,7 @@ constexpr int kStickyDomain = 4, kStickyRow = 5, kFullReq = 6;
 static int ws_reserve(prosstt_amd_ctx* c, size_t bytes)
 {
     // every user of the workspace overwrites what the last sample_counts call left there: its list is gone
-    c->list = nullptr;
-    c->list_count = nullptr;
-    c->list_bail_id = nullptr;
-    c->list_dense = nullptr;
-    c->list_regions = 0;
+    c->list = k3::HeavyList{};
     if (bytes <= c->ws_bytes) return 0;
     if (c->ws) {
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -170,9 +162,12 @@ __global__ void prep_kernel(const double* __restrict__ scaling, int64_t N,
                             const int32_t* __restrict__ row_of_cell, int64_t rows, uint64_t cell_offset,
                             const int64_t* __restrict__ cell_index, int32_t strip_cells,
                             uint32_t k0, uint32_t k1, k3::CellInfo* __restrict__ info, int64_t* __restrict__ flags,
-                            const uint8_t* __restrict__ row_bad, uint32_t parity)
+                            const uint8_t* __restrict__ row_bad, uint32_t parity, k3::HeavyList heavy,
+                            k3::HeavyList* __restrict__ heavy_rec)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (heavy_rec && i < k3::kSegs + 2) heavy.seg_cnt[i] = 0u;      // the fill of the dense lists K3h reads
+    if (heavy_rec && i == 0) *heavy_rec = heavy;                       // ... and their description, for the two kernels behind
     if (flags && i == 0) {
         flags[3] = 0;                       // list overflow of this call (set by the streaming kernel)
         flags[kFullReq + (parity ^ 1u)] = 0;  // the NEXT call's full-test request (this call's was cleared by the previous one)
@@ -673,6 +668,9 @@ struct SamplerArgs {
     const int64_t* cell_index;   // device copy (NULL: cells are numbered from cell_offset)
     float *scal, *ga, *gbm1, *gphi;
     void* extra;     // `extra_bytes` of workspace behind the parameter vectors (256-B aligned)
+    k3::HeavyList heavy;           // K3h's lists (a sample_counts call) ...
+    k3::HeavyList* heavy_rec;      // ... and where the preparation kernel puts their description for the kernels behind it
+    k3::CellInfo* cellinfo;
 };
 
 // Geometry of a streaming-kernel launch (k3_stream.h): strips of 64 cells per wave (the kernel takes up
@@ -682,8 +680,9 @@ struct StreamGeometry {
     int64_t tiles_g, strip_cells, strips, groups;
     uint64_t regions;       // one region of the K3h list per wave
     uint32_t region_cap;    // room for one in 16 of a wave's samples (beyond that K3h redoes the region itself)
-    size_t list_bytes, count_bytes, bail_st_bytes, bail_id_bytes, dense_bytes, info_bytes;
-    size_t total() const { return list_bytes + count_bytes + bail_st_bytes + bail_id_bytes + dense_bytes + info_bytes + 256; }
+    uint32_t ent_cap;          // entries per segment of the dense lists K3h reads (k3::HeavyList)
+    size_t list_bytes, cnt_bytes, dense_bytes, count_bytes, ent_bytes, wst_bytes, wid_bytes, ovf_bytes, redo_bytes, info_bytes;
+    size_t total() const { return list_bytes + cnt_bytes + dense_bytes + count_bytes + ent_bytes + wst_bytes + wid_bytes + ovf_bytes + redo_bytes + info_bytes + 256; }
 };
 
 static StreamGeometry stream_geometry(int64_t N, int32_t G, int64_t rows)
@@ -698,11 +697,22 @@ static StreamGeometry stream_geometry(int64_t N, int32_t G, int64_t rows)
     g.regions = (uint64_t)(g.groups * g.tiles_g) * 4u;
     g.region_cap = (uint32_t)g.strip_cells * (kTileG / 16);
     if (g.region_cap > 1024u) g.region_cap = 1024u;             // K3h's second phase takes kDense + 16 chunks of 64
-    g.list_bytes = ((g.regions * (size_t)g.region_cap * sizeof(uint2)) + 255) & ~(size_t)255;      // {pos, scaled mean}
-    g.count_bytes = ((g.regions * 4u) + 255) & ~(size_t)255;
-    g.bail_st_bytes = ((g.regions * (size_t)k3::kBailSlots * 16u) + 255) & ~(size_t)255;            // walk states handed over
-    g.bail_id_bytes = ((g.regions * (size_t)k3::kBailSlots * 4u) + 255) & ~(size_t)255;
-    g.dense_bytes = ((g.regions * (size_t)k3::kDense * sizeof(uint2)) + 255) & ~(size_t)255;       // a region's first entries
+    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    g.list_bytes = pad(g.regions * ((size_t)g.region_cap + k3::kListTail) * sizeof(uint2));      // staging: {pos, scaled mean} per region (+ its tail)
+    g.cnt_bytes = pad(768 + sizeof(k3::HeavyList));      // the segments' counters, and (at 768) the lists' description
+    static_assert((k3::kSegs + 2) * 4 <= 768, "the counters end where the record starts");
+    g.dense_bytes = pad(g.regions * (size_t)k3::kDense * sizeof(uint2));      // a region's first entries
+    g.count_bytes = pad(g.regions * 4u);
+    // the segments (what regions list beyond their first kDense entries) take one sample in 64 of the matrix between them
+    // (typical workloads list one to three in a thousand); a region that finds its segment full is redone as a whole, like
+    // one whose own list was too small
+    const uint64_t per_seg = ((uint64_t)n * (uint64_t)(G > 0 ? G : 0) / 64u + k3::kSegs - 1) / k3::kSegs;
+    g.ent_cap = (uint32_t)(per_seg < 4u * g.region_cap ? 4u * g.region_cap : (per_seg > 0x7fffffffull ? 0x7fffffffull : per_seg));
+    g.ent_bytes = pad((size_t)k3::kSegs * g.ent_cap * sizeof(k3::HeavyEntry));
+    g.wst_bytes = pad(g.regions * (size_t)k3::kWalkSlots * 16u);            // walk states handed over
+    g.wid_bytes = pad(g.regions * (size_t)k3::kWalkSlots * 4u);
+    g.ovf_bytes = pad(g.regions * 4u);
+    g.redo_bytes = pad((size_t)k3::kRedoCap * sizeof(int2));
     g.info_bytes = ((size_t)n + 4) * sizeof(k3::CellInfo);
     return g;
 }
@@ -756,7 +766,27 @@ static int sampler_setup(prosstt_amd_ctx* c, Staging& st, const float* means, in
     A->gphi = A->gbm1 + G;
     A->extra = (char*)c->ws + vec_bytes;
     k3::CellInfo* info = nullptr;
-    if (geo) info = (k3::CellInfo*)((char*)A->extra + geo->list_bytes + geo->count_bytes + geo->bail_st_bytes + geo->bail_id_bytes + geo->dense_bytes);
+    A->heavy = k3::HeavyList{};
+    A->heavy_rec = nullptr;
+    if (geo) {
+        char* at = (char*)A->extra;
+        k3::HeavyList& heavy = A->heavy;
+        heavy.list = (uint2*)at; at += geo->list_bytes;
+        heavy.seg_cnt = (uint32_t*)at;                                // zeroed by the preparation kernel
+        A->heavy_rec = (k3::HeavyList*)(at + 768); at += geo->cnt_bytes;
+        heavy.dense = (uint2*)at; at += geo->dense_bytes;
+        heavy.count = (uint32_t*)at; at += geo->count_bytes;
+        heavy.ent = (k3::HeavyEntry*)at; at += geo->ent_bytes;
+        heavy.wst = (k3::f32x4_t*)at; at += geo->wst_bytes;
+        heavy.wid = (uint32_t*)at; at += geo->wid_bytes;
+        heavy.ovf_regions = (uint32_t*)at; at += geo->ovf_bytes;
+        heavy.redo = (int2*)at; at += geo->redo_bytes;
+        info = (k3::CellInfo*)at;
+        heavy.cap = geo->region_cap;
+        heavy.ent_cap = geo->ent_cap;
+        heavy.overflow = (uint32_t*)(c->scratch + 3);           // zeroed by the preparation kernel
+    }
+    A->cellinfo = info;
     // a checked call needs the per-row flags of THIS mean tensor: scanned now unless the caller vouches that the tensor
     // the ctx last scanned (same pointer, same shape) has not changed since
     const uint8_t* row_bad = nullptr;
@@ -786,7 +816,7 @@ static int sampler_setup(prosstt_amd_ctx* c, Staging& st, const float* means, in
     prep_kernel<<<dim3((unsigned)((span + 255) / 256)), dim3(256), 0, c->stream>>>(
         scaling, N, alpha, beta, G, A->scal, A->ga, A->gbm1, A->gphi, row_of_cell, rows, cell_offset, cell_index,
         geo ? (int32_t)geo->strip_cells : 1, (uint32_t)seed, (uint32_t)(seed >> 32), info, geo ? c->scratch : nullptr,
-        row_bad, c->call_parity);
+        row_bad, c->call_parity, A->heavy, A->heavy_rec);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -860,15 +890,8 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
                            cell_index, seed);
     if (rc) return rc;
     if (N == 0 || G == 0) return 0;
-    k3::HeavyList heavy;
-    heavy.list = (uint2*)A.extra;
-    heavy.count = (uint32_t*)((char*)A.extra + geo.list_bytes);
-    heavy.overflow = (uint32_t*)(c->scratch + 3);           // zeroed by the preparation kernel
-    heavy.cap = geo.region_cap;
-    heavy.bail_st = (k3::f32x4_t*)((char*)A.extra + geo.list_bytes + geo.count_bytes);
-    heavy.bail_id = (uint32_t*)((char*)A.extra + geo.list_bytes + geo.count_bytes + geo.bail_st_bytes);
-    heavy.dense = (uint2*)((char*)A.extra + geo.list_bytes + geo.count_bytes + geo.bail_st_bytes + geo.bail_id_bytes);
-    k3::CellInfo* cellinfo = (k3::CellInfo*)((char*)A.extra + geo.list_bytes + geo.count_bytes + geo.bail_st_bytes + geo.bail_id_bytes + geo.dense_bytes);
+    const k3::HeavyList heavy = A.heavy;
+    k3::CellInfo* cellinfo = A.cellinfo;
     const int64_t* d_cell_index = A.cell_index;
     int32_t* d_out = out;
     if (flags & PROSSTT_AMD_HOST_OUTPUT) {
@@ -895,7 +918,7 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
 #define K3_LAUNCH(V, B)                                                                                          \
     hipExtLaunchKernelGGL((k3::sample_counts_stream_kernel<V, B>), grid, block, 0, c->stream, ev_start, ev_stop, 0,  \
         A.means, G, (const k3::CellInfo*)cellinfo, (const float*)A.ga, (const float*)A.gbm1, (const float*)A.gphi, N, k0, k1, \
-        d_out, ld_out, (int32_t)geo.strips, (int32_t)geo.strip_cells, heavy)
+        d_out, ld_out, (int32_t)geo.strips, (int32_t)geo.strip_cells, heavy.list, heavy.cap, heavy.dense, (const k3::HeavyList*)A.heavy_rec)
     if (vec && big) K3_LAUNCH(true, true);
     else if (vec) K3_LAUNCH(true, false);
     else if (big) K3_LAUNCH(false, true);
@@ -908,19 +931,15 @@ PA_EXPORT int prosstt_amd_sample_counts(prosstt_amd_ctx* c, const float* means, 
     const uint64_t region_blocks = (geo.regions + 15u) / 16u;
     const unsigned heavy_blocks = (unsigned)(region_blocks < 256u ? 256u : (region_blocks < (uint64_t)c->heavy_grid ? region_blocks : (uint64_t)c->heavy_grid));
     k3::sample_counts_heavy_kernel<<<dim3(heavy_blocks), dim3(k3::kHeavyBlock), 0, c->stream>>>(
-        heavy, (uint32_t)geo.regions, (int32_t)geo.strips, (int32_t)geo.strip_cells, A.means, rows, G, A.row_of_cell,
+        (const k3::HeavyList*)A.heavy_rec, (uint32_t)geo.regions, (int32_t)geo.strips, (int32_t)geo.strip_cells, A.means, rows, G, A.row_of_cell,
         A.scal, A.ga, A.gbm1, N, k0, k1, cell_offset, d_cell_index, d_out, ld_out,
         // the per-sample part of a checked call's domain test rides at the end of K3h (it leaves at once unless a gene has
         // alpha < 0 or beta < 1: prep_kernel's request word of this call's parity)
         (checked && !(flags & PROSSTT_AMD_PARAMS_NONNEG)) ? c->scratch : nullptr, (uint32_t)kFullReq + c->call_parity,
         (uint32_t)kStickyRow, (uint32_t)kStickyDomain);
     HIP_TRY(hipGetLastError());
-    c->list = heavy.list;
-    c->list_count = heavy.count;
-    c->list_bail_id = heavy.bail_id;
-    c->list_dense = heavy.dense;
+    c->list = heavy;
     c->list_regions = geo.regions;
-    c->list_cap = heavy.cap;
     c->list_groups = geo.groups;
     c->list_strip_cells = geo.strip_cells;
     c->call_parity ^= 1u;
@@ -950,32 +969,46 @@ PA_EXPORT int prosstt_amd_last_list(prosstt_amd_ctx* c, int64_t* cells, int32_t*
     if (cap > 0 && (!cells || !genes)) return fail(PROSSTT_AMD_EINVAL, "NULL output array");
     *total = 0;
     if (overflowed) *overflowed = 0;
-    if (!c->list || c->list_regions == 0) return 0;
+    if (!c->list.seg_cnt) return 0;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    std::vector<uint32_t> counts(c->list_regions);
-    HIP_TRY(hipMemcpy(counts.data(), c->list_count, counts.size() * 4, hipMemcpyDeviceToHost));
     int64_t flagw[4];
     HIP_TRY(hipMemcpy(flagw, c->scratch, sizeof(flagw), hipMemcpyDeviceToHost));
     if (overflowed) *overflowed = (int32_t)((uint32_t)flagw[3] != 0u);
-    std::vector<uint2> entries(c->list_cap);
-    uint32_t bail[k3::kBailSlots];
     int64_t written = 0;
+    // per region: the first entries and the walks
+    std::vector<uint32_t> counts(c->list_regions);
+    HIP_TRY(hipMemcpy(counts.data(), c->list.count, counts.size() * 4, hipMemcpyDeviceToHost));
+    uint2 dense[k3::kDense];
+    uint32_t wid[k3::kWalkSlots];
     for (uint64_t r = 0; r < c->list_regions; ++r) {
         const uint32_t listed = counts[r] & 0xffffu, walks = counts[r] >> 16;
-        const uint32_t n = listed < c->list_cap ? listed : c->list_cap;
-        *total += n + walks;
-        if (n + walks == 0 || written >= cap) continue;
-        const uint32_t nd = n < (uint32_t)k3::kDense ? n : (uint32_t)k3::kDense;      // the first entries lie in the dense array
-        if (nd) HIP_TRY(hipMemcpy(entries.data(), c->list_dense + r * k3::kDense, (size_t)nd * sizeof(uint2), hipMemcpyDeviceToHost));
-        if (n > nd) HIP_TRY(hipMemcpy(entries.data() + nd, c->list + r * c->list_cap + nd, (size_t)(n - nd) * sizeof(uint2), hipMemcpyDeviceToHost));
-        if (walks) HIP_TRY(hipMemcpy(bail, c->list_bail_id + r * k3::kBailSlots, (size_t)walks * 4, hipMemcpyDeviceToHost));
+        const uint32_t nd = listed > c->list.cap ? 0u : (listed < (uint32_t)k3::kDense ? listed : (uint32_t)k3::kDense);
+        *total += nd + walks;
+        if (nd + walks == 0 || written >= cap) continue;
+        if (nd) HIP_TRY(hipMemcpy(dense, c->list.dense + r * k3::kDense, (size_t)nd * sizeof(uint2), hipMemcpyDeviceToHost));
+        if (walks) HIP_TRY(hipMemcpy(wid, c->list.wid + r * k3::kWalkSlots, (size_t)walks * 4, hipMemcpyDeviceToHost));
         const int64_t blk = (int64_t)(r >> 2), tile_g = blk / c->list_groups;
         const int64_t n0 = ((blk - tile_g * c->list_groups) * 4 + (int64_t)(r & 3)) * c->list_strip_cells;
-        for (uint32_t i = 0; i < n + walks && written < cap; ++i, ++written) {
-            const uint32_t pos = i < n ? entries[i].x : (bail[i - n] & 0xffffu);
+        for (uint32_t i = 0; i < nd + walks && written < cap; ++i, ++written) {
+            const uint32_t pos = i < nd ? dense[i].x : (wid[i - nd] & 0xffffu);
             cells[written] = n0 + (pos >> 8);
             genes[written] = (int32_t)(tile_g * kTileG + (pos & 255u));
+        }
+    }
+    // the segments: what regions listed beyond their first entries
+    uint32_t fill[k3::kSegs];
+    HIP_TRY(hipMemcpy(fill, c->list.seg_cnt, sizeof(fill), hipMemcpyDeviceToHost));
+    std::vector<k3::HeavyEntry> ent;
+    for (int sg = 0; sg < k3::kSegs; ++sg) {
+        const uint32_t ne = fill[sg] < c->list.ent_cap ? fill[sg] : c->list.ent_cap;
+        *total += (int64_t)ne;
+        if (written >= cap || ne == 0) continue;
+        ent.resize(ne);
+        HIP_TRY(hipMemcpy(ent.data(), c->list.ent + (size_t)sg * c->list.ent_cap, (size_t)ne * sizeof(k3::HeavyEntry), hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < ne && written < cap; ++i, ++written) {
+            cells[written] = ent[i].n;
+            genes[written] = ent[i].g;
         }
     }
     return 0;

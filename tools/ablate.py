@@ -57,14 +57,31 @@ VARIANTS = {
     # everything, rows not stored
     "nostore": [STORE_OFF],
     # K3h (round 6 sources) without the handed-over walks / without the gamma-Poisson samples / with an empty list
-    "k3h_nowalk": [("            walk_push((uint32_t)sl < n_bail,", "            walk_push(false && (uint32_t)sl < n_bail,")],
-    "k3h_noheavy": [("        const bool heavy_c = has && m >= 0.0f;", "        const bool heavy_c = false && has && m >= 0.0f;")],
-    "k3h_none": [("            walk_push((uint32_t)sl < n_bail,", "            walk_push(false && (uint32_t)sl < n_bail,"),
-                 ("        const bool heavy_c = has && m >= 0.0f;", "        const bool heavy_c = false && has && m >= 0.0f;")],
+    "k3h_nowalk": [("                walk_push(slot < cur.n_walks,", "                walk_push(false && slot < cur.n_walks,")],
+    "k3h_noheavy": [("        const unsigned long long mh = __builtin_amdgcn_ballot_w64(has);\n        if (has) {\n            HGEntry h;", "        has = false;\n        const unsigned long long mh = __builtin_amdgcn_ballot_w64(has);\n        if (has) {\n            HGEntry h;")],
+    "k3h_none": [("                walk_push(slot < cur.n_walks,", "                walk_push(false && slot < cur.n_walks,"),
+                 ("        const unsigned long long mh = __builtin_amdgcn_ballot_w64(has);\n        if (has) {\n            HGEntry h;", "        has = false;\n        const unsigned long long mh = __builtin_amdgcn_ballot_w64(has);\n        if (has) {\n            HGEntry h;")],
     # K3h leaves at once / after its 1/k table / without looking at the list: what a launch of it costs at least
     "k3h_exit0": [("    __shared__ HeavyLds lds_all[kHeavyBlock / 64];\n    const int tid = threadIdx.x,", "    __shared__ HeavyLds lds_all[kHeavyBlock / 64];\n    if (N >= 0) return;\n    const int tid = threadIdx.x,")],
     "k3h_exit1": [("    int hg_top = 0, hp_top = 0, hw_top = 0;      // wave-uniform", "    if (N >= 0) return;\n    int hg_top = 0, hp_top = 0, hw_top = 0;      // wave-uniform")],
     "k3h_onestep": [("base += 4ull * waves) {", "base += 1ull << 40) {")],
+    # where K3h's time goes when its list is empty: leave after the tables / skip phase 1 / skip phase 2
+    "k3h_exitA": [("    // blk / groups for blk < 2^32:", "    if (N >= 0) return;\n    // blk / groups for blk < 2^32:")],
+    "k3h_none_nop1": [("                walk_push(slot < cur.n_walks,", "                walk_push(false && slot < cur.n_walks,"),
+                 ("        const unsigned long long mh = __builtin_amdgcn_ballot_w64(has);\n        if (has) {\n            HGEntry h;", "        has = false;\n        const unsigned long long mh = __builtin_amdgcn_ballot_w64(has);\n        if (has) {\n            HGEntry h;"),
+                 ("        for (uint64_t r0 = wave_id; r0 < (uint64_t)regions; r0 += 4ull * waves) {", "        for (uint64_t r0 = wave_id; r0 < (uint64_t)regions && N < 0; r0 += 4ull * waves) {")],
+    "k3h_none_nop2": [("                walk_push(slot < cur.n_walks,", "                walk_push(false && slot < cur.n_walks,"),
+                 ("        const unsigned long long mh = __builtin_amdgcn_ballot_w64(has);\n        if (has) {\n            HGEntry h;", "        has = false;\n        const unsigned long long mh = __builtin_amdgcn_ballot_w64(has);\n        if (has) {\n            HGEntry h;"),
+                 ("        for (uint32_t p0 = 0u; p0 < pairs; p0 += 64u) {", "        for (uint32_t p0 = 0u; p0 < pairs && N < 0; p0 += 64u) {")],
+    "k3h_none_nop12": [("                walk_push(slot < cur.n_walks,", "                walk_push(false && slot < cur.n_walks,"),
+                 ("        const unsigned long long mh = __builtin_amdgcn_ballot_w64(has);\n        if (has) {\n            HGEntry h;", "        has = false;\n        const unsigned long long mh = __builtin_amdgcn_ballot_w64(has);\n        if (has) {\n            HGEntry h;"),
+                 ("        for (uint64_t r0 = wave_id; r0 < (uint64_t)regions; r0 += 4ull * waves) {", "        for (uint64_t r0 = wave_id; r0 < (uint64_t)regions && N < 0; r0 += 4ull * waves) {"),
+                 ("        for (uint32_t p0 = 0u; p0 < pairs; p0 += 64u) {", "        for (uint32_t p0 = 0u; p0 < pairs && N < 0; p0 += 64u) {")],
+    "k3h_exitB": [("    const int32_t groups = (strips + 3) / 4;\n    const uint32_t waves = gridDim.x * (kHeavyBlock / 64);", "    if (N >= 0) return;\n    const int32_t groups = (strips + 3) / 4;\n    const uint32_t waves = gridDim.x * (kHeavyBlock / 64);")],
+    "k3h_exitC": [("                walk_push(slot < cur.n_walks,", "                walk_push(false && slot < cur.n_walks,"),
+                 ("        const unsigned long long mh = __builtin_amdgcn_ballot_w64(has);\n        if (has) {\n            HGEntry h;", "        has = false;\n        const unsigned long long mh = __builtin_amdgcn_ballot_w64(has);\n        if (has) {\n            HGEntry h;"), ("    // The walks: to one wave in four", "    if (N >= 0) return;\n    // The walks: to one wave in four")],
+    "k3h_exitD": [("                walk_push(slot < cur.n_walks,", "                walk_push(false && slot < cur.n_walks,"),
+                 ("        const unsigned long long mh = __builtin_amdgcn_ballot_w64(has);\n        if (has) {\n            HGEntry h;", "        has = false;\n        const unsigned long long mh = __builtin_amdgcn_ballot_w64(has);\n        if (has) {\n            HGEntry h;"), ("    // Regions whose list or segment was too small:", "    if (N >= 0) return;\n    // Regions whose list or segment was too small:")],
     # ... the gamma-Poisson entries dropped after the gamma pass
     "k3h_nopois": [("        while (hp_top >= 64) poisson_pass();\n    };", "        hp_top = 0;\n    };")],
     "k3h_gamma1": [("                    ok = last;\n                    if (!ok) {", "                    ok = true;\n                    if (!ok) {")],
@@ -85,9 +102,9 @@ VARIANTS = {
                   ("    auto walk_service = [&](bool drain) __attribute__((always_inline)) {\n        for (;;) {", "    auto walk_service = [&](bool drain) __attribute__((always_inline)) {\n        const long long tl0 = clock64();\n        for (;;) {"),
                   ("            if (busy <= 32 && (drain ? hw_top > 0 : hw_top >= 32)) walk_take();\n            else if (drain ? busy > 0 : busy > 32) walk_pass();\n            else break;\n        }",
                    "            if (busy <= 32 && (drain ? hw_top > 0 : hw_top >= 32)) { walk_take(); ++np_l; }\n            else if (drain ? busy > 0 : busy > 32) { walk_pass(); ++np_w; }\n            else break;\n        }\n        TL += clock64() - tl0;"),
-                  ("        hg_top += __popcll(mh);\n        while (hg_top >= 64) gamma_pass();\n        const bool redo", "        hg_top += __popcll(mh);\n        n_ent += __popcll(mh);\n        while (hg_top >= 64) gamma_pass();\n        const bool redo"),
-                  ("    // Phase 2: what a region lists behind", "    const long long T1 = clock64();\n    // Phase 2: what a region lists behind"),
-                  ("                const uint2 e = nx;\n", "                const uint2 e = nx;\n                ++n_chunks;\n"),
+                  ("            hg_top += __popcll(mh);\n            while (hg_top >= 64) gamma_pass();\n            const bool redo", "            hg_top += __popcll(mh);\n            n_ent += __popcll(mh);\n            while (hg_top >= 64) gamma_pass();\n            const bool redo"),
+                  ("    // The walks: to one wave in four", "    const long long T1 = clock64();\n    // The walks: to one wave in four"),
+                  ("            walk_push(has, id.n, id.g, id.k, st);", "            walk_push(has, id.n, id.g, id.k, st);\n            ++n_chunks;"),
                   ("    walk_service(true);\n    while (hg_top > 0) gamma_pass();\n    while (hp_top > 0) poisson_pass();",
                    "    const long long T2 = clock64();\n    walk_service(true);\n    const long long T3 = clock64();\n    while (hg_top > 0) gamma_pass();\n    while (hp_top > 0) poisson_pass();\n"
                    "    const long long T4 = clock64(); const long long W1 = wall_clock64();\n"
@@ -362,6 +379,19 @@ VARIANTS["r6_s2_7terms"] = [
     ("            e2.x = ps2 * PRNB_FMA(dd, 0.33333334f, qq);      // pmf at k = 3 (the 1/k table's 1/3)", "            e2.x = ps6 * PRNB_FMA(dd, 0.14285715f, qq);"),
     ("            e2.w = r2;", "            e2.w = r6;"),
 ]
+
+
+# round 6 (timing only): what the end of a strip costs the streaming kernel -- no hand-over at all / the atomics but no copy
+VARIANTS["r6_end_none"] = [("    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0)\n    const int n_kept", "    if (N >= 0) { for (int cl = (cells > kRing ? cells - kRing : 0); cl < cells; ++cl) flush_row(cl); flush_late(); return; }\n    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0)\n    const int n_kept")]
+VARIANTS["r6_end_nowait"] = [("    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0)\n    const int n_kept", "    const int n_kept")]
+VARIANTS["r6_end_nocopy"] = [("    for (uint32_t i = (uint32_t)lane; i < n_ent; i += 64u) {\n        const unsigned long long raw = i < 64u ? first_raw : staged(i);", "    for (uint32_t i = (uint32_t)lane; i < n_ent && N < 0; i += 64u) {\n        const unsigned long long raw = i < 64u ? first_raw : staged(i);"),
+                              ("    if ((uint32_t)lane < n_ent) first_raw = staged((uint32_t)lane);", "")]
+
+
+# round 6: how many of K3h's blocks walk (of every 16)
+def _walkers(n):
+    return [("constexpr uint32_t kWalkerBlocks = 6u;", "constexpr uint32_t kWalkerBlocks = %du;" % n)]
+VARIANTS.update({"k3h_walk2": _walkers(2), "k3h_walk4": _walkers(4), "k3h_walk5": _walkers(5), "k3h_walk6": _walkers(6), "k3h_walk8": _walkers(8)})
 
 
 def build(name):
