@@ -327,8 +327,12 @@ def run_case(job, config, scaling, cells_per_gpu, steps, warmup, strict_steps, g
     # its copy to the host (end_to_end_ms includes that).  --plain-order presents the cells as planned (ms_per_step_plan_order).
     from prosstt_amd import device as _dev
     mine = np.asarray(mine, dtype=np.int64)
+    plan_order_ms = None
     if not job.args.plain_order:
-        mine = mine[_dev.plan_order(rows[mine], means.shape[0])]
+        t_po = time.perf_counter()
+        perm = _dev.plan_order(rows[mine], means.shape[0])
+        plan_order_ms = (time.perf_counter() - t_po) * 1e3      # host-side counting sort of the plan: once per plan, outside the step
+        mine = mine[perm]
     d_rows = ctx.tensor(rows[mine], torch.int32)
     d_sc = ctx.tensor(sc[mine], torch.float64)
     d_al = ctx.tensor(work.alpha, torch.float64)
@@ -379,7 +383,7 @@ def run_case(job, config, scaling, cells_per_gpu, steps, warmup, strict_steps, g
     res = dict(work=work, plan=(pt, br, sc), G=G, n_total=n_total, per_gpu=per_gpu, cells_on_rank=int(len(mine)),
                ms_per_step=elapsed / steps * 1e3, value=n_total * G / (elapsed / steps), kernel_ms=kms,
                rows_total=work.info["resident_rows"], ms_unchecked=None, ms_cold=ms_cold, gather_ms=None,
-               ramp_calls=ramp_calls)
+               ramp_calls=ramp_calls, plan_order_ms=plan_order_ms)
 
     # the same steps without the domain check (strict=False)
     if strict_steps > 0:
@@ -673,6 +677,14 @@ def assemble_line(args, job, main_case, strong, end_to_end, extras_error):
                    "presentation": "plan order" if args.plain_order else
                                    "cells grouped by mean-tensor row (simulation.draw_counts' call: prosstt_amd_plan_order); rows of "
                                    "the matrix in that order, put back in plan order inside the copy to the host",
+                   "api_call": ("the step is the device part of prosstt_amd.simulation.draw_counts(tree, pseudotime, branches, scalings, "
+                                "alpha, beta, out='torch'%s) -- the same prosstt_amd_sample_counts call on the same arrays; its return is "
+                                "the matrix as timed (device.PresentedCounts: counts + cell_of_row); the host-side grouping of the plan "
+                                "(plan_order_host_ms, once per plan) and the row-index computation are outside the step"
+                                % (", order='plan'" if args.plain_order else "")),
+                   "plan_order_host_ms": main_case.get("plan_order_ms"),
+                   "library_version": _library_version(), "sampler_definition": "PRNB-7",
+                   "gcn_arch": job.torch.cuda.get_device_properties(job.ctx.device).gcnArchName,
                    "sum_counts_over_sum_means": round(main_case["ratio"], 5)},
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
@@ -730,6 +742,11 @@ def assemble_line(args, job, main_case, strong, end_to_end, extras_error):
     if extras_error:
         line["extras_error"] = extras_error
     return line
+
+
+def _library_version():
+    from prosstt_amd import _native
+    return int(_native.load().prosstt_amd_version())
 
 
 def end_to_end_ms(tree, work, n_cells, out="numpy"):

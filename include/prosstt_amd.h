@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define PROSSTT_AMD_VERSION 500 /* 0.5.0: prosstt_amd_plan_order (the order of presentation that keeps the mean tensor in cache) */
+#define PROSSTT_AMD_VERSION 600 /* 0.6.0: sampler definition PRNB-7 (counts for a given seed differ from 0.5.0's PRNB-6); prosstt_amd_hw_math_at.
+                                  The version is the reproducibility key: it changes whenever the sampler's definition does. */
 
 enum {
     PROSSTT_AMD_OK = 0,

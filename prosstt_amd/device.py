@@ -366,6 +366,9 @@ def to_host(counts, dtype=np.int64, chunk_bytes=256 << 20, row_order=None):
         inv = torch.as_tensor(inv_host).to(dev)
     convert = t_dtype != torch.int32 or inv is not None
     staging = [torch.empty((rows, g), dtype=t_dtype, device=dev) for _ in range(2 if rows < n else 1)] if convert else []
+    # (gathered rows of a chunk that is also widened or narrowed: ONE int32 scratch for the whole copy, not a fresh
+    # temporary per chunk beside a count matrix that may fill most of the device)
+    gathered = torch.empty((rows, g), dtype=torch.int32, device=dev) if (inv is not None and t_dtype != torch.int32) else None
     copied = [None, None]
     too_big = torch.zeros((), dtype=torch.int32, device=dev) if dtype.itemsize == 2 else None
     for i, lo in enumerate(range(0, n, rows)):
@@ -382,7 +385,8 @@ def to_host(counts, dtype=np.int64, chunk_bytes=256 << 20, row_order=None):
             elif t_dtype == torch.int32:
                 torch.index_select(counts, 0, inv[lo:hi], out=stage)
             else:
-                stage.copy_(counts.index_select(0, inv[lo:hi]))
+                torch.index_select(counts, 0, inv[lo:hi], out=gathered[:hi - lo])
+                stage.copy_(gathered[:hi - lo])
         else:
             stage = counts[lo:hi]
         ready = torch.cuda.Event()
@@ -398,6 +402,50 @@ def to_host(counts, dtype=np.int64, chunk_bytes=256 << 20, row_order=None):
         raise OverflowError("a count of %d does not fit uint16: ask for 'numpy32'" % int(too_big))
     out = host.numpy()
     return out.view(np.uint16) if dtype.itemsize == 2 else out
+
+
+class PresentedCounts:
+    """The count matrix as it lies on the device after a call that PRESENTED its cells grouped by their row of the mean
+    tensor (what keeps a gene tile's rows of the tensor in cache: 2 to 5 % of the kernel, and 1.75 x less HBM traffic on a
+    32-branch tree): ``counts`` is the (N, G) int32 device tensor, row i of it belongs to cell ``cell_of_row[i]`` of the
+    plan (the order of the pseudotime / branch / scaling arrays the call returns).  Every count is keyed by the cell's
+    position in the plan, so ``counts`` holds exactly the rows of the plan-ordered matrix, permuted.
+
+        counts, cell_of_row = presented                  # unpacks like a pair
+        presented.in_plan_order()                        # a new device tensor, rows in plan order (one gather pass)
+        presented.to_host("numpy32")                     # host ndarray in plan order (the gather rides in the copy)
+        presented.row_of_cell                            # the inverse permutation
+    """
+
+    def __init__(self, counts, cell_of_row):
+        self.counts = counts
+        self.cell_of_row = np.asarray(cell_of_row, dtype=np.int64)
+        self._row_of_cell = None
+
+    def __iter__(self):
+        return iter((self.counts, self.cell_of_row))
+
+    def __len__(self):
+        return 2
+
+    @property
+    def shape(self):
+        return tuple(self.counts.shape)
+
+    @property
+    def row_of_cell(self):
+        if self._row_of_cell is None:
+            inv = np.empty_like(self.cell_of_row)
+            inv[self.cell_of_row] = np.arange(self.cell_of_row.size, dtype=np.int64)
+            self._row_of_cell = inv
+        return self._row_of_cell
+
+    def in_plan_order(self):
+        torch = _torch()
+        return self.counts.index_select(0, torch.as_tensor(self.row_of_cell).to(self.counts.device))
+
+    def to_host(self, out="numpy"):
+        return to_host(self.counts, HOST_DTYPES[out], row_order=self.cell_of_row)
 
 
 def to_host_int64(counts, chunk_bytes=256 << 20):

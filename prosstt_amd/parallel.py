@@ -238,13 +238,19 @@ def assert_replicas_agree(tree, alpha, beta, group=None):
 
 
 def sample_density_sharded(tree, no_cells, alpha=0.3, beta=2, scale=True, scale_v=0.7, scale_mean=0.,
-                           *, seed=None, group=None, strict=True):
+                           *, seed=None, group=None, strict=True, order="presented"):
     """``simulation.sample_density`` (simulation.py:416-471) across the ranks of ``group``.
 
     Returns ``(counts, cell_index, sample_pt, branches, scalings)``: ``counts`` is this rank's
     int32 device tensor (len(cell_index), G); the last three are the GLOBAL plan, identical on
     every rank.  ``counts[i]`` equals row ``cell_index[i]`` of the single-GPU result for the
     same seed.
+
+    ROW ORDER.  With ``order="presented"`` (default) the rank's cells are presented to the sampler grouped by their row of
+    the mean tensor (``simulation.draw_counts`` says why), and ``cell_index`` comes back in THAT order: it is NOT
+    ascending.  Label rows by ``sample_pt[cell_index]`` / ``branches[cell_index]`` -- never by a separately computed
+    ascending list of the rank's cells.  ``order="plan"`` presents the rank's cells in ascending plan position
+    (``cell_index`` ascending, as until round 4): 2 to 5 % slower, more HBM traffic on trees with many branches.
 
     EVERY rank draws the plan, the scalings and the default seed from its own numpy stream (the
     draws of the single-process call), then rank 0's values are broadcast: ranks that were seeded
@@ -270,10 +276,14 @@ def sample_density_sharded(tree, no_cells, alpha=0.3, beta=2, scale=True, scale_
     rows = sim.cell_rows(tree, pt[mine], br[mine])
     # the rank's cells are presented grouped by their row of the mean tensor (simulation.draw_counts says why); row i of
     # `counts` is the cell at position `mine[i]` of the plan, which is what every consumer of the pair goes by
+    if order not in ("presented", "plan"):
+        raise ValueError("order must be 'presented' or 'plan'")
     means = tree.device_means()
-    order = _device.plan_order(rows, means.shape[0])
-    mine = np.asarray(mine, dtype=np.int64)[order]
-    counts = ctx.sample_counts(means, rows[order], sc[mine], alpha, beta, seed=seed, cell_index=mine, check_domain=strict)
+    mine = np.asarray(mine, dtype=np.int64)
+    if order == "presented":
+        perm = _device.plan_order(rows, means.shape[0])
+        mine, rows = mine[perm], rows[perm]
+    counts = ctx.sample_counts(means, rows, sc[mine], alpha, beta, seed=seed, cell_index=mine, check_domain=strict)
     return counts, mine, pt, br, sc
 
 
@@ -391,19 +401,26 @@ def sample_and_gather(tree, no_cells, alpha=0.3, beta=2, scale=True, scale_v=0.7
             for src, lo, hi, buf in got:
                 out.index_copy_(0, torch.as_tensor(shards[src][lo:hi], dtype=torch.int64, device=dev), buf)
 
+    # A sender keeps at most two rounds of sends in flight (round r is posted once round r - 2 has left): the root posts
+    # round r's receives only after round r - 1 has arrived, and an unbounded queue of sends has nowhere to go on a
+    # backend with a fixed number of point-to-point channels.
     sends, pending = [], ([], [])
     for r in range(rounds):
         lo, hi = sample(r)                                   # enqueued; the transfers below are ordered behind it
         if size > 1 and not is_root and lo < hi:
-            sends += dist.batch_isend_irecv([dist.P2POp(dist.isend, local[lo:hi], peer(dst), group)])
+            if len(sends) >= 2:
+                for req in sends[-2]:
+                    req.wait()
+            sends.append(dist.batch_isend_irecv([dist.P2POp(dist.isend, local[lo:hi], peer(dst), group)]))
         if size > 1 and is_root:
             got, reqs = pending
             for req in reqs:
                 req.wait()
             pending = post_receives(r)                       # round r travels while round r + 1 is sampled
             land(got)                                        # (order="plan": round r - 1 is scattered under it)
-    for req in sends:
-        req.wait()
+    for reqs_ in sends[-2:]:
+        for req in reqs_:
+            req.wait()
     if is_root:
         got, reqs = pending
         for req in reqs:
@@ -418,11 +435,15 @@ def sample_and_gather(tree, no_cells, alpha=0.3, beta=2, scale=True, scale_v=0.7
 
 
 def gather_rows(local_rows, cell_index, total_rows, group=None, dst=0, chunk_rows=None, chunk_bytes=256 << 20,
-                to_host=False):
+                to_host=False, index_of_rank=None):
     """Collect row shards on rank ``dst`` (a rank of ``group``) into a (total_rows, G) tensor in global order.
 
     ``local_rows`` (n_local, G) and ``cell_index`` (n_local,) of every rank; returns the full
-    tensor on ``dst`` and None elsewhere.  Point-to-point (shards are unequal, so not a gather
+    tensor on ``dst`` and None elsewhere.  Only rows travel in the rounds: where a row goes is known before -- from
+    ``index_of_rank`` (the cell indices of EVERY rank's shard, in the order of its rows: every rank can derive them from
+    the broadcast plan, ``shards_in_presentation_order``: then nothing but rows is exchanged at all), else each sender's
+    index vector travels once, in front of its rows (8 B per row; until round 5 an index tensor went with every chunk, and
+    the shard sizes as pickled objects).  Point-to-point (shards are unequal, so not a gather
     collective), in rounds of ``chunk_rows`` rows per sender (default: ``chunk_bytes`` = 256 MB per
     sender, so the root stages 2 rounds x (size - 1) x 256 MB whatever G is): the root posts the
     receives of a round from ALL senders at once (``batch_isend_irecv``: every xGMI link of the root
@@ -463,8 +484,30 @@ def gather_rows(local_rows, cell_index, total_rows, group=None, dst=0, chunk_row
     def peer(r):                     # P2POp addresses GLOBAL ranks
         return dist.get_global_rank(group, r) if group is not None else r
 
-    sizes = [None] * size
-    dist.all_gather_object(sizes, int(local_rows.shape[0]), group=group)
+    comm_dev = local_rows.device
+    if index_of_rank is not None:
+        if len(index_of_rank) != size or len(index_of_rank[rank]) != local_rows.shape[0]:
+            raise ValueError("index_of_rank must hold one index vector per rank, this rank's as long as its rows")
+        sizes = [int(len(a)) for a in index_of_rank]
+        where = [torch.as_tensor(np.asarray(a), dtype=torch.int64, device=comm_dev) if rank == dst else None for a in index_of_rank]
+    else:
+        mine_n = torch.tensor([int(local_rows.shape[0])], dtype=torch.int64, device=comm_dev)
+        all_n = [torch.zeros(1, dtype=torch.int64, device=comm_dev) for _ in range(size)]
+        dist.all_gather(all_n, mine_n, group=group)
+        sizes = [int(t.item()) for t in all_n]
+        # every sender's index vector, once
+        where = [None] * size
+        if rank == dst:
+            ops = []
+            for src in range(size):
+                if src != dst and sizes[src]:
+                    where[src] = torch.empty(sizes[src], dtype=torch.int64, device=comm_dev)
+                    ops.append(dist.P2POp(dist.irecv, where[src], peer(src), group))
+            for req in (dist.batch_isend_irecv(ops) if ops else []):
+                req.wait()
+        elif sizes[rank]:
+            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, index.contiguous(), peer(dst), group)]):
+                req.wait()
     rounds = max((n + chunk_rows - 1) // chunk_rows for n in sizes) if max(sizes) else 0
     if rank != dst:
         rows = local_rows.contiguous()
@@ -472,9 +515,7 @@ def gather_rows(local_rows, cell_index, total_rows, group=None, dst=0, chunk_row
             lo, hi = r * chunk_rows, min((r + 1) * chunk_rows, sizes[rank])
             if lo >= hi:
                 break
-            ops = [dist.P2POp(dist.isend, index[lo:hi].contiguous(), peer(dst), group),
-                   dist.P2POp(dist.isend, rows[lo:hi], peer(dst), group)]
-            for req in dist.batch_isend_irecv(ops):
+            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, rows[lo:hi], peer(dst), group)]):
                 req.wait()
         return None
     if to_host:
@@ -491,10 +532,9 @@ def gather_rows(local_rows, cell_index, total_rows, group=None, dst=0, chunk_row
             n = min((r + 1) * chunk_rows, sizes[src]) - r * chunk_rows
             if src == dst or n <= 0:
                 continue
-            idx = torch.empty(n, dtype=torch.int64, device=local_rows.device)
             buf = torch.empty((n, G), dtype=local_rows.dtype, device=local_rows.device)
-            bufs.append((idx, buf))
-            ops += [dist.P2POp(dist.irecv, idx, peer(src), group), dist.P2POp(dist.irecv, buf, peer(src), group)]
+            bufs.append((where[src][r * chunk_rows:r * chunk_rows + n], buf))
+            ops.append(dist.P2POp(dist.irecv, buf, peer(src), group))
         return bufs, (dist.batch_isend_irecv(ops) if ops else [])
 
     pending = post(0) if rounds else ([], [])

@@ -149,7 +149,7 @@ def belongs_to(timezone, branch):
     return (timezone[0] >= branch[0]) and (timezone[1] <= branch[1])
 
 
-def pick_branches(tree, pseudotime, fix_density_index=False):
+def pick_branches(tree, pseudotime, *, fix_density_index=False):
     """Random branch for every pseudotime value (sim_utils.py:342-403).
 
     One uniform per cell is consumed, exactly like the reference's per-cell
@@ -218,7 +218,7 @@ def max_relat_exp(tree, relative_means):
 
 
 def simulate_base_gene_exp(tree, relative_means, abs_max=5000, gene_mean=0.8, gene_std=1,
-                           max_attempts=None):
+                           *, max_attempts=None):
     """Base expression per gene: redraw exp(N(gene_mean, gene_std)) until
     ``value * max relative expression <= abs_max`` (sim_utils.py:429-470).
 

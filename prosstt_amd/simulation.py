@@ -437,16 +437,20 @@ def sample_density(tree, no_cells, alpha=0.3, beta=2, scale=True, scale_v=0.7, s
 
 
 def sample_density_chunks(tree, no_cells, chunk_cells, alpha=0.3, beta=2, scale=True, scale_v=0.7, scale_mean=0.,
-                          *, seed=None, out="numpy32", strict=True):
+                          *, seed=None, out="numpy32", strict=True, order="presented"):
     """``sample_density`` (simulation.py:416-471) for matrices that should not exist whole on the host -- or
     not all at once: a generator of ``(counts, pseudotime, branches, scalings)`` for successive ranges of
     ``chunk_cells`` cells of ONE plan (drawn up front, with the reference's numpy calls).  Chunk i + 1 is
     sampled on the device while chunk i travels to the host; every count equals the one the single call
     returns for that cell (the sampler is keyed by the cell's position in the plan), so the chunks
-    concatenate to ``sample_density``'s matrix.  ``out``: as in ``draw_counts`` ("torch" yields device
-    tensors that the consumer must be done with before asking for the next chunk but one)."""
+    concatenate to ``sample_density``'s matrix.  ``out``, ``order``: as in ``draw_counts`` ("torch" yields
+    ``device.PresentedCounts`` -- the chunk's device tensor in the order its cells were presented, and the permutation --
+    or, with ``order="plan"``, plain device tensors in plan order; the consumer must be done with a chunk before asking
+    for the next chunk but one)."""
     if out != "torch" and out not in _HOST_DTYPES:
         raise ValueError("out must be 'numpy', 'numpy32', 'numpy16' or 'torch'")
+    if order not in ("presented", "plan"):
+        raise ValueError("order must be 'presented' or 'plan'")
     if chunk_cells <= 0:
         raise ValueError("chunk_cells must be positive")
     alpha, beta = (np.full(tree.G, v, dtype=np.float64) if np.ndim(v) == 0 else np.asarray(v, dtype=np.float64)
@@ -464,30 +468,36 @@ def sample_density_chunks(tree, no_cells, chunk_cells, alpha=0.3, beta=2, scale=
     def launch(lo):
         # (presented grouped by mean-tensor row, put back in plan order inside the copy to the host: see draw_counts)
         hi = min(lo + chunk_cells, no_cells)
-        if out == "torch":
+        if out == "torch" and order == "plan":
             return ctx.sample_counts(means, rows[lo:hi], scalings[lo:hi], alpha, beta, seed=seed, cell_offset=lo,
                                      check_domain="deferred" if strict else False, means_token=token), None
-        order = _device.plan_order(rows[lo:hi], means.shape[0])
-        return ctx.sample_counts(means, rows[lo:hi][order], scalings[lo:hi][order], alpha, beta, seed=seed,
-                                 cell_index=lo + order.astype(np.int64),
-                                 check_domain="deferred" if strict else False, means_token=token), order
+        perm = _device.plan_order(rows[lo:hi], means.shape[0])
+        return ctx.sample_counts(means, rows[lo:hi][perm], scalings[lo:hi][perm], alpha, beta, seed=seed,
+                                 cell_index=lo + perm.astype(np.int64),
+                                 check_domain="deferred" if strict else False, means_token=token), perm
 
     # The verdict of the deferred domain check is sticky in the ctx and covers every chunk enqueued so far (an invalid
     # chunk i + 1 may already be reported with chunk i: the plan is one call).  Whatever ends the generator -- exhaustion,
     # an exception of the host copy, the consumer dropping it -- leaves no verdict behind for an unrelated later call.
+    # (verdict_open: a checked launch has been enqueued whose verdict nobody has read yet)
+    verdict_open = False
     pending = launch(0) if no_cells else None
+    verdict_open = strict and pending is not None
     try:
         for lo in range(0, no_cells, chunk_cells):
             hi = min(lo + chunk_cells, no_cells)
-            counts, order = pending
+            counts, perm = pending
             pending = launch(hi) if hi < no_cells else None      # enqueued behind `counts`, runs under its copy
-            host = counts if out == "torch" else _to_host(counts, _HOST_DTYPES[out], row_order=order)
+            if out == "torch":
+                host = counts if perm is None else _device.PresentedCounts(counts, perm)
+            else:
+                host = _to_host(counts, _HOST_DTYPES[out], row_order=perm)
             if strict:
                 ctx.domain_status()
+                verdict_open = pending is not None               # (the next chunk's launch is already behind it)
             yield host, sample_time[lo:hi], sample_branches[lo:hi], scalings[lo:hi]
-        pending = None
     finally:
-        if strict and pending is not None:
+        if verdict_open:
             _discard_verdict(ctx)
 
 
@@ -547,13 +557,13 @@ def cell_rows(tree, pseudotime, branches):
 
 
 def draw_counts(tree, pseudotime, branches, scalings, alpha, beta, *, seed=None, out="numpy",
-                strict=True):
+                strict=True, order="presented"):
     """UMI counts of every cell and gene (simulation.py:602-651).
 
     One launch of the fused HIP sampler: gather the cell's row of the mean tensor,
     scale it, form the negative-binomial parameters of ``count_model.get_pr_umi`` and
     draw.  Counts follow the reference's law, NB(n = r, p = 1 - p); the random
-    stream is the counter-based PRNB-6, not numpy's MT19937,
+    stream is the counter-based PRNB-7, not numpy's MT19937,
     so individual values differ from the reference at equal numpy seed.
 
     New keyword-only options
@@ -561,7 +571,14 @@ def draw_counts(tree, pseudotime, branches, scalings, alpha, beta, *, seed=None,
               stream, so ``np.random.seed`` still determines the whole simulation.
       out     "numpy" (default): int64 ndarray like the reference; "numpy32": int32 (what the
               device holds -- half the bytes over PCIe); "numpy16": uint16 (a quarter; OverflowError
-              if a count does not fit); "torch": the int32 device tensor, no host copy.
+              if a count does not fit); "torch": no host copy -- the int32 device matrix as ``device.PresentedCounts``
+              (see ``order``).
+      order   (with out="torch"; host arrays always come back in plan order) "presented" (default): the matrix as it
+              lies on the device -- the cells are presented to the sampler grouped by their row of the mean tensor, which
+              keeps a gene tile's rows of the tensor in cache -- with the permutation: ``counts, cell_of_row = result``,
+              row i belongs to cell ``cell_of_row[i]``; ``result.in_plan_order()`` gathers.  "plan": a plain device
+              tensor whose row n is cell n; the cells are then presented as planned (2 to 5 % slower, and on a
+              32-branch tree 1.75 x the HBM traffic: the mean tensor's rows are fetched once per cell).
       strict  raise ``ValueError`` where scipy's argument check would (an exact-zero
               mean, or alpha*m + beta < 1); the test rides in the call's own kernels (the per-row flags of
               the mean tensor are kept until the tensor changes) and costs no launch and no extra
@@ -579,10 +596,12 @@ def draw_counts(tree, pseudotime, branches, scalings, alpha, beta, *, seed=None,
         raise ValueError("out must be 'numpy', 'numpy32', 'numpy16' or 'torch'")
     # the domain check rides in the call's own kernels and is not waited for; its verdict is read behind the copy to the
     # host (which synchronises anyway), or at once when the device tensor itself is returned
+    if order not in ("presented", "plan"):
+        raise ValueError("order must be 'presented' or 'plan'")
     token = tree.means_token()
     means = tree.device_means()
     scalings = np.asarray(scalings, dtype=np.float64)
-    if out == "torch":
+    if out == "torch" and order == "plan":
         counts = ctx.sample_counts(means, rows, scalings, np.asarray(alpha, dtype=np.float64), np.asarray(beta, dtype=np.float64),
                                    seed=seed, check_domain="deferred" if strict else False, means_token=token)
         if strict:
@@ -593,12 +612,16 @@ def draw_counts(tree, pseudotime, branches, scalings, alpha, beta, *, seed=None,
     # tile's rows of the mean tensor in cache instead of fetching them once per cell, 2 to 5 % of its time
     # (profiles/r05_ablation.txt).  The device matrix is in the order of presentation; the copy to the host puts the rows
     # back in plan order chunk by chunk (a gather on the device, under the transfer of the previous chunk).
-    order = _device.plan_order(rows, means.shape[0])
-    counts = ctx.sample_counts(means, rows[order], scalings[order], np.asarray(alpha, dtype=np.float64),
-                               np.asarray(beta, dtype=np.float64), seed=seed, cell_index=order.astype(np.int64),
+    perm = _device.plan_order(rows, means.shape[0])
+    counts = ctx.sample_counts(means, rows[perm], scalings[perm], np.asarray(alpha, dtype=np.float64),
+                               np.asarray(beta, dtype=np.float64), seed=seed, cell_index=perm.astype(np.int64),
                                check_domain="deferred" if strict else False, means_token=token)
+    if out == "torch":
+        if strict:
+            ctx.domain_status()
+        return _device.PresentedCounts(counts, perm)
     try:
-        host = _to_host(counts, _HOST_DTYPES[out], row_order=order)
+        host = _to_host(counts, _HOST_DTYPES[out], row_order=perm)
     except BaseException:
         if strict:
             _discard_verdict(ctx)       # (an OverflowError of "numpy16", a failed page-lock: the call's verdict must not outlive it)

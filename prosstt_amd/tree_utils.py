@@ -65,9 +65,12 @@ def save_matrices(job_id, save_dir, X, uMs, H):
 def save_matrices_npz(job_id, save_dir, X, uMs=None, H=None, compressed=False):
     """Binary alternative to ``save_matrices`` for matrices the text format cannot carry (the 50 000 x
     20 000 headline matrix is 4 GB as int32 and several times that as text): one
-    ``<save_dir>/<job_id>_simulation.npz`` holding ``X`` as int32 (an int32 device tensor -- what
-    ``draw_counts(..., out="torch")`` returns -- is copied to the host as it is, never widened to
-    int64), ``H`` and ``ums<branch>`` when given.  Row i is cell_i, column j gene_j, as in the text file."""
+    ``<save_dir>/<job_id>_simulation.npz`` holding ``X`` as int32 (an int32 device tensor, or the
+    ``device.PresentedCounts`` that ``draw_counts(..., out="torch")`` returns -- its rows are put back in plan order
+    inside the copy -- travels to the host as it is, never widened to int64), ``H`` and ``ums<branch>`` when given.
+    Row i is cell_i, column j gene_j, as in the text file."""
+    if hasattr(X, "cell_of_row") and hasattr(X, "to_host"):      # device.PresentedCounts
+        X = X.to_host("numpy32")
     if hasattr(X, "detach"):                         # torch tensor
         X = X.detach().cpu().numpy()
     X = np.asarray(X)

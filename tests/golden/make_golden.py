@@ -235,7 +235,10 @@ def g7_nb_tables():
             (60.0, 0.2, 2.0), (75.0, 0.1, 3.0), (80.0, 0.1, 3.0), (106.0, 0.0, 17.0), (40.0, 0.37, 2.0),
             (44.0, 0.37, 2.0), (25.0, 0.02, 1.3),
             # PRNB-6: the inversion class up to theta <= 24 -- its new corner (long walks), the middle of the new range, just outside by -log P0
-            (135.0, 0.163, 2.0), (100.0, 0.2, 2.0), (140.0, 0.157, 2.0), (60.0, 0.38, 1.2)]
+            (135.0, 0.163, 2.0), (100.0, 0.2, 2.0), (140.0, 0.157, 2.0), (60.0, 0.38, 1.2),
+            # round 6: tiny means, where the binary32 P(X = 0) is relatively weakest (and the Poisson limit)
+            (1e-4, 0.2, 2.0), (1e-3, 0.2, 2.0), (1e-2, 0.2, 2.0), (1e-4, 0.0, 1.0 + 1e-8), (1e-3, 0.0, 1.0 + 1e-8),
+            (1e-2, 0.0, 1.0 + 1e-8)]
     kmax = 4096
     k = np.arange(kmax)
     pmf = np.zeros((len(grid), kmax))

@@ -168,8 +168,8 @@ def test_minimal_example_and_alias():
         np.testing.assert_array_equal(sc, g["scalings"])
         assert abs(X.sum() - int(g["total"])) < 0.1 * int(g["total"])
         import torch
-        Xd = sim.draw_counts(t, pt, br, sc, [0.2] * t.G, [3.0] * t.G, seed=5, out="torch")
-        assert Xd.dtype == torch.int32 and Xd.is_cuda
+        Xd, cell_of_row = sim.draw_counts(t, pt, br, sc, [0.2] * t.G, [3.0] * t.G, seed=5, out="torch")
+        assert Xd.dtype == torch.int32 and Xd.is_cuda and sorted(cell_of_row.tolist()) == list(range(80))
         with pytest.raises(ValueError):       # exact-zero mean -> scipy's domain error in the reference
             t.means = {b: np.zeros((40, 500)) for b in t.branches}
             sim.draw_counts(t, pt, br, sc, [0.2] * t.G, [3.0] * t.G)
@@ -286,3 +286,45 @@ def test_secondary_samplers_counts_bit_exact_vs_model():
     want = nb_model.sample_counts(base[:extra].astype(np.float32).reshape(1, extra), np.zeros(150, np.int32),
                                   sc, alpha[:extra], beta[:extra], 105)
     np.testing.assert_array_equal(wide[:, G:], want)
+
+
+def test_device_returns_present_cells_grouped_and_carry_the_permutation():
+    """out="torch": the default return is the matrix as it lies on the device -- cells presented grouped by their row of the
+    mean tensor (the regime bench.py times) -- with the permutation; order="plan" presents the cells as planned.  Both hold
+    the same counts, bit for bit: grouped return + permutation == plan-order return == the host array; the chunked
+    generator yields the same, chunk by chunk."""
+    import torch
+    from prosstt_amd import device, simulation as sim, workloads
+    work = workloads.build("C2", G=1024)
+    t, al, be = work.tree, work.alpha, work.beta
+    np.random.seed(21)
+    planned, pt, br, sc = sim.sample_density(t, 1500, alpha=al, beta=be, seed=17, out="torch", order="plan")
+    np.random.seed(21)
+    presented, pt2, br2, sc2 = sim.sample_density(t, 1500, alpha=al, beta=be, seed=17, out="torch")
+    np.random.seed(21)
+    host = sim.sample_density(t, 1500, alpha=al, beta=be, seed=17, out="numpy32")[0]
+    assert isinstance(presented, device.PresentedCounts) and torch.is_tensor(planned)
+    np.testing.assert_array_equal(pt, pt2)
+    counts, cell_of_row = presented
+    assert counts.shape == (1500, 1024) == presented.shape and sorted(cell_of_row.tolist()) == list(range(1500))
+    rows = sim.cell_rows(t, pt, br)
+    assert (np.diff(rows[cell_of_row]) >= 0).all() and (np.diff(rows) < 0).any()      # grouped by row; the plan is not
+    assert torch.equal(counts, planned[torch.as_tensor(cell_of_row, device=planned.device)])
+    assert torch.equal(presented.in_plan_order(), planned)
+    np.testing.assert_array_equal(presented.to_host("numpy32"), host)
+    np.testing.assert_array_equal(planned.cpu().numpy(), host)
+    with pytest.raises(ValueError):
+        sim.sample_density(t, 10, alpha=al, beta=be, seed=17, out="torch", order="sorted")
+    for order in ("presented", "plan"):
+        np.random.seed(21)
+        got = np.empty_like(host)
+        lo = 0
+        for part, ppt, pbr, psc in sim.sample_density_chunks(t, 1500, 400, alpha=al, beta=be, seed=17, out="torch", order=order):
+            hi = lo + len(ppt)
+            if order == "presented":
+                c, perm = part
+                got[lo + perm] = c.cpu().numpy()
+            else:
+                got[lo:hi] = part.cpu().numpy()
+            lo = hi
+        np.testing.assert_array_equal(got, host)

@@ -1,7 +1,7 @@
 """
 -m gpu: the HIP count sampler (K3) against the oracle, through the C ABI.
 
- * counts: BIT-EXACT against oracle/nb_model.c (the scalar C model of PRNB-6, reading the device's own tables of v_rcp/v_log/v_exp) on the
+ * counts: BIT-EXACT against oracle/nb_model.c (the scalar C model of PRNB-7, reading the device's own tables of v_rcp/v_log/v_exp and asking it for the gamma-Poisson class's transcendentals) on the
    same seeded inputs -- integer work, no tolerance;
  * (mu, p, r): bit-exact against the model AND within rtol 1e-6 of the reference's
    float64 get_pr_umi (count_model.py:156-158) -- the stated fp32 tolerance;

@@ -37,7 +37,7 @@ def test_sample_density_sharded_single_process_equals_sample_density():
     from prosstt_amd import parallel, simulation as sim, workloads
     work = workloads.build("C2", G=512)
     np.random.seed(5)
-    X, pt, br, sc = sim.sample_density(work.tree, 700, alpha=work.alpha, beta=work.beta, seed=9, out="torch")
+    X, pt, br, sc = sim.sample_density(work.tree, 700, alpha=work.alpha, beta=work.beta, seed=9, out="torch", order="plan")
     np.random.seed(5)
     counts, idx, pt2, br2, sc2 = parallel.sample_density_sharded(work.tree, 700, alpha=work.alpha, beta=work.beta, seed=9)
     np.testing.assert_array_equal(pt, pt2)
@@ -54,7 +54,7 @@ def test_sample_and_gather_single_process_equals_sample_density():
     from prosstt_amd import parallel, simulation as sim, workloads
     work = workloads.build("C2", G=512)
     np.random.seed(5)
-    X, pt, br, sc = sim.sample_density(work.tree, 700, alpha=work.alpha, beta=work.beta, seed=9, out="torch")
+    X, pt, br, sc = sim.sample_density(work.tree, 700, alpha=work.alpha, beta=work.beta, seed=9, out="torch", order="plan")
     np.random.seed(5)
     full, cell_of_row, pt2, br2, sc2 = parallel.sample_and_gather(work.tree, 700, alpha=work.alpha, beta=work.beta, seed=9, chunk_cells=128)
     np.testing.assert_array_equal(pt, pt2)

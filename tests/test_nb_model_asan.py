@@ -2,7 +2,7 @@
 CPU: the scalar model of the count sampler under AddressSanitizer / UBSan at the corner of the inversion class
 (theta = 24, -log P(X = 0) just under 19: means around 141, tail ratio 24/25; PRNB-5's corner at theta = 16 as well), where walks are longest.  Round 3's
 definition let a walk run past its 1/k table there (a read beyond the table in the model, beyond the LDS copy on the
-device); PRNB-5 / PRNB-6 end every walk at k = 1022 and the table covers it.  The driver below is compiled together with
+device); PRNB-5 / PRNB-6 end every walk at k = 1022, PRNB-7 at k = 1024, and the table covers it.  The driver below is compiled together with
 oracle/nb_model.c (no GPU: the libm stand-ins of the three hardware functions).
 """
 import os

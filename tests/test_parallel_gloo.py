@@ -168,6 +168,17 @@ def _worker_sharded(rank, world_size, port, tmpdir, same_seed):
             assert full is None
         other = parallel.gather_rows(counts, mine, N, dst=1, chunk_rows=1000)      # another root, one round
         assert (other is not None) == (rank == 1)
+        # nothing but rows exchanged: every rank derives every shard's cell indices from the broadcast plan
+        layout = parallel.shards_in_presentation_order(t, pt, br, world_size)
+        assert np.array_equal(layout[rank], mine)
+        known = parallel.gather_rows(counts, mine, N, chunk_rows=16, index_of_rank=layout)
+        assert torch.equal(known, want) if rank == 0 else known is None
+        # (order="plan": the rank's cells in ascending plan position, as until round 4)
+        np.random.seed(77)
+        c_plan, mine_plan, _, _, _ = parallel.sample_density_sharded(t, N, seed=3, order="plan")
+        assert np.array_equal(mine_plan, np.sort(mine)) and (len(mine) < 2 or (np.diff(mine_plan) > 0).all())
+        again = parallel.gather_rows(c_plan, mine_plan, N)
+        assert torch.equal(again, want) if rank == 0 else again is None
         # the same gather assembled in host memory on the root (a result too large for one device)
         on_host = parallel.gather_rows(counts, mine, N, chunk_rows=16, to_host=True)
         if rank == 0:
