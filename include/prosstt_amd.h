@@ -36,7 +36,8 @@ enum {
     PROSSTT_AMD_EDOMAIN = -2, /* a mean <= 0 or a*m+b < 1 (the reference raises ValueError there) */
     PROSSTT_AMD_EHIP = -3,    /* HIP runtime error */
     PROSSTT_AMD_ENOMEM = -4,
-    PROSSTT_AMD_ENODEV = -5   /* no gfx950 device visible */
+    PROSSTT_AMD_ENODEV = -5,  /* no gfx950 device visible */
+    PROSSTT_AMD_ERCCL = -6    /* RCCL could not be opened, or reported an error (prosstt_amd_comm_*, prosstt_amd_gather_counts) */
 };
 
 /* flags of prosstt_amd_sample_counts / prosstt_amd_nb_params */
@@ -161,6 +162,36 @@ int prosstt_amd_hw_math(prosstt_amd_ctx* ctx, int32_t op, uint32_t first_bits, u
  */
 int prosstt_amd_hw_math_at(prosstt_amd_ctx* ctx, int32_t op, const float* x, uint64_t count, float* out,
                            uint32_t flags);
+
+/*
+ * Multi-GPU at the C boundary: the ONE exchange of the path (SURVEY.md section 8 b/e) -- count rows of every rank's shard to
+ * one root, point-to-point over xGMI -- on RCCL directly, for host bindings that do not go through torch.distributed
+ * (prosstt_amd/parallel.py is the Python form of the same exchange).  One process per GPU.  The reference has no
+ * multi-device path at all: its draw_counts (simulation.py:602-651) fills one (N, G) matrix in one process.
+ *
+ *   prosstt_amd_comm_unique_id   rank 0 makes the 128-byte id; the caller carries it to the other ranks by whatever it
+ *                                has (MPI, a file, a socket): the library has no bootstrap of its own.
+ *   prosstt_amd_comm_init        collective over the `world` ranks; the communicator works on ctx's device and stream.
+ *   prosstt_amd_gather_counts    every rank: `local_rows` = its n_local x G int32 counts (DEVICE, contiguous rows) and
+ *                                rows_of_rank[world] (HOST: how many rows every rank holds -- each rank derives that from
+ *                                the plan all ranks share).  On `root`, dst (DEVICE, (sum of rows) x G) receives rank r's
+ *                                rows at row offset rows_of_rank[0] + ... + rows_of_rank[r-1] -- shard order, as
+ *                                parallel.sample_and_gather(order="shard"); every sender is received at once (one RCCL
+ *                                group: every xGMI link of the root carries data).  dst is ignored on the other ranks.
+ *                                Enqueued on ctx's stream, not waited for.
+ *   prosstt_amd_comm_selftest    one send / receive of `bytes` bytes from this rank to itself through RCCL, compared on the
+ *                                host: the communicator moves data on this machine (works with world = 1).
+ * RCCL is opened when the first of these is called (librccl.so.1 of the process, i.e. torch's when torch is loaded);
+ * PROSSTT_AMD_ERCCL when it cannot be opened or reports an error.
+ */
+typedef struct prosstt_amd_comm prosstt_amd_comm;
+#define PROSSTT_AMD_COMM_ID_BYTES 128
+int prosstt_amd_comm_unique_id(void* id_out);
+int prosstt_amd_comm_init(prosstt_amd_ctx* ctx, const void* id, int32_t rank, int32_t world, prosstt_amd_comm** out);
+int prosstt_amd_comm_destroy(prosstt_amd_comm* comm);
+int prosstt_amd_gather_counts(prosstt_amd_ctx* ctx, prosstt_amd_comm* comm, const int32_t* local_rows,
+                              const int64_t* rows_of_rank, int32_t G, int32_t root, int32_t* dst);
+int prosstt_amd_comm_selftest(prosstt_amd_ctx* ctx, prosstt_amd_comm* comm, uint64_t bytes);
 
 /*
  * Host only (no device, no ctx): the variates of `attempts` consecutive simulation.sim_expr_branch(T, K) calls

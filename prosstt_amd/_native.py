@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PROSSTT_AMD_LIB") or os.path.join(_HERE, "lib", "libprosstt_amd.so")
 
-OK, EINVAL, EDOMAIN, EHIP, ENOMEM, ENODEV = 0, -1, -2, -3, -4, -5
+OK, EINVAL, EDOMAIN, EHIP, ENOMEM, ENODEV, ERCCL = 0, -1, -2, -3, -4, -5, -6
 HOST_INPUTS, HOST_OUTPUT, CHECK_DOMAIN, TIME_KERNEL, CHECK_DEFERRED, MEANS_CACHED, PARAMS_NONNEG = 1, 2, 4, 8, 16, 32, 64
 
 # every symbol include/prosstt_amd.h declares
@@ -20,7 +20,8 @@ SYMBOLS = [
     "prosstt_amd_version", "prosstt_amd_last_error", "prosstt_amd_device_count",
     "prosstt_amd_ctx_create", "prosstt_amd_ctx_destroy", "prosstt_amd_ctx_synchronize",
     "prosstt_amd_last_kernel_ms", "prosstt_amd_sample_counts", "prosstt_amd_plan_order", "prosstt_amd_last_list", "prosstt_amd_nb_params",
-    "prosstt_amd_hw_math", "prosstt_amd_hw_math_at", "prosstt_amd_domain_status", "prosstt_amd_numpy_programs",
+    "prosstt_amd_hw_math", "prosstt_amd_hw_math_at", "prosstt_amd_comm_unique_id", "prosstt_amd_comm_init", "prosstt_amd_comm_destroy",
+    "prosstt_amd_gather_counts", "prosstt_amd_comm_selftest", "prosstt_amd_domain_status", "prosstt_amd_numpy_programs",
     "prosstt_amd_lineage_attempt", "prosstt_amd_lineage_attempt_batch", "prosstt_amd_lineage_walk",
     "prosstt_amd_lineage_walk_batch",
     "prosstt_amd_lineage_commit",
@@ -72,6 +73,11 @@ def load():
         L.prosstt_amd_nb_params.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp, u32]
         L.prosstt_amd_hw_math.argtypes = [vp, i32, u32, u64, vp, u32]
         L.prosstt_amd_hw_math_at.argtypes = [vp, i32, vp, u64, vp, u32]
+        L.prosstt_amd_comm_unique_id.argtypes = [vp]
+        L.prosstt_amd_comm_init.argtypes = [vp, vp, i32, i32, ctypes.POINTER(vp)]
+        L.prosstt_amd_comm_destroy.argtypes = [vp]
+        L.prosstt_amd_gather_counts.argtypes = [vp, vp, vp, vp, i32, i32, vp]
+        L.prosstt_amd_comm_selftest.argtypes = [vp, vp, u64]
         L.prosstt_amd_domain_status.argtypes = [vp, ctypes.POINTER(i32)]
         L.prosstt_amd_numpy_programs.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
         L.prosstt_amd_lineage_attempt.argtypes = [vp, vp, i32, i32, vp, i64, i32, vp, vp, vp, vp]

@@ -1101,6 +1101,155 @@ PA_EXPORT int prosstt_amd_hw_math_at(prosstt_amd_ctx* c, int32_t op, const float
 }
 PA_CATCH
 
+// ------------------------------------------------------------------ the exchange on RCCL (include/prosstt_amd.h)
+// RCCL is opened at first use (dlopen: a process that never calls these never loads it, and one that has torch loaded
+// gets torch's copy by its soname).
+#include <dlfcn.h>
+namespace rccl {
+typedef struct { char internal[128]; } UniqueId;
+typedef void* Comm;
+enum { kInt32 = 2, kUint8 = 1 };
+static int (*GetUniqueId)(UniqueId*) = nullptr;
+static int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
+static int (*CommDestroy)(Comm) = nullptr;
+static int (*Send)(const void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+static int (*Recv)(void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+static int (*GroupStart)() = nullptr;
+static int (*GroupEnd)() = nullptr;
+static const char* (*GetErrorString)(int) = nullptr;
+static bool open()
+{
+    if (GroupEnd) return true;
+    void* h = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+        if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) return false;
+    auto sym = [&](const char* n) { return dlsym(h, n); };
+    GetUniqueId = (int (*)(UniqueId*))sym("ncclGetUniqueId");
+    CommInitRank = (int (*)(Comm*, int, UniqueId, int))sym("ncclCommInitRank");
+    CommDestroy = (int (*)(Comm))sym("ncclCommDestroy");
+    Send = (int (*)(const void*, size_t, int, int, Comm, hipStream_t))sym("ncclSend");
+    Recv = (int (*)(void*, size_t, int, int, Comm, hipStream_t))sym("ncclRecv");
+    GroupStart = (int (*)())sym("ncclGroupStart");
+    GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+    auto ge = (int (*)())sym("ncclGroupEnd");
+    if (!GetUniqueId || !CommInitRank || !CommDestroy || !Send || !Recv || !GroupStart || !ge) return false;
+    GroupEnd = ge;
+    return true;
+}
+}  // namespace rccl
+
+struct prosstt_amd_comm { rccl::Comm comm = nullptr; int32_t rank = 0, world = 1; };
+
+#define RCCL_TRY(expr)                                                                                   \
+    do {                                                                                                 \
+        int r_ = (expr);                                                                                 \
+        if (r_ != 0) return fail(PROSSTT_AMD_ERCCL, "%s: %s", #expr, rccl::GetErrorString ? rccl::GetErrorString(r_) : "RCCL error"); \
+    } while (0)
+
+PA_EXPORT int prosstt_amd_comm_unique_id(void* id_out) try
+{
+    if (!id_out) return fail(PROSSTT_AMD_EINVAL, "NULL argument");
+    if (!rccl::open()) return fail(PROSSTT_AMD_ERCCL, "librccl.so.1 could not be opened: %s", dlerror());
+    rccl::UniqueId id;
+    RCCL_TRY(rccl::GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof(id));
+    return 0;
+}
+PA_CATCH
+
+PA_EXPORT int prosstt_amd_comm_init(prosstt_amd_ctx* c, const void* id, int32_t rank, int32_t world, prosstt_amd_comm** out) try
+{
+    if (!c || !id || !out) return fail(PROSSTT_AMD_EINVAL, "NULL argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(PROSSTT_AMD_EINVAL, "rank %d of %d", rank, world);
+    if (!rccl::open()) return fail(PROSSTT_AMD_ERCCL, "librccl.so.1 could not be opened: %s", dlerror());
+    HIP_TRY(hipSetDevice(c->device));
+    rccl::UniqueId uid;
+    memcpy(&uid, id, sizeof(uid));
+    prosstt_amd_comm* k = new prosstt_amd_comm;
+    k->rank = rank;
+    k->world = world;
+    const int r = rccl::CommInitRank(&k->comm, world, uid, rank);
+    if (r != 0) {
+        delete k;
+        return fail(PROSSTT_AMD_ERCCL, "ncclCommInitRank: %s", rccl::GetErrorString ? rccl::GetErrorString(r) : "RCCL error");
+    }
+    *out = k;
+    return 0;
+}
+PA_CATCH
+
+PA_EXPORT int prosstt_amd_comm_destroy(prosstt_amd_comm* k) try
+{
+    if (!k) return 0;
+    if (k->comm && rccl::CommDestroy) (void)rccl::CommDestroy(k->comm);
+    delete k;
+    return 0;
+}
+PA_CATCH
+
+PA_EXPORT int prosstt_amd_gather_counts(prosstt_amd_ctx* c, prosstt_amd_comm* k, const int32_t* local_rows,
+                                        const int64_t* rows_of_rank, int32_t G, int32_t root, int32_t* dst) try
+{
+    if (!c || !k || !rows_of_rank) return fail(PROSSTT_AMD_EINVAL, "NULL argument");
+    if (G < 0 || root < 0 || root >= k->world) return fail(PROSSTT_AMD_EINVAL, "bad G or root");
+    for (int32_t r = 0; r < k->world; ++r)
+        if (rows_of_rank[r] < 0) return fail(PROSSTT_AMD_EINVAL, "rows_of_rank[%d] is negative", r);
+    const int64_t mine = rows_of_rank[k->rank];
+    if (mine > 0 && G > 0 && !local_rows) return fail(PROSSTT_AMD_EINVAL, "local_rows is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    if (k->rank != root) {
+        if (mine > 0 && G > 0) RCCL_TRY(rccl::Send(local_rows, (size_t)mine * G, rccl::kInt32, root, k->comm, c->stream));
+        return 0;
+    }
+    if (!dst) return fail(PROSSTT_AMD_EINVAL, "dst is NULL on the root");
+    // every sender at once: one group, so that every link of the root carries data; the root's own rows are a local copy
+    RCCL_TRY(rccl::GroupStart());
+    int64_t first = 0;
+    int err = 0;
+    for (int32_t r = 0; r < k->world && !err; ++r) {
+        if (r != root && rows_of_rank[r] > 0 && G > 0)
+            err = rccl::Recv(dst + first * G, (size_t)rows_of_rank[r] * G, rccl::kInt32, r, k->comm, c->stream);
+        first += rows_of_rank[r];
+    }
+    const int end = rccl::GroupEnd();
+    if (err) RCCL_TRY(err);
+    RCCL_TRY(end);
+    first = 0;
+    for (int32_t r = 0; r < root; ++r) first += rows_of_rank[r];
+    if (mine > 0 && G > 0)
+        HIP_TRY(hipMemcpyAsync(dst + first * G, local_rows, (size_t)mine * G * 4, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+PA_CATCH
+
+PA_EXPORT int prosstt_amd_comm_selftest(prosstt_amd_ctx* c, prosstt_amd_comm* k, uint64_t bytes) try
+{
+    if (!c || !k) return fail(PROSSTT_AMD_EINVAL, "NULL argument");
+    if (bytes == 0 || bytes > ((uint64_t)1 << 30)) return fail(PROSSTT_AMD_EINVAL, "1 .. 2^30 bytes");
+    HIP_TRY(hipSetDevice(c->device));
+    Staging st;
+    void *src = nullptr, *dstb = nullptr;
+    int rc;
+    if ((rc = st.alloc(&src, bytes)) || (rc = st.alloc(&dstb, bytes))) return rc;
+    std::vector<unsigned char> pattern(bytes), back(bytes, 0);
+    for (uint64_t i = 0; i < bytes; ++i) pattern[i] = (unsigned char)((i * 2654435761u) >> 13);
+    HIP_TRY(hipMemcpyAsync(src, pattern.data(), bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(dstb, 0, bytes, c->stream));
+    RCCL_TRY(rccl::GroupStart());
+    const int e1 = rccl::Send(src, bytes, rccl::kUint8, k->rank, k->comm, c->stream);
+    const int e2 = rccl::Recv(dstb, bytes, rccl::kUint8, k->rank, k->comm, c->stream);
+    const int e3 = rccl::GroupEnd();
+    RCCL_TRY(e1);
+    RCCL_TRY(e2);
+    RCCL_TRY(e3);
+    HIP_TRY(hipMemcpyAsync(back.data(), dstb, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (memcmp(back.data(), pattern.data(), bytes) != 0) return fail(PROSSTT_AMD_ERCCL, "the bytes RCCL delivered differ from the ones sent");
+    return 0;
+}
+PA_CATCH
+
 PA_EXPORT int prosstt_amd_numpy_programs(uint32_t* mt_words, int32_t* mt_next, int32_t* has_gauss, double* gauss,
                                          int32_t attempts, int32_t T, int32_t K, double* start, double* vel0, double* eta,
                                          double* noise, uint32_t* after_words, int32_t* after_next,

@@ -404,6 +404,59 @@ def to_host(counts, dtype=np.int64, chunk_bytes=256 << 20, row_order=None):
     return out.view(np.uint16) if dtype.itemsize == 2 else out
 
 
+class Comm:
+    """The one exchange of the path on RCCL directly, through the C ABI (prosstt_amd_comm_* / prosstt_amd_gather_counts:
+    what a host binding without torch.distributed uses; prosstt_amd.parallel is the torch.distributed form).
+
+        uid = Comm.unique_id()                 # on rank 0; carry the 128 bytes to the other ranks yourself
+        comm = Comm(ctx, uid, rank, world)     # collective
+        full = comm.gather_counts(counts, rows_of_rank, root=0)      # (sum(rows_of_rank), G) on the root, None elsewhere:
+                                                                     # rank 0's rows, then rank 1's, ... (shard order)
+    """
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(128)
+        _native.check(_native.load().prosstt_amd_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, ctx, unique_id, rank, world):
+        if len(unique_id) != 128:
+            raise ValueError("the unique id is 128 bytes")
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        self._lib = _native.load()
+        self._h = ctypes.c_void_p()
+        _native.check(self._lib.prosstt_amd_comm_init(ctx._h, ctypes.c_char_p(unique_id), self.rank, self.world,
+                                                      ctypes.byref(self._h)))
+
+    def gather_counts(self, counts, rows_of_rank, root=0):
+        torch = _torch()
+        rows_of_rank = np.ascontiguousarray(rows_of_rank, dtype=np.int64)
+        if rows_of_rank.shape != (self.world,) or int(rows_of_rank[self.rank]) != counts.shape[0]:
+            raise ValueError("rows_of_rank must hold every rank's row count, this rank's equal to its rows")
+        counts = counts.contiguous()
+        G = int(counts.shape[1])
+        dst = torch.empty((int(rows_of_rank.sum()), G), dtype=torch.int32, device=counts.device) if self.rank == root else None
+        _native.check(self._lib.prosstt_amd_gather_counts(
+            self.ctx._h, self._h, ctypes.c_void_p(counts.data_ptr()), rows_of_rank.ctypes.data_as(ctypes.c_void_p), G, int(root),
+            ctypes.c_void_p(dst.data_ptr()) if dst is not None else None))
+        return dst
+
+    def selftest(self, nbytes=1 << 20):
+        _native.check(self._lib.prosstt_amd_comm_selftest(self.ctx._h, self._h, ctypes.c_uint64(int(nbytes))))
+
+    def close(self):
+        if self._h:
+            self._lib.prosstt_amd_comm_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class PresentedCounts:
     """The count matrix as it lies on the device after a call that PRESENTED its cells grouped by their row of the mean
     tensor (what keeps a gene tile's rows of the tensor in cache: 2 to 5 % of the kernel, and 1.75 x less HBM traffic on a

@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_native.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert _native.load().prosstt_amd_version() == 500
+    assert _native.load().prosstt_amd_version() == 600       # PRNB-7 (the version moves with the sampler's definition)
 
 
 def test_no_cpu_fallback():

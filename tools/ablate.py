@@ -345,9 +345,9 @@ VARIANTS.update({
 
 
 # round 6: the unfinished walks of a strip travel to K3h with their state -- how many may be left when the strip's drain stops
-def _bail(n, slots):
-    return [("constexpr int kBail = 6; ", "constexpr int kBail = %d; " % n), ("constexpr int kBailSlots = 8; ", "constexpr int kBailSlots = %d; " % slots)]
-VARIANTS.update({"r6_bail3": _bail(3, 8), "r6_bail8": _bail(8, 8), "r6_bail12": _bail(12, 16), "r6_bail16": _bail(16, 16)})
+def _bail(n, slots=None):
+    return [("constexpr int kBail = 6; ", "constexpr int kBail = %d; " % n)]
+VARIANTS.update({"r6_bail0": _bail(0), "r6_bail2": _bail(2), "r6_bail3": _bail(3), "r6_bail8": _bail(8)})
 
 
 # round 6 (timing only: the walk's groups would have to move in the definition): stage 2 takes the terms k = 0..4, not 0..2
