@@ -2,7 +2,7 @@
 # Runs on the GPU box AFTER tools/collect_profile.sh <tag> has put the round's summaries into profiles/ (and they have been
 # committed): the bench lines then carry roofline.traffic from them (bench.py reads profiles/<tag>_summary.txt and
 # profiles/<tag>_t32_summary.txt and compares their kernel_source_sha).  usage: tools/bench_after_profile.sh <tag> -> gpurun_out/after_<tag>/
-TAG=${1:-r05}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/after_$TAG; mkdir -p $O; cd /tmp && export TMPDIR=/tmp; cd $R
+TAG=${1:-r06}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/after_$TAG; mkdir -p $O; cd /tmp && export TMPDIR=/tmp; cd $R
 ARGS="bench.py --steps 10 --warmup 2 --cpu-cells 0 --no-end-to-end --no-target-shape"
 python3 $ARGS 2> $O/unprofiled.err | tail -1 > $O/bench_unprofiled.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $ARGS 2> $O/trace.err | tail -1 > $O/bench_under_rocprof.json

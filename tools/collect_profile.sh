@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copies what tools/profile_bench.sh <tag> left under gpurun_out/prof_<tag>/ into profiles/ (tracked).
-TAG=${1:-r05}; cd "$(dirname "$0")/.."; O=gpurun_out/prof_$TAG
+TAG=${1:-r06}; cd "$(dirname "$0")/.."; O=gpurun_out/prof_$TAG
 cp $O/summary.txt profiles/${TAG}_summary.txt
 cp $O/bench_unprofiled.json profiles/${TAG}_bench_unprofiled.json
 cp $O/bench_trace.json profiles/${TAG}_bench_under_rocprof.json

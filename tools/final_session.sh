@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box: the round's closing measurements.  usage: tools/final_session.sh <tag>
-TAG=${1:-r05}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final_$TAG; mkdir -p $O; cd $R
+TAG=${1:-r06}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final_$TAG; mkdir -p $O; cd $R
 timeout 2400 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
 timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 bash tools/profile_bench.sh $TAG > /dev/null 2>&1; grep "under the tracer\|derived" -A2 gpurun_out/prof_$TAG/summary.txt | cut -c1-300
@@ -9,9 +9,9 @@ python3 bench.py 2> $O/bench_default.err | tail -1 > $O/bench_default.json
 PROSSTT_BENCH_BACKEND=gloo PROSSTT_BENCH_ONE_GPU=1 timeout 900 python3 bench.py --gpus 2 --steps 5 --warmup 2 2> $O/bench2.err | tail -1 > $O/bench_2ranks_gloo_one_gpu.json
 {
 echo "# cells presented grouped by mean-tensor row (KBENCH_SORT=1: what simulation.draw_counts does), 20 calls back to back per round:"
-for c in C3 T32 C2 C4 C5; do if [ $c = C5 ]; then export KBENCH_CELLS=125000; else unset KBENCH_CELLS; fi; KBENCH_SORT=1 KBENCH_BURST=20 timeout 600 python3 tools/kbench_ab.py $c 8 shipped build/ab/libprosstt_amd_r4.so 2>&1 | grep -v amdgpu; done
+for c in C3 T32 C2 C4 C5; do if [ $c = C5 ]; then export KBENCH_CELLS=125000; else unset KBENCH_CELLS; fi; KBENCH_SORT=1 KBENCH_BURST=20 timeout 600 python3 tools/kbench_ab.py $c 8 shipped build/ab/libprosstt_amd_r5.so 2>&1 | grep -v amdgpu; done
 echo "# cells in the order of the plan:"
-for c in C3 T32 C2 C4 C5; do if [ $c = C5 ]; then export KBENCH_CELLS=125000; else unset KBENCH_CELLS; fi; KBENCH_BURST=20 timeout 600 python3 tools/kbench_ab.py $c 8 shipped build/ab/libprosstt_amd_r4.so 2>&1 | grep -v amdgpu; done
+for c in C3 T32 C2 C4 C5; do if [ $c = C5 ]; then export KBENCH_CELLS=125000; else unset KBENCH_CELLS; fi; KBENCH_BURST=20 timeout 600 python3 tools/kbench_ab.py $c 8 shipped build/ab/libprosstt_amd_r5.so 2>&1 | grep -v amdgpu; done
 } | tee $O/other_configs.txt
 unset KBENCH_CELLS
 KBENCH_SORT=1 bash tools/stage_budget.sh ${TAG}_c3 C3 > /dev/null 2>&1; tail -7 gpurun_out/stage_budget_${TAG}_c3.txt | cut -c1-170

@@ -3,7 +3,7 @@
 # usage: [BENCH_EXTRA="--config T32"] tools/profile_bench.sh <tag>     (summaries land in gpurun_out/prof_<tag>/)
 # The default set is taken WITHOUT the extra case on north_star's shape (--no-target-shape): the kernel stats then hold the
 # headline workload's dispatches only; the T32 set is its own run (BENCH_EXTRA="--config T32").
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O

@@ -4,7 +4,7 @@
 # differences are what stages 2 and 3 issue.  K3h's counts come with the shipped pass.
 # usage (on the GPU box, after `python3 tools/ablate.py s1 s12`): tools/stage_budget.sh [tag] [C3|T32|C4] -> gpurun_out/stage_budget_<tag>.txt
 cd /tmp && export TMPDIR=/tmp
-TAG=${1:-r05}; CFG=${2:-C3}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/stage_budget_$CFG; rm -rf $O; mkdir -p $O; cd $R
+TAG=${1:-r06}; CFG=${2:-C3}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/stage_budget_$CFG; rm -rf $O; mkdir -p $O; cd $R
 for v in shipped s1 s12; do
   if [ $v = shipped ]; then unset PROSSTT_AMD_LIB; else export PROSSTT_AMD_LIB=$R/build/ab/libprosstt_amd_$v.so; fi
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES \
