@@ -87,8 +87,9 @@ int prosstt_amd_last_kernel_ms(prosstt_amd_ctx* ctx, float* ms);
  *   out          [N][ld_out] int32 counts (the reference returns int64)
  * Limits, refused with PROSSTT_AMD_EINVAL before anything is allocated: N < 2^31, ld_out >= G,
  * ld_out * 128 < 2^29, ceil(N/64)/4 * ceil(G/256) < 2^29 (chunk the cells beyond that), rows > 0.
- * Workspace: the ctx grows its device workspace to about N*G/4 + 36*N + 12*G bytes for the call (one
- * region of the list of samples drawn by the second kernel per 64 x 256 block of the matrix).
+ * Workspace: the ctx grows its device workspace to about 0.8 * N*G + 36*N + 12*G bytes for the call (per 64 x 256
+ * block of the matrix one region of the lists the second kernel draws from: N*G/2 for the staging lists, N*G/4 for the
+ * segments, 400 B of dense entries and walk states; 0.76 GB for the 4 GB matrix of 50 000 x 20 000).
  */
 int prosstt_amd_sample_counts(prosstt_amd_ctx* ctx, const float* means, int64_t rows, int32_t G,
                               const int32_t* row_of_cell, const double* scaling,
@@ -120,7 +121,7 @@ int prosstt_amd_domain_status(prosstt_amd_ctx* ctx, int32_t* status);
 /*
  * The samples that the streaming kernel of the LAST prosstt_amd_sample_counts call on this ctx left
  * to its second kernel (K3h): the gamma-Poisson class, the walks still running when their strip of
- * 64 cells ended, walks past k = 254.  Decoded to (cell, gene)
+ * 64 cells ended and the walks past term 252 (both handed over with their state).  Decoded to (cell, gene)
  * pairs, cells[i] indexing that call's arrays; at most `cap` pairs are written, *total receives the
  * number listed, *overflowed whether a wave's region of the list was too small (more than one in 16 of
  * its 64 x 256 samples listed; K3h then redoes that region sample by sample, and the list holds the

@@ -311,6 +311,11 @@ VARIANTS.update({
     "run16b": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 16;")],
     "run24": [("constexpr int kS2Run = 32;", "constexpr int kS2Run = 24;")],
     "run32c": [("constexpr int kS2Run = 40;", "constexpr int kS2Run = 32;")],
+    "run36c": [("constexpr int kS2Run = 40;", "constexpr int kS2Run = 36;")],
+    "run28c": [("constexpr int kS2Run = 40;", "constexpr int kS2Run = 28;")],
+    "run30c": [("constexpr int kS2Run = 40;", "constexpr int kS2Run = 30;")],
+    "run34c": [("constexpr int kS2Run = 40;", "constexpr int kS2Run = 34;")],
+    "run24c": [("constexpr int kS2Run = 40;", "constexpr int kS2Run = 24;")],
     "run48c": [("constexpr int kS2Run = 40;", "constexpr int kS2Run = 48;"), ("constexpr int kS2Cap = 104;", "constexpr int kS2Cap = 112;")],
     "bail4": [("constexpr int kBail = 6;", "constexpr int kBail = 4;")],
     "bail8": [("constexpr int kBail = 6;", "constexpr int kBail = 8;")],
