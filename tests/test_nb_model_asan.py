@@ -3,7 +3,9 @@ CPU: the scalar model of the count sampler under AddressSanitizer / UBSan at the
 (theta = 24, -log P(X = 0) just under 19: means around 141, tail ratio 24/25; PRNB-5's corner at theta = 16 as well), where walks are longest.  Round 3's
 definition let a walk run past its 1/k table there (a read beyond the table in the model, beyond the LDS copy on the
 device); PRNB-5 / PRNB-6 end every walk at k = 1022, PRNB-7 at k = 1024, and the table covers it.  The driver below is compiled together with
-oracle/nb_model.c (no GPU: the libm stand-ins of the three hardware functions).
+oracle/nb_model.c (no GPU: the libm stand-ins of the hardware functions).  Round 6: the gamma-Poisson class's question / tape /
+replay resolver (PRNB-7: nb_model.c, resolve_waiting) runs under the sanitizers as well, answered by the stand-ins THROUGH the query
+machinery -- its counts must equal the direct evaluation's, and leak detection is on for that part.
 """
 import os
 import shutil
@@ -19,8 +21,31 @@ DRIVER = r"""
 #include <stdio.h>
 #include <stdlib.h>
 void prnb_sample_iid(float m, double a, double b, uint64_t seed, uint64_t first_cell, uint32_t gene, int64_t n, int32_t* out);
+void prnb_set_hw_query_standins(void);
+void prnb_set_hw_query(void* fn);
+void prnb_query_stats(int64_t* rounds, int64_t* values);
+static int resolver_case(float m, double a, double b, int64_t n)
+{
+    /* the gamma-Poisson class through the resolver (questions, tapes, replay) == the direct evaluation */
+    int32_t* direct = malloc(sizeof(int32_t) * n);
+    int32_t* asked = malloc(sizeof(int32_t) * n);
+    prnb_sample_iid(m, a, b, 4242, 77, 3, n, direct);
+    prnb_set_hw_query_standins();
+    prnb_sample_iid(m, a, b, 4242, 77, 3, n, asked);
+    int64_t rounds = 0, values = 0;
+    prnb_query_stats(&rounds, &values);
+    prnb_set_hw_query(0);
+    int bad = 0;
+    for (int64_t i = 0; i < n; ++i) bad += direct[i] != asked[i];
+    printf("resolver m = %g a = %g b = %g: %lld rounds, %lld values, %d differ\n", (double)m, a, b, (long long)rounds, (long long)values, bad);
+    free(direct); free(asked);
+    return bad != 0 || rounds < 3;
+}
 int main(void)
 {
+    /* theta > 24 (PTRS), r < 1 (the boost, small lambda), the Poisson limit at a large mean, a huge mean */
+    if (resolver_case(300.0f, 0.3, 2.0, 60000) || resolver_case(8.0f, 3.0, 40.0, 60000) || resolver_case(40.0f, 0.0, 1.00000001, 60000) ||
+        resolver_case(3.0e5f, 0.3, 2.0, 5000)) return 5;
     const int64_t n = 400000;
     int32_t* out = malloc(sizeof(int32_t) * n);
     /* (m, alpha, beta): theta = alpha*m + beta - 1 */
@@ -56,8 +81,8 @@ def test_model_walks_stay_inside_their_table_under_asan():
         if build.returncode != 0 and "sanitize" in build.stderr:
             pytest.skip("this gcc has no sanitizer runtime")
         assert build.returncode == 0, build.stderr[-2000:]
-        run = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, OMP_NUM_THREADS="2", ASAN_OPTIONS="detect_leaks=0"))
+        run = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, OMP_NUM_THREADS="2", ASAN_OPTIONS="detect_leaks=1"))
         assert run.returncode == 0, (run.stdout + run.stderr)[-3000:]
-        assert "largest count" in run.stdout
+        assert "largest count" in run.stdout and run.stdout.count(", 0 differ") == 4
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
