@@ -252,7 +252,7 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
 
     // ---- inversion walks: the ones the streaming kernel had not finished when their strip ended arrive with their
     // state and go on from it; a walk past k = 254 and the samples of an overflowed region start at k = 0 (walk_from_start).
-    // Every lane walks its own pmf eight terms per pass; walks differ in length by two orders of magnitude, so a lane's
+    // Every lane walks its own pmf sixteen terms per pass; walks differ in length by two orders of magnitude, so a lane's
     // walk lives in registers across passes and an idle lane takes the next entry of the stack: a pass runs with more
     // than half of the lanes walking, and new walks start at least 32 at a time.
     int32_t wk = -1;                                  // next term of this lane's walk; -1: idle
@@ -273,43 +273,53 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
         hw_top -= idle < hw_top ? idle : hw_top;
     };
     auto walk_pass = [&]() __attribute__((always_inline)) {
-        // two groups of four terms for every walking lane (an idle lane computes on zeros).  Most passes of a
-        // strip's longest walks end nowhere: one wave-level test then skips everything but the arithmetic.
+        // FOUR groups of four terms for every walking lane (an idle lane computes on zeros): the longest walk of a launch is a
+        // chain of passes one after the other -- its length is K3h's floor --, and a pass of 16 terms pays the LDS round trip
+        // for the reciprocals, the tests and the loop once per 16 terms (8 terms per pass: the chain 17 us at C3).  Most
+        // passes of the longest walks end nowhere: one wave-level test then skips everything but the arithmetic.
         const bool busy = wk >= 0;
         const float* tab = &inv_k[busy ? wk + 1 : 6];
-        const float4 ia = *reinterpret_cast<const float4*>(__builtin_assume_aligned(tab, 16));
-        const float4 ib = *reinterpret_cast<const float4*>(__builtin_assume_aligned(tab + 4, 16));
-        const float a1 = wrem - wps;
-        const float q2 = wps * PRNB_FMA(wd, ia.x, wq);
-        const float a2 = a1 - q2;
-        const float q3 = q2 * PRNB_FMA(wd, ia.y, wq);
-        const float a3 = a2 - q3;
-        const float q4 = q3 * PRNB_FMA(wd, ia.z, wq);
-        const float a4 = a3 - q4;
-        const float q5 = q4 * PRNB_FMA(wd, ia.w, wq);
-        const float b1 = a4 - q5;
-        const float q6 = q5 * PRNB_FMA(wd, ib.x, wq);
-        const float b2 = b1 - q6;
-        const float q7 = q6 * PRNB_FMA(wd, ib.y, wq);
-        const float b3 = b2 - q7;
-        const float q8 = q7 * PRNB_FMA(wd, ib.z, wq);
-        const float b4 = b3 - q8;
-        // the remainders only fall: one of a group's four is negative iff its last one is
-        const bool end_a = (a4 < 0.0f) || (q4 < 1.0f) || (wk + 3 >= prnb::kWalkEnd);      // (the walk's last group)
-        const bool end_b = (b4 < 0.0f) || (q8 < 1.0f);
-        if (__builtin_amdgcn_ballot_w64(busy && (end_a || end_b)) != 0ull) {
-            const int32_t at_a = (a1 < 0.0f) ? wk : ((a2 < 0.0f) ? wk + 1 : ((a3 < 0.0f) ? wk + 2 : wk + 3));
-            const int32_t at_b = (b1 < 0.0f) ? wk + 4 : ((b2 < 0.0f) ? wk + 5 : ((b3 < 0.0f) ? wk + 6 : wk + 7));
-            if (busy && (end_a || end_b)) {
-                out[(int64_t)wn * ld + wg] = end_a ? at_a : at_b;         // (>= 5)
+        float4 iv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) iv[j] = *reinterpret_cast<const float4*>(__builtin_assume_aligned(tab + 4 * j, 16));
+        // term t[i] is the pmf at k = wk + i (t[0] = wps), r[i] the remainder behind it
+        float t = wps, r = wrem;
+        float rg[4][4], tl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            rg[j][0] = r - t;
+            t = t * PRNB_FMA(wd, iv[j].x, wq);
+            rg[j][1] = rg[j][0] - t;
+            t = t * PRNB_FMA(wd, iv[j].y, wq);
+            rg[j][2] = rg[j][1] - t;
+            t = t * PRNB_FMA(wd, iv[j].z, wq);
+            rg[j][3] = rg[j][2] - t;
+            tl[j] = t;                                   // the group's last term (k = wk + 4 j + 3)
+            r = rg[j][3];
+            t = t * PRNB_FMA(wd, iv[j].w, wq);           // the next group's first term
+        }
+        // a group ends the walk when its last remainder is negative (the remainders only fall: one of its four is negative iff
+        // the last one is), when its last term is under 1, or when it is the walk's last group; the first such group decides
+        bool end[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) end[j] = (rg[j][3] < 0.0f) || (tl[j] < 1.0f) || (wk + 4 * j + 3 >= prnb::kWalkEnd);
+        const bool ended = busy && (end[0] || end[1] || end[2] || end[3]);
+        if (__builtin_amdgcn_ballot_w64(ended) != 0ull) {
+            // the count: the group's last k less one for each of its first three remainders that is negative
+            int32_t at[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                at[j] = ((wk + 4 * j + 3) + ((int32_t)prnb::f2u(rg[j][0]) >> 31)) + (((int32_t)prnb::f2u(rg[j][1]) >> 31) + ((int32_t)prnb::f2u(rg[j][2]) >> 31));
+            if (ended) {
+                out[(int64_t)wn * ld + wg] = end[0] ? at[0] : (end[1] ? at[1] : (end[2] ? at[2] : at[3]));         // (>= 5)
                 wk = -1;
                 wps = 0.0f;
             }
         }
         if (wk >= 0) {
-            wps = q8 * PRNB_FMA(wd, ib.w, wq);
-            wk += 8;
-            wrem = b4;
+            wps = t;
+            wk += 16;
+            wrem = r;
         }
     };
     auto walk_service = [&](bool drain) __attribute__((always_inline)) {
@@ -388,7 +398,7 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
     // ---- the list -------------------------------------------------------------------------------------
     const uint32_t wave_id = blockIdx.x * (kHeavyBlock / 64) + (uint32_t)wv;
     // Six blocks in sixteen (kWalkerBlocks) only walk, the others only draw: the walks differ in length by two orders of magnitude (the
-    // longest of a launch runs forty passes of eight terms, one after the other), so they start at once, on waves that
+    // longest of a launch runs twenty passes of sixteen terms, one after the other), so they start at once, on waves that
     // have nothing else to do, and a walker with a few hundred walks keeps its lanes busy.  (With every wave walking the
     // fifty walks of its own regions, a wave ran as many passes as its longest walk has groups of eight terms, mostly for
     // a handful of lanes.)

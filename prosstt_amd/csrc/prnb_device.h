@@ -36,7 +36,7 @@ constexpr float kRMin = 9.094947e-13f;       // 2^-40
 // Groups: k = 0..4 (stage 2 of the streaming kernel), then four at a time from k = 5 -- so a 16-byte read of 1/(k+1)..1/(k+4)
 // is aligned when the table's entry 6 is (kTabShift).
 constexpr int kWalkEnd = 1024;
-constexpr int kKTab = 1034;
+constexpr int kKTab = 1048;            // (K3h's walk pass reads 1/(k+1) .. 1/(k+16) from k = 1021 at the latest)
 constexpr int kTabShift = 2;           // inv_k = (16-byte aligned store) + kTabShift: &inv_k[6 + 4 j] is 16-byte aligned
 constexpr float kPoisInv = 10.0f;
 constexpr float kLamBig = 4194304.0f;        // 2^22
