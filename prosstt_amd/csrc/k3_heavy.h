@@ -1,8 +1,8 @@
 // K3h: the samples the streaming kernel (k3_stream.h) listed instead of drawing them: the
 // gamma-Poisson class of PRNB-7 (prnb_device.h; theta above 24 or -log2 P(X = 0) of 27.4 or more, one to
 // three in a thousand of a typical workload), the walks that were still running when their strip was done
-// (continued here from the state the streaming kernel hands over) and the walks that passed k = 254 (redone here
-// from k = 0: seventy per 10^9 samples).
+// and the walks that ran past term 252 (seventy per 10^9 samples): both continued here from the state the streaming
+// kernel hands over.  Only the samples of a region whose list overflowed start at k = 0 here.
 // Both halves of the gamma-Poisson path are rejection samplers; run lane-per-sample
 // they would make every wave repeat each half until its unluckiest lane is accepted.  Here
 // every ATTEMPT is a stack entry: a gamma pass runs one Marsaglia-Tsang attempt for 64
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
     };
 
     // ---- inversion walks: the ones the streaming kernel had not finished when their strip ended arrive with their
-    // state and go on from it; a walk past k = 254 and the samples of an overflowed region start at k = 0 (walk_from_start).
+    // state and go on from it; only the samples of an overflowed region (and a fifth walk past term 252 of one strip) start at k = 0 (from_start).
     // Every lane walks its own pmf sixteen terms per pass; walks differ in length by two orders of magnitude, so a lane's
     // walk lives in registers across passes and an idle lane takes the next entry of the stack: a pass runs with more
     // than half of the lanes walking, and new walks start at least 32 at a time.
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
         if (hw_top >= 32) walk_service(false);
     };
 
-    // ---- a sample from its start (rare: a walk past k = 254, or any sample of an overflowed region): the mean is
+    // ---- a sample from its start (rare: any sample of an overflowed region, a fifth walk past term 252 of one strip): the mean is
     // gathered, the class decided; the gamma-Poisson class goes on HG, an inversion walk is taken through its first
     // group (k = 0 .. 4) and, when that does not decide it, pushed as a walk state at k = 5
     auto from_start = [&](bool has, int32_t n, int32_t g) __attribute__((always_inline)) {
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(kHeavyBlock) void sample_counts_heavy_kernel(
     // Six blocks in sixteen (kWalkerBlocks) only walk, the others only draw: the walks differ in length by two orders of magnitude (the
     // longest of a launch runs twenty passes of sixteen terms, one after the other), so they start at once, on waves that
     // have nothing else to do, and a walker with a few hundred walks keeps its lanes busy.  (With every wave walking the
-    // fifty walks of its own regions, a wave ran as many passes as its longest walk has groups of eight terms, mostly for
+    // fifty walks of its own regions, a wave ran as many passes as its longest walk needs, mostly for
     // a handful of lanes.)
     const bool walker = (blockIdx.x & 15u) < kWalkerBlocks;
     const uint32_t walker_blocks = (gridDim.x >> 4) * kWalkerBlocks + ((gridDim.x & 15u) < kWalkerBlocks ? (gridDim.x & 15u) : kWalkerBlocks);

@@ -2,34 +2,36 @@
 // on its own strip of the count matrix, with LDS stacks between the stages so that every
 // stage executes with (nearly) all 64 lanes busy.
 //
-// The scalar algorithm (PRNB-6, prnb_device.h) has very different costs per sample:
+// The scalar algorithm (PRNB-7, prnb_device.h) has very different costs per sample:
 //   ~65 % of the samples of the headline workload are zeros that a 6-instruction bound
 //         settles (exp(-m * phi_gene) <= P(X = 0), prnb::zero_test_factor);
-//   the rest need P(X = 0) itself (two reciprocals, a log2 and an exp2 of the hardware: PRNB-6), and
+//   the rest need P(X = 0) itself (two reciprocals, a log2 and an exp2 of the hardware), and
 //   ~33 % then walk the pmf for k >= 1 (data-dependent length, half of them end at k <= 2);
 //   ~0.1 % need gamma-Poisson.
 // Run lane-per-sample, every wave pays for its slowest lane in every one of these.  Here
 //   stage 1 (uniform)   one count-matrix row segment per wave pass: 16-B mean load, one
 //                       Philox call per lane, the bound test as a compare mask; survivors are
 //                       pushed on stack S1 under exec = mask;
-//   stage 2 (64 of S1)  P(X = 0) and the class test, then the terms k = 0, 1, 2; what is still
-//                       undecided is pushed on S2 with the pmf state at k = 3;
-//   stage 3 (lanes pull from S2)  four pmf steps per lane per pass; a lane that finishes
+//   stage 2 (64 of S1)  P(X = 0) and the class test, then the terms k = 0 .. 4 (PRNB-7; 0 .. 2 until round 5: a quarter of
+//                       the walks that reached stage 3 ended within two more terms); what is still
+//                       undecided is pushed on S2 with the pmf state at k = 5;
+//   stage 3 (lanes pull from S2)  two groups of four pmf steps per lane per pass; a lane that finishes
 //                       writes its count into the LDS row ring and pulls the next entry;
 //   output              the last kRing rows of the strip live in LDS, 8 bits per count (a walk past
-//                       k = 254 -- 70 per 10^9 samples of the headline workload -- is left to K3h); a row
+//                       term 252 -- 70 per 10^9 samples of the headline workload -- leaves for K3h with its state); a row
 //                       is stored (one coalesced 1 KiB store per wave) kRing cells after stage 1
 //                       started it.  The few counts that arrive later than that (long walks, and the
 //                       entries at the bottom of the two LIFO stacks, which wait for the drain)
 //                       are collected in LDS and written in bursts of 4-B stores -- a store per
 //                       late count would sit in front of every wait for the next mean load
 //                       (loads and stores retire in order on one counter);
-//   samples of the gamma-Poisson class are only LISTED here (a lane that meets one keeps it in
-//   a register; when a lane meets its second, and at the end of the strip, the wave writes what
-//   its lanes hold to its own region of a global list -- no atomics: one counter for all waves
-//   serialises them); sample_counts_heavy_kernel (k3_heavy.h) draws them afterwards.
+//   samples of the gamma-Poisson class are only LISTED here (a lane that meets one keeps it and its scaled
+//   mean in two registers; when a lane meets its second, and at the end of the strip, the wave writes what
+//   its lanes hold to its own region of K3h's lists -- no atomics on that path: one counter for all waves
+//   serialises them); the walks still running when the strip has nothing else to do travel there with their
+//   state; sample_counts_heavy_kernel (k3_heavy.h) draws and continues them afterwards.
 //
-// P(X = 0) is PRNB-6's: the hardware's v_rcp/v_log/v_exp ARE the definition (prnb_device.h: hw_p0), so
+// P(X = 0): the hardware's v_rcp/v_log/v_exp ARE the definition (prnb_device.h: hw_p0), so
 // stage 2 needs no error margins and no sample is given up because it came close to a threshold (PRNB-4
 // defined P(X = 0) in polynomial arithmetic and paid for margins, a give-up list and K3h redo walks: -5 % of the
 // kernel and -0.03 ms of K3h when removed, profiles/r04_ablation.txt).

@@ -32,7 +32,7 @@ constexpr float kThetaMax = 1.0e18f;
 constexpr float kRMin = 9.094947e-13f;       // 2^-40
 // The inversion walk ends at k = kWalkEnd at the latest: the group k = 1021..1024 is the last one, and when it ends
 // without a negative remainder the count is 1024 (in the inversion class the mean is below 142 and the tail ratio at
-// most 24/25: P(X > 1022) < 1e-12, scipy's nbinom.sf at the class corner).  The 1/k table holds 1/k for 1 <= k < kKTab (the K3h walk reads two groups ahead).
+// most 24/25: P(X > 1022) < 1e-12, scipy's nbinom.sf at the class corner).  The 1/k table holds 1/k for 1 <= k < kKTab (K3h's walk pass reads four groups).
 // Groups: k = 0..4 (stage 2 of the streaming kernel), then four at a time from k = 5 -- so a 16-byte read of 1/(k+1)..1/(k+4)
 // is aligned when the table's entry 6 is (kTabShift).
 constexpr int kWalkEnd = 1024;

@@ -225,7 +225,7 @@ __global__ void nb_params_kernel(const float* __restrict__ means, int32_t G,
     if (path) path[i] = !P.valid ? 0 : (P.light ? 1 : 2);
 }
 
-// The probe of PRNB-6's three hardware functions (prnb_device.h: hw_rcp, hw_log2, hw_exp2): their values over a
+// The probe of the three hardware functions of the inversion class (prnb_device.h: hw_rcp, hw_log2, hw_exp2): their values over a
 // range of binary32 bit patterns, written by the device itself.  The scalar model that checks the kernels reads these
 // tables instead of re-implementing the functions.  op: 0 v_rcp_f32(x), 1 v_log_f32(x), 2 v_exp_f32(-x).
 __global__ void hw_math_kernel(int32_t op, uint32_t first_bits, uint64_t count, float* __restrict__ y)
