@@ -94,7 +94,7 @@ VARIANTS = {
     "k3h_twice": [("    k3::sample_counts_heavy_kernel<<<dim3(heavy_blocks),", "    for (int rep_ = 0; rep_ < 2; ++rep_) k3::sample_counts_heavy_kernel<<<dim3(heavy_blocks),")],
     # K3h with a device printf of per-phase cycle counts of a few waves (diagnosis; printf costs registers and time)
     "k3h_trace": [("    int hg_top = 0, hp_top = 0, hw_top = 0;      // wave-uniform",
-                   "    int hg_top = 0, hp_top = 0, hw_top = 0;      // wave-uniform\n    int np_l = 0, np_w = 0, np_g = 0, np_p = 0, n_ent = 0, n_chunks = 0; const long long W0 = wall_clock64(); long long T0 = clock64(), TL = 0, TG = 0, TP = 0;"),
+                   "    int hg_top = 0, hp_top = 0, hw_top = 0;      // wave-uniform\n    int np_l = 0, np_w = 0, np_g = 0, np_p = 0, n_ent = 0; const long long W0 = wall_clock64(); long long T0 = clock64(), TL = 0, TG = 0, TP = 0;"),
                   ("    auto poisson_pass = [&]() __attribute__((always_inline)) {\n", "    auto poisson_pass = [&]() __attribute__((always_inline)) {\n        ++np_p; const long long tp0 = clock64();\n"),
                   ("        hp_top += __popcll(m);\n    };", "        hp_top += __popcll(m);\n        TP += clock64() - tp0;\n    };"),
                   ("    auto gamma_pass = [&]() __attribute__((always_inline)) {\n", "    auto gamma_pass = [&]() __attribute__((always_inline)) {\n        ++np_g; const long long tg0 = clock64();\n"),
@@ -102,13 +102,12 @@ VARIANTS = {
                   ("    auto walk_service = [&](bool drain) __attribute__((always_inline)) {\n        for (;;) {", "    auto walk_service = [&](bool drain) __attribute__((always_inline)) {\n        const long long tl0 = clock64();\n        for (;;) {"),
                   ("            if (busy <= 32 && (drain ? hw_top > 0 : hw_top >= 32)) walk_take();\n            else if (drain ? busy > 0 : busy > 32) walk_pass();\n            else break;\n        }",
                    "            if (busy <= 32 && (drain ? hw_top > 0 : hw_top >= 32)) { walk_take(); ++np_l; }\n            else if (drain ? busy > 0 : busy > 32) { walk_pass(); ++np_w; }\n            else break;\n        }\n        TL += clock64() - tl0;"),
-                  ("            hg_top += __popcll(mh);\n            while (hg_top >= 64) gamma_pass();\n            const bool redo", "            hg_top += __popcll(mh);\n            n_ent += __popcll(mh);\n            while (hg_top >= 64) gamma_pass();\n            const bool redo"),
-                  ("    // The walks: to one wave in four", "    const long long T1 = clock64();\n    // The walks: to one wave in four"),
-                  ("            walk_push(has, id.n, id.g, id.k, st);", "            walk_push(has, id.n, id.g, id.k, st);\n            ++n_chunks;"),
+                  ("        hg_top += __popcll(mh);\n        while (hg_top >= 64) gamma_pass();\n    };", "        hg_top += __popcll(mh);\n        n_ent += __popcll(mh);\n        while (hg_top >= 64) gamma_pass();\n    };"),
+                  ("    // Regions whose list or segment was too small:", "    const long long T1 = clock64();\n    // Regions whose list or segment was too small:"),
                   ("    walk_service(true);\n    while (hg_top > 0) gamma_pass();\n    while (hp_top > 0) poisson_pass();",
                    "    const long long T2 = clock64();\n    walk_service(true);\n    const long long T3 = clock64();\n    while (hg_top > 0) gamma_pass();\n    while (hp_top > 0) poisson_pass();\n"
                    "    const long long T4 = clock64(); const long long W1 = wall_clock64();\n"
-                   "    if (lane == 0 && ((blockIdx.x * 4 + wv) % 61) == 5) printf(\"K3HTRACE wave %d wall %lld..%lld | ticks total %lld phase1 %lld phase2 %lld walkdrain %lld gpdrain %lld | entries %d chunks %d | walk %d takes %d passes %lld | gamma %d passes %lld | poisson %d passes %lld\\n\", (int)(blockIdx.x * 4 + wv), W0, W1, T4 - T0, T1 - T0, T2 - T1, T3 - T2, T4 - T3, n_ent, n_chunks, np_l, np_w, TL, np_g, TG, np_p, TP);")],
+                   "    if (lane == 0 && ((blockIdx.x * 4 + wv) % 61) == 5) printf(\"K3HTRACE wave %d walker %d wall %lld..%lld | ticks total %lld lists %lld ovf %lld walkdrain %lld gpdrain %lld | entries %d | walk %d takes %d passes %lld | gamma %d passes %lld | poisson %d passes %lld\\n\", (int)(blockIdx.x * 4 + wv), (int)walker, W0, W1, T4 - T0, T1 - T0, T2 - T1, T3 - T2, T4 - T3, n_ent, np_l, np_w, TL, np_g, TG, np_p, TP);")],
     # the library default of 10 Philox rounds instead of 7 (timing only: the model is not changed along)
     "philox10": [("constexpr int kCountRounds = 7;", "constexpr int kCountRounds = 10;")],
     # real variants (correct results): tuning constants
