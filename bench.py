@@ -544,7 +544,7 @@ def main():
     if world == 1:
         main_case.pop("shard", None)
     if world == 1 and not args.no_end_to_end and rank == 0:
-        end_to_end = (end_to_end_ms(main_case["tree"], work, n_total), end_to_end_ms(main_case["tree"], work, n_total, "numpy32"))
+        end_to_end = tuple(end_to_end_ms(main_case["tree"], work, n_total, out) for out in ("numpy", "numpy32", "csr"))
 
     # With N > 1 the measurements beyond the contract's line (the row gather, the strong-scaling configurations)
     # run under a watchdog: if one of them raises or stalls, rank 0 still prints the line -- with what was
@@ -731,7 +731,7 @@ def assemble_line(args, job, main_case, strong, end_to_end, extras_error):
     if strong:
         line["strong_scaling"] = strong
     if end_to_end is not None:
-        line["end_to_end_ms"], line["end_to_end_ms_int32"] = end_to_end
+        line["end_to_end_ms"], line["end_to_end_ms_int32"], line["end_to_end_ms_csr"] = end_to_end
     if world == 1 and args.cpu_cells > 0:
         line["cpu_baseline"] = cpu_baseline(work, pt, br, sc, min(args.cpu_cells, n_total))
         line["speedup_vs_cpu_1core"] = main_case["value"] / line["cpu_baseline"]["value"]
@@ -753,7 +753,8 @@ def end_to_end_ms(tree, work, n_cells, out="numpy"):
     """Wall time of the drop-in call a reference user makes -- ``simulation.sample_density`` returning the
     (N, G) matrix on the host: host plan, kernels, domain check, and the device-to-host copy (PCIe-inclusive;
     never ``value``).  out="numpy": the reference's int64 ndarray (widened on the device, 8 bytes per count over
-    PCIe); "numpy32": int32 as the device holds it.  Second of two calls (the first sizes the pinned buffers)."""
+    PCIe); "numpy32": int32 as the device holds it; "csr": scipy.sparse.csr_matrix compacted on the device (8 bytes per
+    non-zero over PCIe).  Second of two calls (the first sizes the pinned buffers)."""
     from prosstt_amd import simulation as sim
     best = None
     for _ in range(2):
@@ -762,6 +763,7 @@ def end_to_end_ms(tree, work, n_cells, out="numpy"):
         x = sim.sample_density(tree, n_cells, alpha=work.alpha, beta=work.beta, out=out)[0]
         dt = (time.perf_counter() - t0) * 1e3
         assert x.shape == (n_cells, tree.G) and x.dtype == (np.int64 if out == "numpy" else np.int32)
+        assert out != "csr" or x.format == "csr"
         del x
         best = dt
     return best

@@ -13,7 +13,7 @@ import numpy as np
 from numpy import random
 
 from . import device as _device
-from .device import HOST_DTYPES as _HOST_DTYPES, to_host as _to_host
+from .device import HOST_OUTS as _HOST_OUTS, OUT_CHOICES as _OUT_CHOICES, host_return as _host_return
 
 
 def generate_negbin_params(tree, mean_alpha=0.2, mean_beta=2, a_scale=1.5, b_scale=1.5):
@@ -56,6 +56,6 @@ def sample_counts(mu, alpha, beta, *, seed=None, out="numpy", strict=True):
                                seed=seed, check_domain=strict)
     if out == "torch":
         return counts
-    if out not in _HOST_DTYPES:
-        raise ValueError("out must be 'numpy', 'numpy32', 'numpy16' or 'torch'")
-    return _to_host(counts, _HOST_DTYPES[out])
+    if out not in _HOST_OUTS:
+        raise ValueError(_OUT_CHOICES)
+    return _host_return(counts, out)

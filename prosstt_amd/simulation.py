@@ -22,7 +22,7 @@ import pandas as pd
 from . import count_model as cm
 from . import device as _device
 from . import sim_utils as sut
-from .device import HOST_DTYPES as _HOST_DTYPES, to_host as _to_host
+from .device import HOST_OUTS as _HOST_OUTS, OUT_CHOICES as _OUT_CHOICES, host_return as _host_return
 
 
 # ----------------------------------------------------------------------------------
@@ -447,8 +447,8 @@ def sample_density_chunks(tree, no_cells, chunk_cells, alpha=0.3, beta=2, scale=
     ``device.PresentedCounts`` -- the chunk's device tensor in the order its cells were presented, and the permutation --
     or, with ``order="plan"``, plain device tensors in plan order; the consumer must be done with a chunk before asking
     for the next chunk but one)."""
-    if out != "torch" and out not in _HOST_DTYPES:
-        raise ValueError("out must be 'numpy', 'numpy32', 'numpy16' or 'torch'")
+    if out != "torch" and out not in _HOST_OUTS:
+        raise ValueError(_OUT_CHOICES)
     if order not in ("presented", "plan"):
         raise ValueError("order must be 'presented' or 'plan'")
     if chunk_cells <= 0:
@@ -491,7 +491,7 @@ def sample_density_chunks(tree, no_cells, chunk_cells, alpha=0.3, beta=2, scale=
             if out == "torch":
                 host = counts if perm is None else _device.PresentedCounts(counts, perm)
             else:
-                host = _to_host(counts, _HOST_DTYPES[out], row_order=perm)
+                host = _host_return(counts, out, row_order=perm)
             if strict:
                 ctx.domain_status()
                 verdict_open = pending is not None               # (the next chunk's launch is already behind it)
@@ -571,8 +571,10 @@ def draw_counts(tree, pseudotime, branches, scalings, alpha, beta, *, seed=None,
               stream, so ``np.random.seed`` still determines the whole simulation.
       out     "numpy" (default): int64 ndarray like the reference; "numpy32": int32 (what the
               device holds -- half the bytes over PCIe); "numpy16": uint16 (a quarter; OverflowError
-              if a count does not fit); "torch": no host copy -- the int32 device matrix as ``device.PresentedCounts``
-              (see ``order``).
+              if a count does not fit); "csr": ``scipy.sparse.csr_matrix`` of int32, compacted on the device -- 8 bytes
+              per NON-ZERO cross PCIe and the dense matrix never exists on the host (two thirds of a count matrix are
+              zeros: ``device.to_host_csr``); "torch": no host copy -- the int32 device matrix as
+              ``device.PresentedCounts`` (see ``order``).
       order   (with out="torch"; host arrays always come back in plan order) "presented" (default): the matrix as it
               lies on the device -- the cells are presented to the sampler grouped by their row of the mean tensor, which
               keeps a gene tile's rows of the tensor in cache -- with the permutation: ``counts, cell_of_row = result``,
@@ -592,8 +594,8 @@ def draw_counts(tree, pseudotime, branches, scalings, alpha, beta, *, seed=None,
         seed = int(lo) | (int(hi) << 32)
     ctx = _device.get_context()
     rows = cell_rows(tree, pseudotime, branches)
-    if out != "torch" and out not in _HOST_DTYPES:
-        raise ValueError("out must be 'numpy', 'numpy32', 'numpy16' or 'torch'")
+    if out != "torch" and out not in _HOST_OUTS:
+        raise ValueError(_OUT_CHOICES)
     # the domain check rides in the call's own kernels and is not waited for; its verdict is read behind the copy to the
     # host (which synchronises anyway), or at once when the device tensor itself is returned
     if order not in ("presented", "plan"):
@@ -621,7 +623,7 @@ def draw_counts(tree, pseudotime, branches, scalings, alpha, beta, *, seed=None,
             ctx.domain_status()
         return _device.PresentedCounts(counts, perm)
     try:
-        host = _to_host(counts, _HOST_DTYPES[out], row_order=perm)
+        host = _host_return(counts, out, row_order=perm)
     except BaseException:
         if strict:
             _discard_verdict(ctx)       # (an OverflowError of "numpy16", a failed page-lock: the call's verdict must not outlive it)

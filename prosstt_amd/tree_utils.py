@@ -68,9 +68,22 @@ def save_matrices_npz(job_id, save_dir, X, uMs=None, H=None, compressed=False):
     ``<save_dir>/<job_id>_simulation.npz`` holding ``X`` as int32 (an int32 device tensor, or the
     ``device.PresentedCounts`` that ``draw_counts(..., out="torch")`` returns -- its rows are put back in plan order
     inside the copy -- travels to the host as it is, never widened to int64), ``H`` and ``ums<branch>`` when given.
-    Row i is cell_i, column j gene_j, as in the text file."""
+    Row i is cell_i, column j gene_j, as in the text file.
+
+    A ``scipy.sparse`` matrix (what ``draw_counts(..., out="csr")`` returns) is stored as it is, in the layout of
+    ``scipy.sparse.save_npz`` (``data`` / ``indices`` / ``indptr`` / ``shape`` / ``format`` instead of ``X``):
+    ``scipy.sparse.load_npz(path)`` gives the matrix back, ``np.load(path)`` the other arrays beside it."""
     if hasattr(X, "cell_of_row") and hasattr(X, "to_host"):      # device.PresentedCounts
         X = X.to_host("numpy32")
+    if hasattr(X, "tocsr") and hasattr(X, "nnz"):                # scipy.sparse
+        X = X.tocsr()
+        if X.data.dtype != np.int32:
+            if X.nnz and (X.data.min() < 0 or X.data.max() > np.iinfo(np.int32).max):
+                raise ValueError("counts do not fit int32")
+            X = X.astype(np.int32)
+        arrays = {"format": np.array("csr".encode("ascii")), "shape": np.array(X.shape, dtype=np.int64), "data": X.data,
+                  "indices": X.indices, "indptr": X.indptr}
+        return _write_npz(job_id, save_dir, arrays, uMs, H, compressed)
     if hasattr(X, "detach"):                         # torch tensor
         X = X.detach().cpu().numpy()
     X = np.asarray(X)
@@ -78,7 +91,10 @@ def save_matrices_npz(job_id, save_dir, X, uMs=None, H=None, compressed=False):
         if X.size and (X.min() < 0 or X.max() > np.iinfo(np.int32).max):
             raise ValueError("counts do not fit int32")
         X = X.astype(np.int32)
-    arrays = {"X": X}
+    return _write_npz(job_id, save_dir, {"X": X}, uMs, H, compressed)
+
+
+def _write_npz(job_id, save_dir, arrays, uMs, H, compressed):
     if H is not None:
         arrays["H"] = np.asarray(H)
     for branch in (uMs.keys() if uMs is not None else ()):

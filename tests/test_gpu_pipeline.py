@@ -212,6 +212,27 @@ def test_compact_host_returns_and_chunk_generator():
         np.random.set_state(state)
         Y = sim.sample_density(t, 1000, alpha=al, beta=be, seed=11, out=out)[0]
         assert Y.dtype == dtype and np.array_equal(Y, X)
+    # out="csr": the same matrix, compacted on the device (rows in plan order, columns ascending within a row)
+    import scipy.sparse as sparse
+    np.random.set_state(state)
+    S = sim.sample_density(t, 1000, alpha=al, beta=be, seed=11, out="csr")[0]
+    assert sparse.isspmatrix_csr(S) and S.dtype == np.int32 and S.shape == X.shape and S.indices.dtype == np.int32
+    assert S.nnz == np.count_nonzero(X) and np.all(S.data != 0)
+    assert np.array_equal(S.toarray(), X)
+    assert all(np.all(np.diff(S.indices[a:b]) > 0) for a, b in zip(S.indptr[:-1], S.indptr[1:]))
+    from prosstt_amd import device
+    np.random.set_state(state)
+    presented = sim.sample_density(t, 1000, alpha=al, beta=be, seed=11, out="torch")[0]
+    for chunk_bytes in (4 * t.G * 7, 4 * t.G * 1000, 1 << 28):        # many chunks (a ragged last one), one chunk exactly, one
+        for row_order in (presented.cell_of_row, None):
+            S = device.to_host_csr(presented.counts, chunk_bytes=chunk_bytes, row_order=row_order)
+            want = X if row_order is not None else X[presented.cell_of_row]
+            assert np.array_equal(S.toarray(), want) and S.has_sorted_indices
+    assert np.array_equal(presented.to_host("csr").toarray(), X)
+    empty = device.to_host_csr(presented.counts[:0])
+    assert empty.shape == (0, t.G) and empty.nnz == 0
+    zeros = device.to_host_csr(presented.counts[:5] * 0)
+    assert zeros.shape == (5, t.G) and zeros.nnz == 0 and np.array_equal(zeros.indptr, np.zeros(6))
     for chunk in (1000, 333, 64, 5000):
         np.random.set_state(state)
         parts = list(sim.sample_density_chunks(t, 1000, chunk, alpha=al, beta=be, seed=11, out="numpy16"))
@@ -220,6 +241,9 @@ def test_compact_host_returns_and_chunk_generator():
         assert np.array_equal(np.concatenate([p[1] for p in parts]), pt)
         assert list(np.concatenate([p[2] for p in parts])) == list(br)
         assert np.array_equal(np.concatenate([p[3] for p in parts]), sc)
+    np.random.set_state(state)
+    parts = list(sim.sample_density_chunks(t, 1000, 333, alpha=al, beta=be, seed=11, out="csr"))
+    assert np.array_equal(sparse.vstack([p[0] for p in parts]).toarray(), X)
     assert list(sim.sample_density_chunks(t, 0, 10, alpha=al, beta=be, seed=1)) == []
     # a count beyond 65 535 does not fit uint16
     mu = np.full((4, 8), 3.0e5)

@@ -331,6 +331,13 @@ def test_writers_reproduce_the_reference_files(tmp_path):
     np.testing.assert_array_equal(back["umsB"], uMs["B"])
     with pytest.raises(ValueError):
         tut.save_matrices_npz("job", d, np.array([[2 ** 40]]))
+    # a sparse matrix (draw_counts(..., out="csr")) is stored in scipy's own layout, the other arrays beside it
+    import scipy.sparse as sparse
+    path = tut.save_matrices_npz("sparse", d, sparse.csr_matrix(g["X"]), uMs, g["H"])
+    again = sparse.load_npz(path)
+    assert again.format == "csr" and again.dtype == np.int32
+    np.testing.assert_array_equal(again.toarray(), g["X"])
+    np.testing.assert_array_equal(np.load(path)["H"], g["H"])
 
 
 def test_host_arrays_stay_writable_and_edits_reach_the_device(monkeypatch):
