@@ -752,7 +752,7 @@ def _library_version():
 def end_to_end_ms(tree, work, n_cells, out="numpy"):
     """Wall time of the drop-in call a reference user makes -- ``simulation.sample_density`` returning the
     (N, G) matrix on the host: host plan, kernels, domain check, and the device-to-host copy (PCIe-inclusive;
-    never ``value``).  out="numpy": the reference's int64 ndarray (widened on the device, 8 bytes per count over
+    never ``value``).  out="numpy": the reference's int64 ndarray (int32 over PCIe, widened by host threads under the transfer: device.to_host; until round 5 on the device, 8 bytes per count over
     PCIe); "numpy32": int32 as the device holds it; "csr": scipy.sparse.csr_matrix compacted on the device (8 bytes per
     non-zero over PCIe).  Second of two calls (the first sizes the pinned buffers)."""
     from prosstt_amd import simulation as sim

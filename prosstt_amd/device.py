@@ -328,8 +328,10 @@ def to_host(counts, dtype=np.int64, chunk_bytes=256 << 20, row_order=None):
     PROSSTT_AMD_PINNED_MAX_BYTES (default 32 GiB): DMA straight into the result, no bounce buffers and no
     first-touch page faults; the block goes back to the allocator's cache when the caller drops the array, so
     the pinning cost is paid once per size.  Larger results (or a failed page-lock) take the same chunked path
-    into ordinary memory.  int64 and uint16 are converted on the device, chunk by chunk (two staging buffers),
-    under the transfer of the previous chunk; int32 is copied as it lies.
+    into ordinary memory.  uint16 is narrowed on the device, chunk by chunk (two staging buffers), under the transfer of
+    the previous chunk; int32 is copied as it lies; int64 crosses PCIe as int32 and is widened by the host's threads
+    under the transfer of the next chunk (``_to_host_widened``; ``WIDEN_ON`` = "device" or a matrix under 2^24 counts:
+    widened on the device like uint16 is narrowed, 8 bytes per count over PCIe).
 
     row_order: the device matrix holds its cells in an order of PRESENTATION (``plan_order``): row i is cell
     ``row_order[i]``.  The host array comes back in plan order -- row ``row_order[i]`` = device row i -- the rows of every
@@ -342,6 +344,8 @@ def to_host(counts, dtype=np.int64, chunk_bytes=256 << 20, row_order=None):
         raise ValueError("host counts are int64, int32 or uint16")
     if n == 0 or g == 0:
         return np.zeros((n, g), dtype=dtype)
+    if dtype == np.dtype(np.int64) and WIDEN_ON == "host" and n * g >= (1 << 24):
+        return _to_host_widened(counts, chunk_bytes, row_order)
     # (torch has no arithmetic on uint16: the device narrows to int16 bit patterns, viewed as uint16 on the host)
     t_dtype = {8: torch.int64, 4: torch.int32, 2: torch.int16}[dtype.itemsize]
     host = None
@@ -402,6 +406,81 @@ def to_host(counts, dtype=np.int64, chunk_bytes=256 << 20, row_order=None):
         raise OverflowError("a count of %d does not fit uint16: ask for 'numpy32'" % int(too_big))
     out = host.numpy()
     return out.view(np.uint16) if dtype.itemsize == 2 else out
+
+
+# Where the reference's int64 is formed from the int32 the device holds: "host" (default) -- 4 bytes per count cross PCIe
+# and the host's threads widen each chunk under the transfer of the next; "device" -- widened on the device, 8 bytes per
+# count over PCIe (what rounds 2 to 5 did; the choice for a host with few cores).  Sixteen threads keep up with the bus
+# (tools/widen_probe.py on the 128-core host of an MI355X box: 142 ms on the device; 4 / 8 / 16 / 32 / 64 host threads
+# 130 / 126 / 94 / 142 / 274 ms -- more threads than that cost more in their start-up than they widen).
+WIDEN_ON = os.environ.get("PROSSTT_AMD_WIDEN", "host")
+HOST_THREADS = int(os.environ.get("PROSSTT_AMD_HOST_THREADS", str(max(1, min(16, os.cpu_count() or 1)))))
+
+
+def _to_host_widened(counts, chunk_bytes, row_order):
+    """``to_host`` for int64 with the widening on the host: the int32 chunks arrive in two page-locked bounce buffers by
+    asynchronous copies on a second stream; chunk i - 1 is widened into the result (torch's CPU copy: HOST_THREADS
+    threads) while chunk i is on the bus.  The copy stays PCIe-bound at 4 bytes per count instead of 8."""
+    torch = _torch()
+    n, g = (int(v) for v in counts.shape)
+    host = None
+    if n * g * 8 <= PINNED_RETURN_MAX:
+        try:
+            host = torch.empty((n, g), dtype=torch.int64, pin_memory=True)
+        except RuntimeError:
+            host = None
+    if host is None:
+        host = torch.empty((n, g), dtype=torch.int64)
+    rows = max(1, min(n, int(chunk_bytes) // (g * 4)))
+    dev = counts.device
+    compute = torch.cuda.current_stream(dev)
+    copier = torch.cuda.Stream(dev)
+    inv = None
+    if row_order is not None:
+        order = np.asarray(row_order, dtype=np.int64)
+        if order.shape != (n,):
+            raise ValueError("row_order must have one entry per row")
+        inv_host = np.empty(n, dtype=np.int64)
+        inv_host[order] = np.arange(n, dtype=np.int64)        # device row of host row j
+        inv = torch.as_tensor(inv_host).to(dev)
+    slots = 2 if rows < n else 1
+    bounce = [torch.empty((rows, g), dtype=torch.int32, pin_memory=True) for _ in range(slots)]
+    gathered = [torch.empty((rows, g), dtype=torch.int32, device=dev) for _ in range(slots)] if inv is not None else None
+    arrived = [None, None]
+    bounds = list(range(0, n, rows)) + [n]
+
+    def widen(i):
+        lo, hi = bounds[i], bounds[i + 1]
+        arrived[i % slots].synchronize()
+        host[lo:hi].copy_(bounce[i % slots][:hi - lo])
+
+    threads_before = torch.get_num_threads()
+    torch.set_num_threads(HOST_THREADS)
+    try:
+        copier.wait_stream(compute)                        # the matrix itself
+        for i in range(len(bounds) - 1):
+            lo, hi = bounds[i], bounds[i + 1]
+            slot = i % slots
+            if inv is None:
+                src = counts[lo:hi]
+            else:
+                if arrived[slot] is not None:
+                    compute.wait_event(arrived[slot])       # the gather buffer's previous chunk has left
+                src = torch.index_select(counts, 0, inv[lo:hi], out=gathered[slot][:hi - lo])
+                ready = torch.cuda.Event()
+                ready.record(compute)
+                copier.wait_event(ready)
+            # (the bounce buffer's previous chunk, i - 2, was widened in the last turn of this loop)
+            with torch.cuda.stream(copier):
+                bounce[slot][:hi - lo].copy_(src, non_blocking=True)
+                arrived[slot] = torch.cuda.Event()
+                arrived[slot].record(copier)
+            if i >= 1:
+                widen(i - 1)
+        widen(len(bounds) - 2)
+    finally:
+        torch.set_num_threads(threads_before)
+    return host.numpy()
 
 
 def to_host_csr(counts, chunk_bytes=256 << 20, row_order=None):

@@ -73,6 +73,16 @@ def _comm_device(group=None):
     return torch.device("cpu")
 
 
+def _host_backend_fence(group=None):
+    """RCCL orders a transfer behind the work already enqueued on the current stream, and the work enqueued later behind
+    the transfer.  A HOST backend (gloo: the functional path of the tests and of PROSSTT_BENCH_BACKEND=gloo) reads and
+    writes the device buffer it is handed from its own CPU threads, knowing nothing of streams: the kernels that write a
+    buffer must have finished before it is posted, and the kernels that read a landed buffer before its memory is reused."""
+    import torch
+    if _dist().get_backend(group) != "nccl" and torch.cuda.is_available():
+        torch.cuda.current_stream().synchronize()
+
+
 def assign_branches_by_density(tree, world_size):
     """owner[label] -> rank before any cell exists: longest-processing-time greedy on the density mass
     of the branches (cells are drawn from it; ties by position in ``tree.branches``)."""
@@ -400,6 +410,8 @@ def sample_and_gather(tree, no_cells, alpha=0.3, beta=2, scale=True, scale_v=0.7
         if order == "plan":
             for src, lo, hi, buf in got:
                 out.index_copy_(0, torch.as_tensor(shards[src][lo:hi], dtype=torch.int64, device=dev), buf)
+            if got:
+                _host_backend_fence(group)                     # (gloo only: the staging buffers may be reused now)
 
     # A sender keeps at most two rounds of sends in flight (round r is posted once round r - 2 has left): the root posts
     # round r's receives only after round r - 1 has arrived, and an unbounded queue of sends has nowhere to go on a
@@ -411,6 +423,7 @@ def sample_and_gather(tree, no_cells, alpha=0.3, beta=2, scale=True, scale_v=0.7
             if len(sends) >= 2:
                 for req in sends[-2]:
                     req.wait()
+            _host_backend_fence(group)                         # (gloo only: the chunk has been sampled)
             sends.append(dist.batch_isend_irecv([dist.P2POp(dist.isend, local[lo:hi], peer(dst), group)]))
         if size > 1 and is_root:
             got, reqs = pending
@@ -506,11 +519,14 @@ def gather_rows(local_rows, cell_index, total_rows, group=None, dst=0, chunk_row
             for req in (dist.batch_isend_irecv(ops) if ops else []):
                 req.wait()
         elif sizes[rank]:
-            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, index.contiguous(), peer(dst), group)]):
+            index = index.contiguous()
+            _host_backend_fence(group)
+            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, index, peer(dst), group)]):
                 req.wait()
     rounds = max((n + chunk_rows - 1) // chunk_rows for n in sizes) if max(sizes) else 0
     if rank != dst:
         rows = local_rows.contiguous()
+        _host_backend_fence(group)                             # (gloo only: whatever produced the rows has finished)
         for r in range(rounds):
             lo, hi = r * chunk_rows, min((r + 1) * chunk_rows, sizes[rank])
             if lo >= hi:
@@ -548,4 +564,6 @@ def gather_rows(local_rows, cell_index, total_rows, group=None, dst=0, chunk_row
                 scatter_to_host(out, idx, buf)
             else:
                 out.index_copy_(0, idx, buf)
+        if bufs and not to_host:
+            _host_backend_fence(group)                         # (gloo only: the staging buffers may be reused now)
     return out.numpy() if to_host else out

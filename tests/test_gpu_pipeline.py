@@ -259,6 +259,33 @@ def test_compact_host_returns_and_chunk_generator():
             pass
 
 
+def test_int64_return_widened_on_the_host_equals_the_device_widened_one(monkeypatch):
+    """The reference's int64 matrix: int32 over PCIe and widened by the host's threads under the next chunk's transfer
+    (the default for matrices of 2^24 counts and more) == widened on the device (PROSSTT_AMD_WIDEN=device) == the device
+    tensor, with and without the row gather, for one chunk, many chunks and a ragged last chunk."""
+    import torch
+    from prosstt_amd import device
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    n, g = 4100, 4100                                   # 1.68e7 >= 2^24
+    counts = torch.randint(-3, 70000, (n, g), device="cuda", generator=gen, dtype=torch.int32)
+    want = counts.cpu().numpy().astype(np.int64)
+    order = np.random.default_rng(1).permutation(n)
+    want_perm = np.empty_like(want)
+    want_perm[order] = want
+    for where in ("host", "device"):
+        monkeypatch.setattr(device, "WIDEN_ON", where)
+        for chunk_bytes in (256 << 20, 4 * g * 1000, 4 * g * 333):
+            got = device.to_host(counts, np.int64, chunk_bytes=chunk_bytes)
+            assert got.dtype == np.int64 and np.array_equal(got, want), (where, chunk_bytes)
+            got = device.to_host(counts, np.int64, chunk_bytes=chunk_bytes, row_order=order)
+            assert np.array_equal(got, want_perm), (where, chunk_bytes)
+    monkeypatch.setattr(device, "WIDEN_ON", "host")
+    monkeypatch.setattr(device, "HOST_THREADS", 3)
+    before = torch.get_num_threads()
+    assert np.array_equal(device.to_host(counts, np.int64, chunk_bytes=4 * g * 777), want)
+    assert torch.get_num_threads() == before            # (the thread count of the process is put back)
+
+
 def test_max_attempts_guard():
     from prosstt_amd import simulation as sim
     from prosstt_amd import tree as ptree
