@@ -1,0 +1,29 @@
+/*
+ * prosstt_amd_host.h -- host-side helpers of the drop-in path (libprosstt_amd_host.so: plain C++ threads, no HIP).
+ *
+ * The device library (prosstt_amd.h) returns counts as the int32 it computes in; the reference returns
+ * int64 (/root/reference/prosstt/simulation.py:651: the ndarray that scipy's nbinom(...).rvs() fills).  Widening on the
+ * device doubles the bytes that cross PCIe (8 GB for 50 000 x 20 000); these helpers widen on the host's cores instead,
+ * a chunk at a time under the transfer of the next (prosstt_amd/device.py, _to_host_widened), so that the copy stays
+ * bound by 4 bytes per count.
+ */
+#ifndef PROSSTT_AMD_HOST_H
+#define PROSSTT_AMD_HOST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* dst[i] = (int64_t)src[i], i < count, on `threads` worker threads (a pool kept by the library; clamped to [1, 64]).
+ * The ranges may not overlap.  Returns 0, or -1 for a NULL pointer with count > 0.  Thread-safe (calls are serialised). */
+int prosstt_amd_host_widen_i32_i64(const int32_t* src, int64_t* dst, uint64_t count, int32_t threads);
+
+/* 1 if the widening loop runs its AVX2 form on this machine, 0 for the portable loop. */
+int prosstt_amd_host_has_avx2(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -30,6 +30,11 @@ SYMBOLS = [
 ]
 
 
+HOST_LIB_PATH = os.environ.get("PROSSTT_AMD_HOST_LIB") or os.path.join(_HERE, "lib", "libprosstt_amd_host.so")
+# every symbol include/prosstt_amd_host.h declares
+HOST_SYMBOLS = ["prosstt_amd_host_widen_i32_i64", "prosstt_amd_host_has_avx2"]
+
+
 class NativeError(RuntimeError):
     def __init__(self, code, message):
         super().__init__("prosstt_amd error %d: %s" % (code, message))
@@ -38,6 +43,26 @@ class NativeError(RuntimeError):
 
 _lib = None
 _lock = threading.Lock()
+
+
+_host_lib = None
+
+
+def load_host():
+    """libprosstt_amd_host.so (include/prosstt_amd_host.h: host-side helpers, no HIP), once.  Raises if it has not been built."""
+    global _host_lib
+    with _lock:
+        if _host_lib is not None:
+            return _host_lib
+        if not os.path.exists(HOST_LIB_PATH):
+            raise RuntimeError("%s not found: build it with `make -C prosstt_amd/csrc/host` (or "
+                               "`python -c 'import __graft_entry__ as g; g.build()'`)" % HOST_LIB_PATH)
+        L = ctypes.CDLL(HOST_LIB_PATH)
+        L.prosstt_amd_host_widen_i32_i64.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32]
+        L.prosstt_amd_host_widen_i32_i64.restype = ctypes.c_int
+        L.prosstt_amd_host_has_avx2.restype = ctypes.c_int
+        _host_lib = L
+        return L
 
 
 def load():

@@ -1,0 +1,182 @@
+// libprosstt_amd_host.so: host-side helpers of the drop-in path (include/prosstt_amd_host.h).  No HIP in here.
+//
+// int32 -> int64 on a pool of worker threads.  The result of a 50 000 x 20 000 call is 8 GB: written once, never read
+// back by this code, so the AVX2 form stores past the caches (non-temporal: no read-for-ownership of 8 GB), and the
+// pool is kept between calls (a chunk of 256 MB is widened in a few milliseconds; starting threads per chunk would show).
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include <immintrin.h>
+#include <pthread.h>
+
+#include "../../../include/prosstt_amd_host.h"
+
+#define PH_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+void widen_plain(const int32_t* src, int64_t* dst, uint64_t n)
+{
+    for (uint64_t i = 0; i < n; ++i) dst[i] = (int64_t)src[i];
+}
+
+__attribute__((target("avx2"))) void widen_avx2(const int32_t* src, int64_t* dst, uint64_t n)
+{
+    uint64_t i = 0;
+    // up to a 32-byte boundary of the destination
+    while (i < n && (reinterpret_cast<uintptr_t>(dst + i) & 31u) != 0u) { dst[i] = (int64_t)src[i]; ++i; }
+    for (; i + 16 <= n; i += 16) {
+        const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i));
+        const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 4));
+        const __m128i c = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 8));
+        const __m128i d = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 12));
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i), _mm256_cvtepi32_epi64(a));
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i + 4), _mm256_cvtepi32_epi64(b));
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i + 8), _mm256_cvtepi32_epi64(c));
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i + 12), _mm256_cvtepi32_epi64(d));
+    }
+    for (; i < n; ++i) dst[i] = (int64_t)src[i];
+    _mm_sfence();
+}
+
+bool has_avx2()
+{
+    static const bool yes = __builtin_cpu_supports("avx2");
+    return yes;
+}
+
+// A pool of workers that all run the same job on their own slice; the caller is worker 0.
+class Pool {
+public:
+    ~Pool()
+    {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            quit_ = true;
+        }
+        wake_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+
+    void run(const int32_t* src, int64_t* dst, uint64_t count, int workers)
+    {
+        std::lock_guard<std::mutex> serial(call_);
+        grow(workers - 1);
+        {
+            std::lock_guard<std::mutex> g(m_);
+            src_ = src; dst_ = dst; count_ = count; workers_ = workers;
+            pending_ = workers - 1;
+            ++epoch_;
+        }
+        wake_.notify_all();
+        slice(0);
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [&] { return pending_ == 0; });
+    }
+
+private:
+    void grow(int n)
+    {
+        while ((int)threads_.size() < n) {
+            const int id = (int)threads_.size() + 1;
+            uint64_t seen;
+            {
+                std::lock_guard<std::mutex> g(m_);
+                seen = epoch_;
+            }
+            threads_.emplace_back([this, id, seen] { loop(id, seen); });
+        }
+    }
+
+    void slice(int id)
+    {
+        // slices of whole 64-element blocks, so that every slice but the first starts on a 512-byte boundary of dst
+        // whenever dst itself does
+        const uint64_t blocks = (count_ + 63) / 64;
+        const uint64_t lo = blocks * (uint64_t)id / (uint64_t)workers_ * 64;
+        uint64_t hi = blocks * (uint64_t)(id + 1) / (uint64_t)workers_ * 64;
+        if (hi > count_) hi = count_;
+        if (lo >= hi) return;
+        (has_avx2() ? widen_avx2 : widen_plain)(src_ + lo, dst_ + lo, hi - lo);
+    }
+
+    void loop(int id, uint64_t seen)
+    {
+        for (;;) {
+            std::unique_lock<std::mutex> g(m_);
+            wake_.wait(g, [&] { return quit_ || epoch_ != seen; });
+            if (quit_) return;
+            seen = epoch_;
+            const bool mine = id < workers_;
+            g.unlock();
+            if (mine) {
+                slice(id);
+                g.lock();
+                if (--pending_ == 0) done_.notify_one();
+            }
+        }
+    }
+
+    std::mutex call_, m_;
+    std::condition_variable wake_, done_;
+    std::vector<std::thread> threads_;
+    const int32_t* src_ = nullptr;
+    int64_t* dst_ = nullptr;
+    uint64_t count_ = 0, epoch_ = 0;
+    int workers_ = 1, pending_ = 0;
+    bool quit_ = false;
+};
+
+// The pool is never destroyed (worker threads must not be joined from a library destructor at exit), and a forked child
+// starts without one: the threads of the parent do not exist there.
+Pool* g_pool = nullptr;
+std::mutex g_pool_m;
+
+void forget_pool_in_child()
+{
+    g_pool = nullptr;
+    new (&g_pool_m) std::mutex();
+}
+
+Pool& pool()
+{
+    std::lock_guard<std::mutex> g(g_pool_m);
+    if (!g_pool) {
+        static const int registered = pthread_atfork(nullptr, nullptr, forget_pool_in_child);
+        (void)registered;
+        g_pool = new Pool();
+    }
+    return *g_pool;
+}
+
+}  // namespace
+
+PH_EXPORT int prosstt_amd_host_widen_i32_i64(const int32_t* src, int64_t* dst, uint64_t count, int32_t threads)
+{
+    if (count == 0) return 0;
+    if (!src || !dst) return -1;
+    int workers = threads < 1 ? 1 : (threads > 64 ? 64 : threads);
+    // nothing to share out below a few pages per worker
+    const uint64_t per = 1u << 14;
+    if ((uint64_t)workers > (count + per - 1) / per) workers = (int)((count + per - 1) / per);
+    if (workers <= 1) {
+        (has_avx2() ? widen_avx2 : widen_plain)(src, dst, count);
+        return 0;
+    }
+    try {
+        pool().run(src, dst, count, workers);
+    } catch (...) {                      // (thread creation failed: the caller's thread does all of it)
+        (has_avx2() ? widen_avx2 : widen_plain)(src, dst, count);
+    }
+    return 0;
+}
+
+PH_EXPORT int prosstt_amd_host_has_avx2(void)
+{
+    return has_avx2() ? 1 : 0;
+}

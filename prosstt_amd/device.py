@@ -410,17 +410,17 @@ def to_host(counts, dtype=np.int64, chunk_bytes=256 << 20, row_order=None):
 
 # Where the reference's int64 is formed from the int32 the device holds: "host" (default) -- 4 bytes per count cross PCIe
 # and the host's threads widen each chunk under the transfer of the next; "device" -- widened on the device, 8 bytes per
-# count over PCIe (what rounds 2 to 5 did; the choice for a host with few cores).  Sixteen threads keep up with the bus
-# (tools/widen_probe.py on the 128-core host of an MI355X box: 142 ms on the device; 4 / 8 / 16 / 32 / 64 host threads
-# 130 / 126 / 94 / 142 / 274 ms -- more threads than that cost more in their start-up than they widen).
+# count over PCIe (what rounds 2 to 5 did; the choice for a host with few cores).
 WIDEN_ON = os.environ.get("PROSSTT_AMD_WIDEN", "host")
-HOST_THREADS = int(os.environ.get("PROSSTT_AMD_HOST_THREADS", str(max(1, min(16, os.cpu_count() or 1)))))
+# (tools/widen_probe.py on an MI355X box's host: to_host of C3's matrix 141.5 ms widened on the device, 73 - 77 ms with 4 to 32
+# host threads -- int32 as it lies: 70.6 ms)
+HOST_THREADS = int(os.environ.get("PROSSTT_AMD_HOST_THREADS", str(max(1, min(8, os.cpu_count() or 1)))))
 
 
 def _to_host_widened(counts, chunk_bytes, row_order):
     """``to_host`` for int64 with the widening on the host: the int32 chunks arrive in two page-locked bounce buffers by
-    asynchronous copies on a second stream; chunk i - 1 is widened into the result (torch's CPU copy: HOST_THREADS
-    threads) while chunk i is on the bus.  The copy stays PCIe-bound at 4 bytes per count instead of 8."""
+    asynchronous copies on a second stream; chunk i - 1 is widened into the result by HOST_THREADS threads of the host
+    library's pool (libprosstt_amd_host.so, include/prosstt_amd_host.h: non-temporal AVX2 stores) while chunk i is on the bus.  The copy stays PCIe-bound at 4 bytes per count instead of 8."""
     torch = _torch()
     n, g = (int(v) for v in counts.shape)
     host = None
@@ -449,37 +449,37 @@ def _to_host_widened(counts, chunk_bytes, row_order):
     arrived = [None, None]
     bounds = list(range(0, n, rows)) + [n]
 
+    widen_lib = _native.load_host()
+    host_at = host.data_ptr()
+
     def widen(i):
         lo, hi = bounds[i], bounds[i + 1]
         arrived[i % slots].synchronize()
-        host[lo:hi].copy_(bounce[i % slots][:hi - lo])
+        if widen_lib.prosstt_amd_host_widen_i32_i64(ctypes.c_void_p(bounce[i % slots].data_ptr()), ctypes.c_void_p(host_at + lo * g * 8),
+                                                    ctypes.c_uint64((hi - lo) * g), HOST_THREADS) != 0:
+            raise RuntimeError("prosstt_amd_host_widen_i32_i64 refused its arguments")
 
-    threads_before = torch.get_num_threads()
-    torch.set_num_threads(HOST_THREADS)
-    try:
-        copier.wait_stream(compute)                        # the matrix itself
-        for i in range(len(bounds) - 1):
-            lo, hi = bounds[i], bounds[i + 1]
-            slot = i % slots
-            if inv is None:
-                src = counts[lo:hi]
-            else:
-                if arrived[slot] is not None:
-                    compute.wait_event(arrived[slot])       # the gather buffer's previous chunk has left
-                src = torch.index_select(counts, 0, inv[lo:hi], out=gathered[slot][:hi - lo])
-                ready = torch.cuda.Event()
-                ready.record(compute)
-                copier.wait_event(ready)
-            # (the bounce buffer's previous chunk, i - 2, was widened in the last turn of this loop)
-            with torch.cuda.stream(copier):
-                bounce[slot][:hi - lo].copy_(src, non_blocking=True)
-                arrived[slot] = torch.cuda.Event()
-                arrived[slot].record(copier)
-            if i >= 1:
-                widen(i - 1)
-        widen(len(bounds) - 2)
-    finally:
-        torch.set_num_threads(threads_before)
+    copier.wait_stream(compute)                        # the matrix itself
+    for i in range(len(bounds) - 1):
+        lo, hi = bounds[i], bounds[i + 1]
+        slot = i % slots
+        if inv is None:
+            src = counts[lo:hi]
+        else:
+            if arrived[slot] is not None:
+                compute.wait_event(arrived[slot])       # the gather buffer's previous chunk has left
+            src = torch.index_select(counts, 0, inv[lo:hi], out=gathered[slot][:hi - lo])
+            ready = torch.cuda.Event()
+            ready.record(compute)
+            copier.wait_event(ready)
+        # (the bounce buffer's previous chunk, i - 2, was widened in the last turn of this loop)
+        with torch.cuda.stream(copier):
+            bounce[slot][:hi - lo].copy_(src, non_blocking=True)
+            arrived[slot] = torch.cuda.Event()
+            arrived[slot].record(copier)
+        if i >= 1:
+            widen(i - 1)
+    widen(len(bounds) - 2)
     return host.numpy()
 
 

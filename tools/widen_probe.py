@@ -38,7 +38,7 @@ def main():
         timed(lambda: device.to_host(counts, np.int64)), timed(lambda: device.to_host(counts, np.int64, row_order=order)),
         timed(lambda: device.to_host(counts, np.int32))))
     device.WIDEN_ON = "host"
-    for threads in (4, 8, 16, 32, 64):
+    for threads in (4, 8, 12, 16, 20, 24, 32, 64):
         device.HOST_THREADS = threads
         got = device.to_host(counts, np.int64)
         same = np.array_equal(got, want)
@@ -48,10 +48,11 @@ def main():
         print("host-widened, %2d threads: %.1f ms   with row gather %.1f ms   equal %s %s" % (
             threads, timed(lambda: device.to_host(counts, np.int64)),
             timed(lambda: device.to_host(counts, np.int64, row_order=order)), same, same_perm))
-    for chunk in (64 << 20, 128 << 20, 512 << 20):
-        device.HOST_THREADS = 32
-        print("host-widened, 32 threads, chunks of %d MB: %.1f ms" % (
-            chunk >> 20, timed(lambda: device.to_host(counts, np.int64, chunk_bytes=chunk))))
+    for threads in (12, 16, 20):
+        for chunk in (32 << 20, 64 << 20, 128 << 20, 512 << 20):
+            device.HOST_THREADS = threads
+            print("host-widened, %d threads, chunks of %d MB: %.1f ms" % (
+                threads, chunk >> 20, timed(lambda: device.to_host(counts, np.int64, chunk_bytes=chunk))))
 
 
 if __name__ == "__main__":
