@@ -426,6 +426,37 @@ def run_case(job, config, scaling, cells_per_gpu, steps, warmup, strict_steps, g
     return res
 
 
+def hbm_achievable(job, n_cells, G, reps=10):
+    """What this device's HBM delivers to the simplest kernels, measured in this process beside the vendor peak that
+    ``roofline.frac`` is priced against (SURVEY section 8 d: "use the vendor peak as denominator; also report the
+    achievable"): a fill of an (N, G) int32 matrix -- write-only, like the sampler's traffic -- and a device-to-device
+    copy of one (bytes read + bytes written).  torch's own kernels: a yardstick, not part of the path."""
+    torch = job.torch
+    dev = job.ctx.torch_device
+    a = torch.empty((n_cells, G), dtype=torch.int32, device=dev)
+    b = torch.empty((n_cells, G), dtype=torch.int32, device=dev)
+    nbytes = 4.0 * n_cells * G
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    t_fill = timed(lambda: a.fill_(3))
+    t_copy = timed(lambda: b.copy_(a))
+    del a, b
+    return {"fill_GBps": nbytes / t_fill / 1e9, "copy_GBps": 2.0 * nbytes / t_copy / 1e9, "matrix_bytes": nbytes,
+            "note": "torch's fill_ (write-only) and copy_ (read + write) of an int32 matrix of the workload's size, %d repeats each; "
+                    "the sampler writes every count once, so fill_GBps is the rate a kernel with no arithmetic at all reaches on "
+                    "this traffic" % reps}
+
+
 def time_gather(job, res, out, mine):
     """The one exchange of the path: count rows to rank 0 (point-to-point over xGMI), timed on its own.
     Bounded so that root's copy of the whole matrix plus its own shard stays far inside 288 GB."""
@@ -541,8 +572,11 @@ def main():
     main_case["target_case"] = target_case
 
     end_to_end = None
+    main_case["achievable"] = None
     if world == 1:
         main_case.pop("shard", None)
+        if 8.0 * main_case["cells_on_rank"] * G < 0.4 * job.torch.cuda.get_device_properties(job.ctx.device).total_memory:
+            main_case["achievable"] = hbm_achievable(job, main_case["cells_on_rank"], G)
     if world == 1 and not args.no_end_to_end and rank == 0:
         end_to_end = tuple(end_to_end_ms(main_case["tree"], work, n_total, out) for out in ("numpy", "numpy32", "csr"))
 
@@ -694,6 +728,7 @@ def assemble_line(args, job, main_case, strong, end_to_end, extras_error):
                      "kernel_ms": kms,
                      "frac_whole_step": abytes / (ms_per_step * 1e-3) / HBM_PEAK,
                      "algorithmic_bytes_per_launch": abytes, "kernel_source_sha": kernel_source_sha(),
+                     "achievable": main_case.get("achievable"),
                      "note": "frac = algorithmic bytes / the dominant kernel's mean duration (HIP events, max over "
                              "ranks); frac_whole_step prices them against ms_per_step (K3h, prep kernels, gaps). "
                              "VALU-issue-bound sampler: DESIGN.md section 6 and profiles/"},
