@@ -1,0 +1,32 @@
+"""End to end of the drop-in call (sample_density -> int64 ndarray) on C3 for several sizes of the host library's widening pool,
+beside the int32 return.  Usage: python3 tools/e2e_threads.py"""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from prosstt_amd import device, simulation as sim, workloads  # noqa: E402
+
+work = workloads.build("C3")
+tree, n = work.tree, work.cfg["N"]
+
+
+def call(out):
+    best = None
+    for _ in range(3):
+        np.random.seed(work.cfg["seed"] + 1)
+        t0 = time.perf_counter()
+        x = sim.sample_density(tree, n, alpha=work.alpha, beta=work.beta, out=out)[0]
+        dt = (time.perf_counter() - t0) * 1e3
+        del x
+        best = dt if best is None else min(best, dt)
+    return best
+
+
+print("int32: %.1f ms" % call("numpy32"))
+for threads in (4, 8, 16, 32):
+    device.HOST_THREADS = threads
+    print("int64, %2d host threads: %.1f ms" % (threads, call("numpy")))
+device.WIDEN_ON = "device"
+print("int64 widened on the device: %.1f ms" % call("numpy"))
