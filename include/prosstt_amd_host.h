@@ -20,6 +20,11 @@ extern "C" {
  * The ranges may not overlap.  Returns 0, or -1 for a NULL pointer with count > 0.  Thread-safe (calls are serialised). */
 int prosstt_amd_host_widen_i32_i64(const int32_t* src, int64_t* dst, uint64_t count, int32_t threads);
 
+/* The same from a uint16 source: the transfer format of prosstt_amd/device.py -- the low 16 bits of every count, 2 bytes over
+ * PCIe; the few counts above 65 535 travel beside them as (position, value) pairs and are written over the widened matrix. */
+int prosstt_amd_host_widen_u16_i64(const uint16_t* src, int64_t* dst, uint64_t count, int32_t threads);
+int prosstt_amd_host_widen_u16_i32(const uint16_t* src, int32_t* dst, uint64_t count, int32_t threads);
+
 /* 1 if the widening loop runs its AVX2 form on this machine, 0 for the portable loop. */
 int prosstt_amd_host_has_avx2(void);
 

@@ -3,6 +3,7 @@
 // int32 -> int64 on a pool of worker threads.  The result of a 50 000 x 20 000 call is 8 GB: written once, never read
 // back by this code, so the AVX2 form stores past the caches (non-temporal: no read-for-ownership of 8 GB), and the
 // pool is kept between calls (a chunk of 256 MB is widened in a few milliseconds; starting threads per chunk would show).
+#include <atomic>
 #include <condition_variable>
 #include <cstdint>
 #include <cstring>
@@ -23,6 +24,46 @@ namespace {
 void widen_plain(const int32_t* src, int64_t* dst, uint64_t n)
 {
     for (uint64_t i = 0; i < n; ++i) dst[i] = (int64_t)src[i];
+}
+
+void widen16_plain(const uint16_t* src, int64_t* dst, uint64_t n)
+{
+    for (uint64_t i = 0; i < n; ++i) dst[i] = (int64_t)src[i];
+}
+
+void widen16to32_plain(const uint16_t* src, int32_t* dst, uint64_t n)
+{
+    for (uint64_t i = 0; i < n; ++i) dst[i] = (int32_t)src[i];
+}
+
+__attribute__((target("avx2"))) void widen16_avx2(const uint16_t* src, int64_t* dst, uint64_t n)
+{
+    uint64_t i = 0;
+    while (i < n && (reinterpret_cast<uintptr_t>(dst + i) & 31u) != 0u) { dst[i] = (int64_t)src[i]; ++i; }
+    for (; i + 16 <= n; i += 16) {
+        const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i));           // 8 counts
+        const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 8));
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i), _mm256_cvtepu16_epi64(a));
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i + 4), _mm256_cvtepu16_epi64(_mm_srli_si128(a, 8)));
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i + 8), _mm256_cvtepu16_epi64(b));
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i + 12), _mm256_cvtepu16_epi64(_mm_srli_si128(b, 8)));
+    }
+    for (; i < n; ++i) dst[i] = (int64_t)src[i];
+    _mm_sfence();
+}
+
+__attribute__((target("avx2"))) void widen16to32_avx2(const uint16_t* src, int32_t* dst, uint64_t n)
+{
+    uint64_t i = 0;
+    while (i < n && (reinterpret_cast<uintptr_t>(dst + i) & 31u) != 0u) { dst[i] = (int32_t)src[i]; ++i; }
+    for (; i + 16 <= n; i += 16) {
+        const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i));
+        const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 8));
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i), _mm256_cvtepu16_epi32(a));
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i + 8), _mm256_cvtepu16_epi32(b));
+    }
+    for (; i < n; ++i) dst[i] = (int32_t)src[i];
+    _mm_sfence();
 }
 
 __attribute__((target("avx2"))) void widen_avx2(const int32_t* src, int64_t* dst, uint64_t n)
@@ -63,13 +104,15 @@ public:
         for (auto& t : threads_) t.join();
     }
 
-    void run(const int32_t* src, int64_t* dst, uint64_t count, int workers)
+    // kind: 0 int32 -> int64, 1 uint16 -> int64, 2 uint16 -> int32
+    void run(const void* src, void* dst, uint64_t count, int workers, int kind)
     {
         std::lock_guard<std::mutex> serial(call_);
         grow(workers - 1);
         {
             std::lock_guard<std::mutex> g(m_);
-            src_ = src; dst_ = dst; count_ = count; workers_ = workers;
+            src_ = src; dst_ = dst; count_ = count; workers_ = workers; kind_ = kind;
+            next_.store(0, std::memory_order_relaxed);
             pending_ = workers - 1;
             ++epoch_;
         }
@@ -93,17 +136,31 @@ private:
         }
     }
 
-    void slice(int id)
+    void slice(int)
     {
-        // slices of whole 64-element blocks, so that every slice but the first starts on a 512-byte boundary of dst
-        // whenever dst itself does
-        const uint64_t blocks = (count_ + 63) / 64;
-        const uint64_t lo = blocks * (uint64_t)id / (uint64_t)workers_ * 64;
-        uint64_t hi = blocks * (uint64_t)(id + 1) / (uint64_t)workers_ * 64;
-        if (hi > count_) hi = count_;
-        if (lo >= hi) return;
-        (has_avx2() ? widen_avx2 : widen_plain)(src_ + lo, dst_ + lo, hi - lo);
+        // Pieces of kPiece counts, handed out by one counter: the workers are not pinned, and one that shares its core or
+        // sits a socket away from the memory would otherwise decide how long the whole job takes.  (Pieces start on
+        // multiples of 2^17 counts, so every piece but a misaligned first starts on a cache line of dst.)
+        for (;;) {
+            const uint64_t lo = next_.fetch_add(kPiece, std::memory_order_relaxed);
+            if (lo >= count_) return;
+            const uint64_t n = count_ - lo < kPiece ? count_ - lo : kPiece;
+            convert(kind_, src_, dst_, lo, n);
+        }
     }
+
+public:
+    static void convert(int kind, const void* src, void* dst, uint64_t lo, uint64_t n)
+    {
+        if (kind == 0)
+            (has_avx2() ? widen_avx2 : widen_plain)(static_cast<const int32_t*>(src) + lo, static_cast<int64_t*>(dst) + lo, n);
+        else if (kind == 1)
+            (has_avx2() ? widen16_avx2 : widen16_plain)(static_cast<const uint16_t*>(src) + lo, static_cast<int64_t*>(dst) + lo, n);
+        else
+            (has_avx2() ? widen16to32_avx2 : widen16to32_plain)(static_cast<const uint16_t*>(src) + lo, static_cast<int32_t*>(dst) + lo, n);
+    }
+
+private:
 
     void loop(int id, uint64_t seen)
     {
@@ -122,13 +179,15 @@ private:
         }
     }
 
+    static constexpr uint64_t kPiece = 1u << 17;
+    std::atomic<uint64_t> next_{0};
     std::mutex call_, m_;
     std::condition_variable wake_, done_;
     std::vector<std::thread> threads_;
-    const int32_t* src_ = nullptr;
-    int64_t* dst_ = nullptr;
+    const void* src_ = nullptr;
+    void* dst_ = nullptr;
     uint64_t count_ = 0, epoch_ = 0;
-    int workers_ = 1, pending_ = 0;
+    int workers_ = 1, pending_ = 0, kind_ = 0;
     bool quit_ = false;
 };
 
@@ -156,7 +215,9 @@ Pool& pool()
 
 }  // namespace
 
-PH_EXPORT int prosstt_amd_host_widen_i32_i64(const int32_t* src, int64_t* dst, uint64_t count, int32_t threads)
+namespace {
+
+int convert_on_pool(const void* src, void* dst, uint64_t count, int32_t threads, int kind)
 {
     if (count == 0) return 0;
     if (!src || !dst) return -1;
@@ -165,15 +226,32 @@ PH_EXPORT int prosstt_amd_host_widen_i32_i64(const int32_t* src, int64_t* dst, u
     const uint64_t per = 1u << 14;
     if ((uint64_t)workers > (count + per - 1) / per) workers = (int)((count + per - 1) / per);
     if (workers <= 1) {
-        (has_avx2() ? widen_avx2 : widen_plain)(src, dst, count);
+        Pool::convert(kind, src, dst, 0, count);
         return 0;
     }
     try {
-        pool().run(src, dst, count, workers);
+        pool().run(src, dst, count, workers, kind);
     } catch (...) {                      // (thread creation failed: the caller's thread does all of it)
-        (has_avx2() ? widen_avx2 : widen_plain)(src, dst, count);
+        Pool::convert(kind, src, dst, 0, count);
     }
     return 0;
+}
+
+}  // namespace
+
+PH_EXPORT int prosstt_amd_host_widen_i32_i64(const int32_t* src, int64_t* dst, uint64_t count, int32_t threads)
+{
+    return convert_on_pool(src, dst, count, threads, 0);
+}
+
+PH_EXPORT int prosstt_amd_host_widen_u16_i64(const uint16_t* src, int64_t* dst, uint64_t count, int32_t threads)
+{
+    return convert_on_pool(src, dst, count, threads, 1);
+}
+
+PH_EXPORT int prosstt_amd_host_widen_u16_i32(const uint16_t* src, int32_t* dst, uint64_t count, int32_t threads)
+{
+    return convert_on_pool(src, dst, count, threads, 2);
 }
 
 PH_EXPORT int prosstt_amd_host_has_avx2(void)

@@ -329,9 +329,10 @@ def to_host(counts, dtype=np.int64, chunk_bytes=256 << 20, row_order=None):
     first-touch page faults; the block goes back to the allocator's cache when the caller drops the array, so
     the pinning cost is paid once per size.  Larger results (or a failed page-lock) take the same chunked path
     into ordinary memory.  uint16 is narrowed on the device, chunk by chunk (two staging buffers), under the transfer of
-    the previous chunk; int32 is copied as it lies; int64 crosses PCIe as int32 and is widened by the host's threads
-    under the transfer of the next chunk (``_to_host_widened``; ``WIDEN_ON`` = "device" or a matrix under 2^24 counts:
-    widened on the device like uint16 is narrowed, 8 bytes per count over PCIe).
+    the previous chunk.  int64 and int32 of 2^24 counts or more cross PCIe in a narrower wire format -- their low 16 bits,
+    and the few entries with high bits set beside them (``WIRE``), or the int32 as it lies -- and are widened by the host library's threads under the transfer
+    of the next chunk (``_to_host_widened``; ``WIDEN_ON`` = "device", or a smaller matrix: int64 is formed on the device
+    like uint16 is narrowed and 8 bytes per count cross PCIe, int32 is copied as it lies).
 
     row_order: the device matrix holds its cells in an order of PRESENTATION (``plan_order``): row i is cell
     ``row_order[i]``.  The host array comes back in plan order -- row ``row_order[i]`` = device row i -- the rows of every
@@ -344,8 +345,14 @@ def to_host(counts, dtype=np.int64, chunk_bytes=256 << 20, row_order=None):
         raise ValueError("host counts are int64, int32 or uint16")
     if n == 0 or g == 0:
         return np.zeros((n, g), dtype=dtype)
-    if dtype == np.dtype(np.int64) and WIDEN_ON == "host" and n * g >= (1 << 24):
-        return _to_host_widened(counts, chunk_bytes, row_order)
+    if dtype.itemsize >= 4 and WIDEN_ON == "host" and n * g >= (1 << 24):
+        if WIRE == "u16":
+            try:
+                return _to_host_widened(counts, chunk_bytes, row_order, dtype, "u16")
+            except _WireTooNarrow:
+                pass
+        if dtype.itemsize == 8:
+            return _to_host_widened(counts, chunk_bytes, row_order, dtype, "i32")
     # (torch has no arithmetic on uint16: the device narrows to int16 bit patterns, viewed as uint16 on the host)
     t_dtype = {8: torch.int64, 4: torch.int32, 2: torch.int16}[dtype.itemsize]
     host = None
@@ -408,29 +415,46 @@ def to_host(counts, dtype=np.int64, chunk_bytes=256 << 20, row_order=None):
     return out.view(np.uint16) if dtype.itemsize == 2 else out
 
 
-# Where the reference's int64 is formed from the int32 the device holds: "host" (default) -- 4 bytes per count cross PCIe
-# and the host's threads widen each chunk under the transfer of the next; "device" -- widened on the device, 8 bytes per
-# count over PCIe (what rounds 2 to 5 did; the choice for a host with few cores).
+# How an int64 / int32 host return of 2^24 counts or more travels.  WIDEN_ON = "host" (default): the matrix crosses PCIe in
+# a WIRE format narrower than its type and the host library's threads (libprosstt_amd_host.so) widen chunk i - 1 into the
+# result while chunk i is on the bus; "device": as rounds 2 to 5 did -- int64 formed on the device, 8 bytes per count over
+# PCIe, int32 copied as it lies (the choice for a host with very few cores).  WIRE = "u16" (default): the low 16 bits of
+# every count, 2 bytes over PCIe, and beside them the few entries that have high bits set (a count above 65 535: C3's
+# largest is 84 036; a negative entry of a matrix that is not one of counts) as (position, value) pairs that are written
+# over the widened matrix at the end; a matrix in which more than one entry in 256 of a chunk is such an exception is
+# sent again as int32.  "i32": the int32 as it lies.
+# (tools/host_widen_probe.py, tools/e2e_threads.py on an MI355X box's host: the pool writes 250 - 340 GB/s from eight threads
+# on; PCIe carries 52 GB/s.  C3 end to end: int64 147 -> 48 ms, int32 76 -> 44 ms.)
 WIDEN_ON = os.environ.get("PROSSTT_AMD_WIDEN", "host")
-# (tools/widen_probe.py on an MI355X box's host: to_host of C3's matrix 141.5 ms widened on the device, 73 - 77 ms with 4 to 32
-# host threads -- int32 as it lies: 70.6 ms)
-HOST_THREADS = int(os.environ.get("PROSSTT_AMD_HOST_THREADS", str(max(1, min(8, os.cpu_count() or 1)))))
+WIRE = os.environ.get("PROSSTT_AMD_WIRE", "u16")
+HOST_THREADS = int(os.environ.get("PROSSTT_AMD_HOST_THREADS", str(max(1, min(16, os.cpu_count() or 1)))))
 
 
-def _to_host_widened(counts, chunk_bytes, row_order):
-    """``to_host`` for int64 with the widening on the host: the int32 chunks arrive in two page-locked bounce buffers by
-    asynchronous copies on a second stream; chunk i - 1 is widened into the result by HOST_THREADS threads of the host
-    library's pool (libprosstt_amd_host.so, include/prosstt_amd_host.h: non-temporal AVX2 stores) while chunk i is on the bus.  The copy stays PCIe-bound at 4 bytes per count instead of 8."""
+class _WireTooNarrow(Exception):
+    """Too many entries of a chunk do not fit the uint16 wire: the copy starts again with int32."""
+
+
+def _to_host_widened(counts, chunk_bytes, row_order, dtype, wire):
+    """``to_host`` for int64 / int32 with the widening on the host: the chunks arrive in their wire format (int32 as the
+    device holds it, or narrowed to uint16 on the device) in two page-locked bounce buffers by asynchronous copies on a
+    second stream; chunk i - 1 is widened into the result by HOST_THREADS threads of the host library's pool
+    (libprosstt_amd_host.so, include/prosstt_amd_host.h: non-temporal AVX2 stores) while chunk i is on the bus.  The copy
+    is bound by the wire's 4 or 2 bytes per count over PCIe, not by the 8 or 4 of the result."""
     torch = _torch()
     n, g = (int(v) for v in counts.shape)
+    t_out = torch.int64 if dtype.itemsize == 8 else torch.int32
+    t_wire = torch.int16 if wire == "u16" else torch.int32          # (uint16 bit patterns: torch has no arithmetic on uint16)
+    lib = _native.load_host()
+    widen = {("i32", 8): lib.prosstt_amd_host_widen_i32_i64, ("u16", 8): lib.prosstt_amd_host_widen_u16_i64,
+             ("u16", 4): lib.prosstt_amd_host_widen_u16_i32}[(wire, dtype.itemsize)]
     host = None
-    if n * g * 8 <= PINNED_RETURN_MAX:
+    if n * g * dtype.itemsize <= PINNED_RETURN_MAX:
         try:
-            host = torch.empty((n, g), dtype=torch.int64, pin_memory=True)
+            host = torch.empty((n, g), dtype=t_out, pin_memory=True)
         except RuntimeError:
             host = None
     if host is None:
-        host = torch.empty((n, g), dtype=torch.int64)
+        host = torch.empty((n, g), dtype=t_out)
     rows = max(1, min(n, int(chunk_bytes) // (g * 4)))
     dev = counts.device
     compute = torch.cuda.current_stream(dev)
@@ -444,31 +468,50 @@ def _to_host_widened(counts, chunk_bytes, row_order):
         inv_host[order] = np.arange(n, dtype=np.int64)        # device row of host row j
         inv = torch.as_tensor(inv_host).to(dev)
     slots = 2 if rows < n else 1
-    bounce = [torch.empty((rows, g), dtype=torch.int32, pin_memory=True) for _ in range(slots)]
-    gathered = [torch.empty((rows, g), dtype=torch.int32, device=dev) for _ in range(slots)] if inv is not None else None
+    bounce = [torch.empty((rows, g), dtype=t_wire, pin_memory=True) for _ in range(slots)]
+    # device staging: the chunk's rows gathered (int32), and -- for the uint16 wire -- narrowed
+    gathered = torch.empty((rows, g), dtype=torch.int32, device=dev) if (inv is not None and wire == "u16") else None
+    staged = [torch.empty((rows, g), dtype=t_wire, device=dev) for _ in range(slots)] if (inv is not None or wire == "u16") else None
     arrived = [None, None]
     bounds = list(range(0, n, rows)) + [n]
-
-    widen_lib = _native.load_host()
     host_at = host.data_ptr()
+    exceptions = []                                     # uint16 wire: (positions in the host matrix, values) of what did not fit
 
-    def widen(i):
+    def note_exceptions(block, lo):
+        """The entries of the chunk (int32, rows in host order from row ``lo``) with high bits set (synchronises the compute stream: their number)."""
+        where = torch.nonzero(torch.bitwise_and(block, -65536).view(-1)).squeeze(1)
+        if int(where.numel()) * 256 > int(block.numel()):
+            copier.synchronize()                        # (nothing of this attempt is in flight when its buffers go back)
+            raise _WireTooNarrow()
+        if int(where.numel()):
+            exceptions.append(((where + lo * g).cpu(), block.reshape(-1).index_select(0, where).cpu()))
+
+    def widen_chunk(i):
         lo, hi = bounds[i], bounds[i + 1]
         arrived[i % slots].synchronize()
-        if widen_lib.prosstt_amd_host_widen_i32_i64(ctypes.c_void_p(bounce[i % slots].data_ptr()), ctypes.c_void_p(host_at + lo * g * 8),
-                                                    ctypes.c_uint64((hi - lo) * g), HOST_THREADS) != 0:
-            raise RuntimeError("prosstt_amd_host_widen_i32_i64 refused its arguments")
+        if widen(ctypes.c_void_p(bounce[i % slots].data_ptr()), ctypes.c_void_p(host_at + lo * g * dtype.itemsize),
+                 ctypes.c_uint64((hi - lo) * g), HOST_THREADS) != 0:
+            raise RuntimeError("the host library refused its arguments")
 
     copier.wait_stream(compute)                        # the matrix itself
     for i in range(len(bounds) - 1):
         lo, hi = bounds[i], bounds[i + 1]
         slot = i % slots
-        if inv is None:
+        if staged is None:
             src = counts[lo:hi]
         else:
             if arrived[slot] is not None:
-                compute.wait_event(arrived[slot])       # the gather buffer's previous chunk has left
-            src = torch.index_select(counts, 0, inv[lo:hi], out=gathered[slot][:hi - lo])
+                compute.wait_event(arrived[slot])       # the staging buffer's previous chunk has left
+            src = staged[slot][:hi - lo]
+            if inv is None:
+                src.copy_(counts[lo:hi])                # the low 16 bits
+                note_exceptions(counts[lo:hi], lo)
+            elif wire == "i32":
+                torch.index_select(counts, 0, inv[lo:hi], out=src)
+            else:
+                torch.index_select(counts, 0, inv[lo:hi], out=gathered[:hi - lo])
+                src.copy_(gathered[:hi - lo])
+                note_exceptions(gathered[:hi - lo], lo)
             ready = torch.cuda.Event()
             ready.record(compute)
             copier.wait_event(ready)
@@ -478,8 +521,11 @@ def _to_host_widened(counts, chunk_bytes, row_order):
             arrived[slot] = torch.cuda.Event()
             arrived[slot].record(copier)
         if i >= 1:
-            widen(i - 1)
-    widen(len(bounds) - 2)
+            widen_chunk(i - 1)
+    widen_chunk(len(bounds) - 2)
+    flat = host.view(-1)
+    for where, values in exceptions:
+        flat[where] = values.to(t_out)
     return host.numpy()
 
 

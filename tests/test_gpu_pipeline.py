@@ -259,31 +259,49 @@ def test_compact_host_returns_and_chunk_generator():
             pass
 
 
-def test_int64_return_widened_on_the_host_equals_the_device_widened_one(monkeypatch):
-    """The reference's int64 matrix: int32 over PCIe and widened by the host's threads under the next chunk's transfer
-    (the default for matrices of 2^24 counts and more) == widened on the device (PROSSTT_AMD_WIDEN=device) == the device
-    tensor, with and without the row gather, for one chunk, many chunks and a ragged last chunk."""
+def test_host_returns_widened_on_the_host_equal_the_device_widened_ones(monkeypatch):
+    """int64 / int32 returns of 2^24 counts and more cross PCIe in a wire format (the low 16 bits of every count and, beside
+    them, the entries that have high bits set; int32 when there are too many of those) and are widened by the host
+    library's threads under the next chunk's transfer == widened on the device (PROSSTT_AMD_WIDEN=device) == the device
+    tensor: with and without the row gather, for one chunk, many chunks and a ragged last chunk, for a matrix that fits
+    the narrow wire, one with a few counts above it and negative entries, and one that is mostly above it."""
     import torch
     from prosstt_amd import device
     gen = torch.Generator(device="cuda").manual_seed(5)
     n, g = 4100, 4100                                   # 1.68e7 >= 2^24
-    counts = torch.randint(-3, 70000, (n, g), device="cuda", generator=gen, dtype=torch.int32)
-    want = counts.cpu().numpy().astype(np.int64)
     order = np.random.default_rng(1).permutation(n)
-    want_perm = np.empty_like(want)
-    want_perm[order] = want
-    for where in ("host", "device"):
-        monkeypatch.setattr(device, "WIDEN_ON", where)
-        for chunk_bytes in (256 << 20, 4 * g * 1000, 4 * g * 333):
-            got = device.to_host(counts, np.int64, chunk_bytes=chunk_bytes)
-            assert got.dtype == np.int64 and np.array_equal(got, want), (where, chunk_bytes)
-            got = device.to_host(counts, np.int64, chunk_bytes=chunk_bytes, row_order=order)
-            assert np.array_equal(got, want_perm), (where, chunk_bytes)
+    fits = torch.randint(0, 65536, (n, g), device="cuda", generator=gen, dtype=torch.int32)
+    fits[17, 5], fits[n - 1, g - 1] = 65535, 0
+    few = fits.clone()
+    few[n // 2, 7], few[0, 0], few[n - 1, g - 2], few[3, 3], few[1000, 4000] = 65536, 84036, 2 ** 31 - 1, -1, -2 ** 31
+    few[2000] += 70000                                  # a whole row above the wire (under one entry in 256 of any chunk here)
+    mostly = fits + 100000
+    calls = []
+    real = device._to_host_widened
+    monkeypatch.setattr(device, "_to_host_widened", lambda *a: (calls.append(a[4]), real(*a))[1])
+    for name, counts, wires in (("fits", fits, ["u16"]), ("few", few, ["u16"]), ("mostly", mostly, ["u16", "i32"])):
+        want32 = counts.cpu().numpy()
+        for dtype in (np.int64, np.int32):
+            want = want32.astype(dtype)
+            want_perm = np.empty_like(want)
+            want_perm[order] = want
+            for where in ("host", "device"):
+                monkeypatch.setattr(device, "WIDEN_ON", where)
+                for chunk_bytes in (256 << 20, 4 * g * 1000, 4 * g * 333):
+                    del calls[:]
+                    got = device.to_host(counts, dtype, chunk_bytes=chunk_bytes)
+                    assert got.dtype == dtype and np.array_equal(got, want), (name, dtype, where, chunk_bytes)
+                    if where == "host":                 # (int32 of a matrix the narrow wire cannot carry: copied as it lies)
+                        assert calls == (wires if dtype == np.int64 or wires == ["u16"] else ["u16"]), (name, dtype, calls)
+                    got = device.to_host(counts, dtype, chunk_bytes=chunk_bytes, row_order=order)
+                    assert np.array_equal(got, want_perm), (name, dtype, where, chunk_bytes)
     monkeypatch.setattr(device, "WIDEN_ON", "host")
+    monkeypatch.setattr(device, "WIRE", "i32")
+    del calls[:]
+    assert np.array_equal(device.to_host(few, np.int64, chunk_bytes=4 * g * 777), few.cpu().numpy().astype(np.int64)) and calls == ["i32"]
+    monkeypatch.setattr(device, "WIRE", "u16")
     monkeypatch.setattr(device, "HOST_THREADS", 3)
-    before = torch.get_num_threads()
-    assert np.array_equal(device.to_host(counts, np.int64, chunk_bytes=4 * g * 777), want)
-    assert torch.get_num_threads() == before            # (the thread count of the process is put back)
+    assert np.array_equal(device.to_host(few, np.int64, chunk_bytes=4 * g * 777, row_order=order)[order], few.cpu().numpy())
 
 
 def test_max_attempts_guard():

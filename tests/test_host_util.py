@@ -58,6 +58,23 @@ def test_widening_equals_astype_for_every_length_alignment_and_thread_count():
     assert L.prosstt_amd_host_widen_i32_i64(None, None, 10, 4) == -1
 
 
+@pytest.mark.parametrize("out_dtype", [np.int64, np.int32])
+def test_widening_from_the_uint16_wire_format(out_dtype):
+    L = lib()
+    fn = L.prosstt_amd_host_widen_u16_i64 if out_dtype == np.int64 else L.prosstt_amd_host_widen_u16_i32
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 7, 8, 15, 16, 17, 31, 33, 1000, (1 << 14) + 3, 2_000_003):
+        x = rng.integers(0, 65536, size=n, dtype=np.int64).astype(np.uint16)
+        x[:min(n, 2)] = np.array([65535, 0], dtype=np.uint16)[:min(n, 2)]
+        for threads in (1, 3, 64):
+            for offset in (0, 1, 3, 5):
+                y = np.full(n + offset + 9, -7, dtype=out_dtype)
+                assert fn(x.ctypes.data, y.ctypes.data + y.itemsize * offset, n, threads) == 0
+                assert np.all(y[:offset] == -7) and np.all(y[offset + n:] == -7), "wrote outside its range"
+                assert np.array_equal(y[offset:offset + n], x.astype(out_dtype)), (n, threads, offset)
+    assert fn(None, None, 10, 2) == -1
+
+
 def test_two_callers_at_once():
     L = lib()
     rng = np.random.default_rng(4)

@@ -1,5 +1,5 @@
-"""End to end of the drop-in call (sample_density -> int64 ndarray) on C3 for several sizes of the host library's widening pool,
-beside the int32 return.  Usage: python3 tools/e2e_threads.py"""
+"""End to end of the drop-in call (sample_density -> int64 / int32 ndarray) on C3 by wire format (device.WIRE) and size of the host
+library's widening pool, beside the device-widened copies, the sparse and the uint16 return.  Usage: python3 tools/e2e_threads.py"""
 import sys
 import time
 
@@ -24,9 +24,11 @@ def call(out):
     return best
 
 
-print("int32: %.1f ms" % call("numpy32"))
-for threads in (4, 8, 16, 32):
-    device.HOST_THREADS = threads
-    print("int64, %2d host threads: %.1f ms" % (threads, call("numpy")))
+for wire in ("u16", "i32"):
+    device.WIRE = wire
+    for threads in (4, 8, 16, 32):
+        device.HOST_THREADS = threads
+        print("wire %s, %2d host threads: int64 %.1f ms   int32 %.1f ms" % (wire, threads, call("numpy"), call("numpy32")))
 device.WIDEN_ON = "device"
-print("int64 widened on the device: %.1f ms" % call("numpy"))
+print("widened on the device / copied as it lies: int64 %.1f ms   int32 %.1f ms" % (call("numpy"), call("numpy32")))
+print("csr: %.1f ms" % call("csr"))
