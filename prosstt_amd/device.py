@@ -427,6 +427,7 @@ def to_host(counts, dtype=np.int64, chunk_bytes=256 << 20, row_order=None):
 # on; PCIe carries 52 GB/s.  C3 end to end: int64 147 -> 48 ms, int32 76 -> 44 ms.)
 WIDEN_ON = os.environ.get("PROSSTT_AMD_WIDEN", "host")
 WIRE = os.environ.get("PROSSTT_AMD_WIRE", "u16")
+RESULT_MEMORY = os.environ.get("PROSSTT_AMD_RESULT_MEMORY", "pinned")
 HOST_THREADS = int(os.environ.get("PROSSTT_AMD_HOST_THREADS", str(max(1, min(16, os.cpu_count() or 1)))))
 
 
@@ -447,14 +448,20 @@ def _to_host_widened(counts, chunk_bytes, row_order, dtype, wire):
     lib = _native.load_host()
     widen = {("i32", 8): lib.prosstt_amd_host_widen_i32_i64, ("u16", 8): lib.prosstt_amd_host_widen_u16_i64,
              ("u16", 4): lib.prosstt_amd_host_widen_u16_i32}[(wire, dtype.itemsize)]
+    # The result is written by the host's threads, not by DMA: it needs no page-locking.  RESULT_MEMORY = "pinned" (default):
+    # from torch's caching host allocator -- 0.5 to 0.9 s to page-lock C3's 8 GB the first time a size is asked for, nothing
+    # afterwards (C3 end to end: first call of a process 560 - 960 ms, then 54 - 59 ms); "pageable": a fresh numpy array --
+    # numpy asks for transparent huge pages, so the pool's first touch costs 45 ms spread over its threads (a torch CPU tensor,
+    # 4 KB pages: 500 ms) -- every call, nothing up front (first call 240 - 470 ms, then 91 - 112 ms: the choice for a script
+    # that makes a handful of calls; tools/hugepage_probe.py, tools/first_call.py).
     host = None
-    if n * g * dtype.itemsize <= PINNED_RETURN_MAX:
+    if RESULT_MEMORY == "pinned" and n * g * dtype.itemsize <= PINNED_RETURN_MAX:
         try:
-            host = torch.empty((n, g), dtype=t_out, pin_memory=True)
+            host = torch.empty((n, g), dtype=t_out, pin_memory=True).numpy()
         except RuntimeError:
             host = None
     if host is None:
-        host = torch.empty((n, g), dtype=t_out)
+        host = np.empty((n, g), dtype=dtype)
     rows = max(1, min(n, int(chunk_bytes) // (g * 4)))
     dev = counts.device
     compute = torch.cuda.current_stream(dev)
@@ -474,7 +481,7 @@ def _to_host_widened(counts, chunk_bytes, row_order, dtype, wire):
     staged = [torch.empty((rows, g), dtype=t_wire, device=dev) for _ in range(slots)] if (inv is not None or wire == "u16") else None
     arrived = [None, None]
     bounds = list(range(0, n, rows)) + [n]
-    host_at = host.data_ptr()
+    host_at = host.ctypes.data
     exceptions = []                                     # uint16 wire: (positions in the host matrix, values) of what did not fit
 
     def note_exceptions(block, lo):
@@ -523,10 +530,10 @@ def _to_host_widened(counts, chunk_bytes, row_order, dtype, wire):
         if i >= 1:
             widen_chunk(i - 1)
     widen_chunk(len(bounds) - 2)
-    flat = host.view(-1)
+    flat = host.reshape(-1)
     for where, values in exceptions:
-        flat[where] = values.to(t_out)
-    return host.numpy()
+        flat[where.numpy()] = values.numpy()
+    return host
 
 
 def to_host_csr(counts, chunk_bytes=256 << 20, row_order=None):

@@ -302,6 +302,11 @@ def test_host_returns_widened_on_the_host_equal_the_device_widened_ones(monkeypa
     monkeypatch.setattr(device, "WIRE", "u16")
     monkeypatch.setattr(device, "HOST_THREADS", 3)
     assert np.array_equal(device.to_host(few, np.int64, chunk_bytes=4 * g * 777, row_order=order)[order], few.cpu().numpy())
+    # the result in ordinary memory (a numpy array; PROSSTT_AMD_RESULT_MEMORY=pageable) instead of page-locked memory
+    monkeypatch.setattr(device, "RESULT_MEMORY", "pageable")
+    for dtype in (np.int64, np.int32):
+        got = device.to_host(few, dtype, chunk_bytes=4 * g * 500, row_order=order)
+        assert got.dtype == dtype and got.flags.writeable and np.array_equal(got[order], few.cpu().numpy())
 
 
 def test_max_attempts_guard():
