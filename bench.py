@@ -787,8 +787,8 @@ def _library_version():
 def end_to_end_ms(tree, work, n_cells, out="numpy"):
     """Wall time of the drop-in call a reference user makes -- ``simulation.sample_density`` returning the
     (N, G) matrix on the host: host plan, kernels, domain check, and the device-to-host copy (PCIe-inclusive;
-    never ``value``).  out="numpy": the reference's int64 ndarray; "numpy32": int32 (both: 2 bytes per count over PCIe -- the low 16 bits, the
-    few larger counts beside them -- widened by host threads under the transfer: device.to_host; until round 5 int64 was formed on the
+    never ``value``).  out="numpy": the reference's int64 ndarray; "numpy32": int32 (both: 1 byte per count over PCIe -- the low 8 bits, the
+    larger counts beside them -- widened by host threads under the transfer: device.to_host; until round 5 int64 was formed on the
     device and 8 bytes per count crossed PCIe, int32 4); "csr": scipy.sparse.csr_matrix compacted on the device (8 bytes per
     non-zero over PCIe).  Third of three calls (the first sizes the pinned buffers)."""
     from prosstt_amd import simulation as sim

@@ -25,6 +25,16 @@ int prosstt_amd_host_widen_i32_i64(const int32_t* src, int64_t* dst, uint64_t co
 int prosstt_amd_host_widen_u16_i64(const uint16_t* src, int64_t* dst, uint64_t count, int32_t threads);
 int prosstt_amd_host_widen_u16_i32(const uint16_t* src, int32_t* dst, uint64_t count, int32_t threads);
 
+/* ... and from a uint8 source: the low 8 bits of every count, 1 byte over PCIe (two thirds of a count matrix are zeros and
+ * one count in a thousand of the headline workload is above 255); the others travel beside them as (position, value) pairs. */
+int prosstt_amd_host_widen_u8_i64(const uint8_t* src, int64_t* dst, uint64_t count, int32_t threads);
+int prosstt_amd_host_widen_u8_i32(const uint8_t* src, int32_t* dst, uint64_t count, int32_t threads);
+
+/* dst[positions[i]] = values[i], i < count, for an int64 (dst_itemsize 8) or int32 (4) destination: the counts that did not fit
+ * the wire, written over the widened matrix.  Positions must be distinct and inside the destination (not checked). */
+int prosstt_amd_host_scatter_i32(void* dst, int32_t dst_itemsize, const int64_t* positions, const int32_t* values,
+                                 uint64_t count, int32_t threads);
+
 /* 1 if the widening loop runs its AVX2 form on this machine, 0 for the portable loop. */
 int prosstt_amd_host_has_avx2(void);
 

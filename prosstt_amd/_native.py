@@ -33,6 +33,7 @@ SYMBOLS = [
 HOST_LIB_PATH = os.environ.get("PROSSTT_AMD_HOST_LIB") or os.path.join(_HERE, "lib", "libprosstt_amd_host.so")
 # every symbol include/prosstt_amd_host.h declares
 HOST_SYMBOLS = ["prosstt_amd_host_widen_i32_i64", "prosstt_amd_host_widen_u16_i64", "prosstt_amd_host_widen_u16_i32",
+                "prosstt_amd_host_widen_u8_i64", "prosstt_amd_host_widen_u8_i32", "prosstt_amd_host_scatter_i32",
                 "prosstt_amd_host_has_avx2"]
 
 
@@ -59,7 +60,10 @@ def load_host():
             raise RuntimeError("%s not found: build it with `make -C prosstt_amd/csrc/host` (or "
                                "`python -c 'import __graft_entry__ as g; g.build()'`)" % HOST_LIB_PATH)
         L = ctypes.CDLL(HOST_LIB_PATH)
-        for name in ("prosstt_amd_host_widen_i32_i64", "prosstt_amd_host_widen_u16_i64", "prosstt_amd_host_widen_u16_i32"):
+        L.prosstt_amd_host_scatter_i32.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32]
+        L.prosstt_amd_host_scatter_i32.restype = ctypes.c_int
+        for name in ("prosstt_amd_host_widen_i32_i64", "prosstt_amd_host_widen_u16_i64", "prosstt_amd_host_widen_u16_i32",
+                     "prosstt_amd_host_widen_u8_i64", "prosstt_amd_host_widen_u8_i32"):
             getattr(L, name).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32]
             getattr(L, name).restype = ctypes.c_int
         L.prosstt_amd_host_has_avx2.restype = ctypes.c_int

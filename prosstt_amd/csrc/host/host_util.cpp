@@ -36,6 +36,52 @@ void widen16to32_plain(const uint16_t* src, int32_t* dst, uint64_t n)
     for (uint64_t i = 0; i < n; ++i) dst[i] = (int32_t)src[i];
 }
 
+void widen8_plain(const uint8_t* src, int64_t* dst, uint64_t n)
+{
+    for (uint64_t i = 0; i < n; ++i) dst[i] = (int64_t)src[i];
+}
+
+void widen8to32_plain(const uint8_t* src, int32_t* dst, uint64_t n)
+{
+    for (uint64_t i = 0; i < n; ++i) dst[i] = (int32_t)src[i];
+}
+
+__attribute__((target("avx2"))) void widen8_avx2(const uint8_t* src, int64_t* dst, uint64_t n)
+{
+    uint64_t i = 0;
+    while (i < n && (reinterpret_cast<uintptr_t>(dst + i) & 31u) != 0u) { dst[i] = (int64_t)src[i]; ++i; }
+    for (; i + 16 <= n; i += 16) {
+        const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i));           // 16 counts
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i), _mm256_cvtepu8_epi64(a));
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i + 4), _mm256_cvtepu8_epi64(_mm_srli_si128(a, 4)));
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i + 8), _mm256_cvtepu8_epi64(_mm_srli_si128(a, 8)));
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i + 12), _mm256_cvtepu8_epi64(_mm_srli_si128(a, 12)));
+    }
+    for (; i < n; ++i) dst[i] = (int64_t)src[i];
+    _mm_sfence();
+}
+
+__attribute__((target("avx2"))) void widen8to32_avx2(const uint8_t* src, int32_t* dst, uint64_t n)
+{
+    uint64_t i = 0;
+    while (i < n && (reinterpret_cast<uintptr_t>(dst + i) & 31u) != 0u) { dst[i] = (int32_t)src[i]; ++i; }
+    for (; i + 16 <= n; i += 16) {
+        const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i));
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i), _mm256_cvtepu8_epi32(a));
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i + 8), _mm256_cvtepu8_epi32(_mm_srli_si128(a, 8)));
+    }
+    for (; i < n; ++i) dst[i] = (int32_t)src[i];
+    _mm_sfence();
+}
+
+// dst[pos[i]] = val[i] for the entries [lo, lo + n) of a list (kinds 5 and 6: an int64 / int32 destination); `src` is the
+// list of values, `aux` the positions
+void scatter(const int32_t* val, const int64_t* pos, void* dst, bool wide, uint64_t lo, uint64_t n)
+{
+    if (wide) for (uint64_t i = lo; i < lo + n; ++i) static_cast<int64_t*>(dst)[pos[i]] = (int64_t)val[i];
+    else for (uint64_t i = lo; i < lo + n; ++i) static_cast<int32_t*>(dst)[pos[i]] = val[i];
+}
+
 __attribute__((target("avx2"))) void widen16_avx2(const uint16_t* src, int64_t* dst, uint64_t n)
 {
     uint64_t i = 0;
@@ -104,14 +150,15 @@ public:
         for (auto& t : threads_) t.join();
     }
 
-    // kind: 0 int32 -> int64, 1 uint16 -> int64, 2 uint16 -> int32
-    void run(const void* src, void* dst, uint64_t count, int workers, int kind)
+    // kind: 0 int32 -> int64, 1 uint16 -> int64, 2 uint16 -> int32, 3 uint8 -> int64, 4 uint8 -> int32,
+    //       5 / 6 scatter of int32 values to the positions `aux` of an int64 / int32 destination
+    void run(const void* src, void* dst, uint64_t count, int workers, int kind, const void* aux = nullptr)
     {
         std::lock_guard<std::mutex> serial(call_);
         grow(workers - 1);
         {
             std::lock_guard<std::mutex> g(m_);
-            src_ = src; dst_ = dst; count_ = count; workers_ = workers; kind_ = kind;
+            src_ = src; dst_ = dst; count_ = count; workers_ = workers; kind_ = kind; aux_ = aux;
             next_.store(0, std::memory_order_relaxed);
             pending_ = workers - 1;
             ++epoch_;
@@ -145,14 +192,20 @@ private:
             const uint64_t lo = next_.fetch_add(kPiece, std::memory_order_relaxed);
             if (lo >= count_) return;
             const uint64_t n = count_ - lo < kPiece ? count_ - lo : kPiece;
-            convert(kind_, src_, dst_, lo, n);
+            convert(kind_, src_, dst_, lo, n, aux_);
         }
     }
 
 public:
-    static void convert(int kind, const void* src, void* dst, uint64_t lo, uint64_t n)
+    static void convert(int kind, const void* src, void* dst, uint64_t lo, uint64_t n, const void* aux = nullptr)
     {
-        if (kind == 0)
+        if (kind >= 5)
+            scatter(static_cast<const int32_t*>(src), static_cast<const int64_t*>(aux), dst, kind == 5, lo, n);
+        else if (kind == 3)
+            (has_avx2() ? widen8_avx2 : widen8_plain)(static_cast<const uint8_t*>(src) + lo, static_cast<int64_t*>(dst) + lo, n);
+        else if (kind == 4)
+            (has_avx2() ? widen8to32_avx2 : widen8to32_plain)(static_cast<const uint8_t*>(src) + lo, static_cast<int32_t*>(dst) + lo, n);
+        else if (kind == 0)
             (has_avx2() ? widen_avx2 : widen_plain)(static_cast<const int32_t*>(src) + lo, static_cast<int64_t*>(dst) + lo, n);
         else if (kind == 1)
             (has_avx2() ? widen16_avx2 : widen16_plain)(static_cast<const uint16_t*>(src) + lo, static_cast<int64_t*>(dst) + lo, n);
@@ -185,6 +238,7 @@ private:
     std::condition_variable wake_, done_;
     std::vector<std::thread> threads_;
     const void* src_ = nullptr;
+    const void* aux_ = nullptr;
     void* dst_ = nullptr;
     uint64_t count_ = 0, epoch_ = 0;
     int workers_ = 1, pending_ = 0, kind_ = 0;
@@ -217,22 +271,22 @@ Pool& pool()
 
 namespace {
 
-int convert_on_pool(const void* src, void* dst, uint64_t count, int32_t threads, int kind)
+int convert_on_pool(const void* src, void* dst, uint64_t count, int32_t threads, int kind, const void* aux = nullptr)
 {
     if (count == 0) return 0;
-    if (!src || !dst) return -1;
+    if (!src || !dst || (kind >= 5 && !aux)) return -1;
     int workers = threads < 1 ? 1 : (threads > 64 ? 64 : threads);
     // nothing to share out below a few pages per worker
     const uint64_t per = 1u << 14;
     if ((uint64_t)workers > (count + per - 1) / per) workers = (int)((count + per - 1) / per);
     if (workers <= 1) {
-        Pool::convert(kind, src, dst, 0, count);
+        Pool::convert(kind, src, dst, 0, count, aux);
         return 0;
     }
     try {
-        pool().run(src, dst, count, workers, kind);
+        pool().run(src, dst, count, workers, kind, aux);
     } catch (...) {                      // (thread creation failed: the caller's thread does all of it)
-        Pool::convert(kind, src, dst, 0, count);
+        Pool::convert(kind, src, dst, 0, count, aux);
     }
     return 0;
 }
@@ -252,6 +306,23 @@ PH_EXPORT int prosstt_amd_host_widen_u16_i64(const uint16_t* src, int64_t* dst, 
 PH_EXPORT int prosstt_amd_host_widen_u16_i32(const uint16_t* src, int32_t* dst, uint64_t count, int32_t threads)
 {
     return convert_on_pool(src, dst, count, threads, 2);
+}
+
+PH_EXPORT int prosstt_amd_host_widen_u8_i64(const uint8_t* src, int64_t* dst, uint64_t count, int32_t threads)
+{
+    return convert_on_pool(src, dst, count, threads, 3);
+}
+
+PH_EXPORT int prosstt_amd_host_widen_u8_i32(const uint8_t* src, int32_t* dst, uint64_t count, int32_t threads)
+{
+    return convert_on_pool(src, dst, count, threads, 4);
+}
+
+PH_EXPORT int prosstt_amd_host_scatter_i32(void* dst, int32_t dst_itemsize, const int64_t* positions, const int32_t* values,
+                                           uint64_t count, int32_t threads)
+{
+    if (dst_itemsize != 8 && dst_itemsize != 4) return -1;
+    return convert_on_pool(values, dst, count, threads, dst_itemsize == 8 ? 5 : 6, positions);
 }
 
 PH_EXPORT int prosstt_amd_host_has_avx2(void)

@@ -329,8 +329,8 @@ def to_host(counts, dtype=np.int64, chunk_bytes=256 << 20, row_order=None):
     first-touch page faults; the block goes back to the allocator's cache when the caller drops the array, so
     the pinning cost is paid once per size.  Larger results (or a failed page-lock) take the same chunked path
     into ordinary memory.  uint16 is narrowed on the device, chunk by chunk (two staging buffers), under the transfer of
-    the previous chunk.  int64 and int32 of 2^24 counts or more cross PCIe in a narrower wire format -- their low 16 bits,
-    and the few entries with high bits set beside them (``WIRE``), or the int32 as it lies -- and are widened by the host library's threads under the transfer
+    the previous chunk.  int64 and int32 of 2^24 counts or more cross PCIe in a narrower wire format -- their low 8 (or 16) bits,
+    and the few entries with higher bits set beside them (``WIRE``), or the int32 as it lies -- and are widened by the host library's threads under the transfer
     of the next chunk (``_to_host_widened``; ``WIDEN_ON`` = "device", or a smaller matrix: int64 is formed on the device
     like uint16 is narrowed and 8 bytes per count cross PCIe, int32 is copied as it lies).
 
@@ -346,13 +346,15 @@ def to_host(counts, dtype=np.int64, chunk_bytes=256 << 20, row_order=None):
     if n == 0 or g == 0:
         return np.zeros((n, g), dtype=dtype)
     if dtype.itemsize >= 4 and WIDEN_ON == "host" and n * g >= (1 << 24):
-        if WIRE == "u16":
+        for wire in WIRES[WIRES.index(WIRE):] if WIRE in WIRES else WIRES[2:]:
+            if wire == "i32" and dtype.itemsize == 4:
+                break                                   # (int32 as it lies needs no widening: the copy below)
             try:
-                return _to_host_widened(counts, chunk_bytes, row_order, dtype, "u16")
+                return _to_host_widened(counts, chunk_bytes, row_order, dtype, wire)
             except _WireTooNarrow:
-                pass
-        if dtype.itemsize == 8:
-            return _to_host_widened(counts, chunk_bytes, row_order, dtype, "i32")
+                continue
+            except _NoBounceBuffers:
+                break                                   # (the device-widened copy below needs no page-locked memory)
     # (torch has no arithmetic on uint16: the device narrows to int16 bit patterns, viewed as uint16 on the host)
     t_dtype = {8: torch.int64, 4: torch.int32, 2: torch.int16}[dtype.itemsize]
     host = None
@@ -418,21 +420,27 @@ def to_host(counts, dtype=np.int64, chunk_bytes=256 << 20, row_order=None):
 # How an int64 / int32 host return of 2^24 counts or more travels.  WIDEN_ON = "host" (default): the matrix crosses PCIe in
 # a WIRE format narrower than its type and the host library's threads (libprosstt_amd_host.so) widen chunk i - 1 into the
 # result while chunk i is on the bus; "device": as rounds 2 to 5 did -- int64 formed on the device, 8 bytes per count over
-# PCIe, int32 copied as it lies (the choice for a host with very few cores).  WIRE = "u16" (default): the low 16 bits of
-# every count, 2 bytes over PCIe, and beside them the few entries that have high bits set (a count above 65 535: C3's
-# largest is 84 036; a negative entry of a matrix that is not one of counts) as (position, value) pairs that are written
-# over the widened matrix at the end; a matrix in which more than one entry in 256 of a chunk is such an exception is
-# sent again as int32.  "i32": the int32 as it lies.
+# PCIe, int32 copied as it lies (the choice for a host with very few cores).  WIRE = "u8" (default): the low 8 bits of
+# every count, 1 byte over PCIe, and beside them the entries that have higher bits set (two thirds of a count matrix are
+# zeros; one count in a thousand of C3 is above 255, the largest is 84 036) as (position, value) pairs that the pool writes
+# over the widened matrix at the end; a matrix in which more than one entry in 256 of a chunk is such an exception is sent
+# again with the next wider wire: "u16" (the low 16 bits), then "i32" (the int32 as it lies).  WIRE names the narrowest
+# wire that is tried.
 # (tools/host_widen_probe.py, tools/e2e_threads.py on an MI355X box's host: the pool writes 250 - 340 GB/s from eight threads
 # on; PCIe carries 52 GB/s.  C3 end to end: int64 147 -> 48 ms, int32 76 -> 44 ms.)
 WIDEN_ON = os.environ.get("PROSSTT_AMD_WIDEN", "host")
-WIRE = os.environ.get("PROSSTT_AMD_WIRE", "u16")
+WIRE = os.environ.get("PROSSTT_AMD_WIRE", "u8")
+WIRES = ("u8", "u16", "i32")
 RESULT_MEMORY = os.environ.get("PROSSTT_AMD_RESULT_MEMORY", "pinned")
 HOST_THREADS = int(os.environ.get("PROSSTT_AMD_HOST_THREADS", str(max(1, min(16, os.cpu_count() or 1)))))
 
 
 class _WireTooNarrow(Exception):
-    """Too many entries of a chunk do not fit the uint16 wire: the copy starts again with int32."""
+    """Too many entries of a chunk do not fit the wire: the copy starts again with the next wider one."""
+
+
+class _NoBounceBuffers(Exception):
+    """The page-locked bounce buffers of the host-widened copy were refused."""
 
 
 def _to_host_widened(counts, chunk_bytes, row_order, dtype, wire):
@@ -444,10 +452,13 @@ def _to_host_widened(counts, chunk_bytes, row_order, dtype, wire):
     torch = _torch()
     n, g = (int(v) for v in counts.shape)
     t_out = torch.int64 if dtype.itemsize == 8 else torch.int32
-    t_wire = torch.int16 if wire == "u16" else torch.int32          # (uint16 bit patterns: torch has no arithmetic on uint16)
+    t_wire = {"u8": torch.uint8, "u16": torch.int16, "i32": torch.int32}[wire]     # (uint16 bit patterns: torch has no arithmetic on uint16)
+    high_bits = {"u8": -256, "u16": -65536, "i32": 0}[wire]
+    narrow = wire != "i32"
     lib = _native.load_host()
     widen = {("i32", 8): lib.prosstt_amd_host_widen_i32_i64, ("u16", 8): lib.prosstt_amd_host_widen_u16_i64,
-             ("u16", 4): lib.prosstt_amd_host_widen_u16_i32}[(wire, dtype.itemsize)]
+             ("u16", 4): lib.prosstt_amd_host_widen_u16_i32, ("u8", 8): lib.prosstt_amd_host_widen_u8_i64,
+             ("u8", 4): lib.prosstt_amd_host_widen_u8_i32}[(wire, dtype.itemsize)]
     # The result is written by the host's threads, not by DMA: it needs no page-locking.  RESULT_MEMORY = "pinned" (default):
     # from torch's caching host allocator -- 0.5 to 0.9 s to page-lock C3's 8 GB the first time a size is asked for, nothing
     # afterwards (C3 end to end: first call of a process 560 - 960 ms, then 54 - 59 ms); "pageable": a fresh numpy array --
@@ -475,18 +486,21 @@ def _to_host_widened(counts, chunk_bytes, row_order, dtype, wire):
         inv_host[order] = np.arange(n, dtype=np.int64)        # device row of host row j
         inv = torch.as_tensor(inv_host).to(dev)
     slots = 2 if rows < n else 1
-    bounce = [torch.empty((rows, g), dtype=t_wire, pin_memory=True) for _ in range(slots)]
+    try:
+        bounce = [torch.empty((rows, g), dtype=t_wire, pin_memory=True) for _ in range(slots)]
+    except RuntimeError as exc:
+        raise _NoBounceBuffers() from exc
     # device staging: the chunk's rows gathered (int32), and -- for the uint16 wire -- narrowed
-    gathered = torch.empty((rows, g), dtype=torch.int32, device=dev) if (inv is not None and wire == "u16") else None
-    staged = [torch.empty((rows, g), dtype=t_wire, device=dev) for _ in range(slots)] if (inv is not None or wire == "u16") else None
+    gathered = torch.empty((rows, g), dtype=torch.int32, device=dev) if (inv is not None and narrow) else None
+    staged = [torch.empty((rows, g), dtype=t_wire, device=dev) for _ in range(slots)] if (inv is not None or narrow) else None
     arrived = [None, None]
     bounds = list(range(0, n, rows)) + [n]
     host_at = host.ctypes.data
-    exceptions = []                                     # uint16 wire: (positions in the host matrix, values) of what did not fit
+    exceptions = []                                     # a narrow wire: (positions in the host matrix, values) of what did not fit
 
     def note_exceptions(block, lo):
         """The entries of the chunk (int32, rows in host order from row ``lo``) with high bits set (synchronises the compute stream: their number)."""
-        where = torch.nonzero(torch.bitwise_and(block, -65536).view(-1)).squeeze(1)
+        where = torch.nonzero(torch.bitwise_and(block, high_bits).view(-1)).squeeze(1)
         if int(where.numel()) * 256 > int(block.numel()):
             copier.synchronize()                        # (nothing of this attempt is in flight when its buffers go back)
             raise _WireTooNarrow()
@@ -511,9 +525,9 @@ def _to_host_widened(counts, chunk_bytes, row_order, dtype, wire):
                 compute.wait_event(arrived[slot])       # the staging buffer's previous chunk has left
             src = staged[slot][:hi - lo]
             if inv is None:
-                src.copy_(counts[lo:hi])                # the low 16 bits
+                src.copy_(counts[lo:hi])                # the low bits
                 note_exceptions(counts[lo:hi], lo)
-            elif wire == "i32":
+            elif not narrow:
                 torch.index_select(counts, 0, inv[lo:hi], out=src)
             else:
                 torch.index_select(counts, 0, inv[lo:hi], out=gathered[:hi - lo])
@@ -530,9 +544,12 @@ def _to_host_widened(counts, chunk_bytes, row_order, dtype, wire):
         if i >= 1:
             widen_chunk(i - 1)
     widen_chunk(len(bounds) - 2)
-    flat = host.reshape(-1)
-    for where, values in exceptions:
-        flat[where.numpy()] = values.numpy()
+    if exceptions:
+        where = np.ascontiguousarray(torch.cat([e[0] for e in exceptions]).numpy())
+        values = np.ascontiguousarray(torch.cat([e[1] for e in exceptions]).numpy())
+        if lib.prosstt_amd_host_scatter_i32(ctypes.c_void_p(host_at), dtype.itemsize, ctypes.c_void_p(where.ctypes.data),
+                                            ctypes.c_void_p(values.ctypes.data), ctypes.c_uint64(where.size), HOST_THREADS) != 0:
+            raise RuntimeError("the host library refused its arguments")
     return host
 
 

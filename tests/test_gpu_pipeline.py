@@ -260,26 +260,32 @@ def test_compact_host_returns_and_chunk_generator():
 
 
 def test_host_returns_widened_on_the_host_equal_the_device_widened_ones(monkeypatch):
-    """int64 / int32 returns of 2^24 counts and more cross PCIe in a wire format (the low 16 bits of every count and, beside
-    them, the entries that have high bits set; int32 when there are too many of those) and are widened by the host
-    library's threads under the next chunk's transfer == widened on the device (PROSSTT_AMD_WIDEN=device) == the device
-    tensor: with and without the row gather, for one chunk, many chunks and a ragged last chunk, for a matrix that fits
-    the narrow wire, one with a few counts above it and negative entries, and one that is mostly above it."""
+    """int64 / int32 returns of 2^24 counts and more cross PCIe in a wire format (the low 8 bits of every count and, beside
+    them, the entries that have higher bits set; the low 16 bits, then int32, when there are too many of those) and are
+    widened by the host library's threads under the next chunk's transfer == widened on the device
+    (PROSSTT_AMD_WIDEN=device) == the device tensor: with and without the row gather, for one chunk, many chunks and a
+    ragged last chunk, for matrices that fit each wire with a few exceptions (counts above it, negative entries) and one
+    that fits none."""
     import torch
     from prosstt_amd import device
     gen = torch.Generator(device="cuda").manual_seed(5)
     n, g = 4100, 4100                                   # 1.68e7 >= 2^24
     order = np.random.default_rng(1).permutation(n)
-    fits = torch.randint(0, 65536, (n, g), device="cuda", generator=gen, dtype=torch.int32)
-    fits[17, 5], fits[n - 1, g - 1] = 65535, 0
-    few = fits.clone()
-    few[n // 2, 7], few[0, 0], few[n - 1, g - 2], few[3, 3], few[1000, 4000] = 65536, 84036, 2 ** 31 - 1, -1, -2 ** 31
-    few[2000] += 70000                                  # a whole row above the wire (under one entry in 256 of any chunk here)
-    mostly = fits + 100000
+
+    def with_exceptions(base, row_add):
+        m = base.clone()
+        m[n // 2, 7], m[0, 0], m[n - 1, g - 2], m[3, 3], m[1000, 4000] = 65536, 84036, 2 ** 31 - 1, -1, -2 ** 31
+        m[17, 5], m[n - 1, g - 1] = 65535, 0
+        m[2000] += row_add                              # a whole row above the wire (under one entry in 256 of any chunk here)
+        return m
+
+    small = with_exceptions(torch.randint(0, 256, (n, g), device="cuda", generator=gen, dtype=torch.int32), 300)
+    medium = with_exceptions(torch.randint(0, 65536, (n, g), device="cuda", generator=gen, dtype=torch.int32), 70000)
+    large = torch.randint(0, 65536, (n, g), device="cuda", generator=gen, dtype=torch.int32) + 100000
     calls = []
     real = device._to_host_widened
     monkeypatch.setattr(device, "_to_host_widened", lambda *a: (calls.append(a[4]), real(*a))[1])
-    for name, counts, wires in (("fits", fits, ["u16"]), ("few", few, ["u16"]), ("mostly", mostly, ["u16", "i32"])):
+    for name, counts, wires in (("small", small, ["u8"]), ("medium", medium, ["u8", "u16"]), ("large", large, ["u8", "u16", "i32"])):
         want32 = counts.cpu().numpy()
         for dtype in (np.int64, np.int32):
             want = want32.astype(dtype)
@@ -291,22 +297,23 @@ def test_host_returns_widened_on_the_host_equal_the_device_widened_ones(monkeypa
                     del calls[:]
                     got = device.to_host(counts, dtype, chunk_bytes=chunk_bytes)
                     assert got.dtype == dtype and np.array_equal(got, want), (name, dtype, where, chunk_bytes)
-                    if where == "host":                 # (int32 of a matrix the narrow wire cannot carry: copied as it lies)
-                        assert calls == (wires if dtype == np.int64 or wires == ["u16"] else ["u16"]), (name, dtype, calls)
+                    if where == "host":                 # (int32 of a matrix no narrow wire can carry: copied as it lies)
+                        assert calls == [w for w in wires if not (w == "i32" and dtype == np.int32)], (name, dtype, calls)
                     got = device.to_host(counts, dtype, chunk_bytes=chunk_bytes, row_order=order)
                     assert np.array_equal(got, want_perm), (name, dtype, where, chunk_bytes)
     monkeypatch.setattr(device, "WIDEN_ON", "host")
-    monkeypatch.setattr(device, "WIRE", "i32")
-    del calls[:]
-    assert np.array_equal(device.to_host(few, np.int64, chunk_bytes=4 * g * 777), few.cpu().numpy().astype(np.int64)) and calls == ["i32"]
-    monkeypatch.setattr(device, "WIRE", "u16")
+    for narrowest, tried in (("i32", ["i32"]), ("u16", ["u16"])):
+        monkeypatch.setattr(device, "WIRE", narrowest)
+        del calls[:]
+        assert np.array_equal(device.to_host(medium, np.int64, chunk_bytes=4 * g * 777), medium.cpu().numpy().astype(np.int64)) and calls == tried
+    monkeypatch.setattr(device, "WIRE", "u8")
     monkeypatch.setattr(device, "HOST_THREADS", 3)
-    assert np.array_equal(device.to_host(few, np.int64, chunk_bytes=4 * g * 777, row_order=order)[order], few.cpu().numpy())
+    assert np.array_equal(device.to_host(small, np.int64, chunk_bytes=4 * g * 777, row_order=order)[order], small.cpu().numpy())
     # the result in ordinary memory (a numpy array; PROSSTT_AMD_RESULT_MEMORY=pageable) instead of page-locked memory
     monkeypatch.setattr(device, "RESULT_MEMORY", "pageable")
     for dtype in (np.int64, np.int32):
-        got = device.to_host(few, dtype, chunk_bytes=4 * g * 500, row_order=order)
-        assert got.dtype == dtype and got.flags.writeable and np.array_equal(got[order], few.cpu().numpy())
+        got = device.to_host(small, dtype, chunk_bytes=4 * g * 500, row_order=order)
+        assert got.dtype == dtype and got.flags.writeable and np.array_equal(got[order], small.cpu().numpy())
 
 
 def test_max_attempts_guard():

@@ -58,14 +58,16 @@ def test_widening_equals_astype_for_every_length_alignment_and_thread_count():
     assert L.prosstt_amd_host_widen_i32_i64(None, None, 10, 4) == -1
 
 
+@pytest.mark.parametrize("wire", [np.uint16, np.uint8])
 @pytest.mark.parametrize("out_dtype", [np.int64, np.int32])
-def test_widening_from_the_uint16_wire_format(out_dtype):
+def test_widening_from_the_narrow_wire_formats(out_dtype, wire):
     L = lib()
-    fn = L.prosstt_amd_host_widen_u16_i64 if out_dtype == np.int64 else L.prosstt_amd_host_widen_u16_i32
+    fn = getattr(L, "prosstt_amd_host_widen_%s_%s" % ("u16" if wire == np.uint16 else "u8", "i64" if out_dtype == np.int64 else "i32"))
     rng = np.random.default_rng(5)
+    top = int(np.iinfo(wire).max)
     for n in (0, 1, 7, 8, 15, 16, 17, 31, 33, 1000, (1 << 14) + 3, 2_000_003):
-        x = rng.integers(0, 65536, size=n, dtype=np.int64).astype(np.uint16)
-        x[:min(n, 2)] = np.array([65535, 0], dtype=np.uint16)[:min(n, 2)]
+        x = rng.integers(0, top + 1, size=n, dtype=np.int64).astype(wire)
+        x[:min(n, 2)] = np.array([top, 0], dtype=wire)[:min(n, 2)]
         for threads in (1, 3, 64):
             for offset in (0, 1, 3, 5):
                 y = np.full(n + offset + 9, -7, dtype=out_dtype)
@@ -73,6 +75,25 @@ def test_widening_from_the_uint16_wire_format(out_dtype):
                 assert np.all(y[:offset] == -7) and np.all(y[offset + n:] == -7), "wrote outside its range"
                 assert np.array_equal(y[offset:offset + n], x.astype(out_dtype)), (n, threads, offset)
     assert fn(None, None, 10, 2) == -1
+
+
+@pytest.mark.parametrize("out_dtype", [np.int64, np.int32])
+def test_scatter_of_the_counts_that_did_not_fit_the_wire(out_dtype):
+    L = lib()
+    rng = np.random.default_rng(6)
+    size = 3_000_017
+    for count in (0, 1, 100, (1 << 14) + 5, 700_001):
+        for threads in (1, 4, 64):
+            dst = rng.integers(0, 200, size=size).astype(out_dtype)
+            pos = np.sort(rng.permutation(size)[:count]).astype(np.int64)
+            val = rng.integers(-2 ** 31, 2 ** 31, size=count, dtype=np.int64).astype(np.int32)
+            want = dst.copy()
+            want[pos] = val
+            assert L.prosstt_amd_host_scatter_i32(dst.ctypes.data, dst.itemsize, pos.ctypes.data, val.ctypes.data, count, threads) == 0
+            assert np.array_equal(dst, want), (count, threads)
+    one = np.zeros(4, out_dtype)
+    assert L.prosstt_amd_host_scatter_i32(one.ctypes.data, 2, one.ctypes.data, one.ctypes.data, 1, 1) == -1       # an item size it does not write
+    assert L.prosstt_amd_host_scatter_i32(one.ctypes.data, one.itemsize, None, None, 1, 1) == -1
 
 
 def test_two_callers_at_once():

@@ -24,9 +24,9 @@ def call(out):
     return best
 
 
-for wire in ("u16", "i32"):
+for wire in ("u8", "u16", "i32"):
     device.WIRE = wire
-    for threads in (4, 8, 16, 32):
+    for threads in (8, 16, 32):
         device.HOST_THREADS = threads
         print("wire %s, %2d host threads: int64 %.1f ms   int32 %.1f ms" % (wire, threads, call("numpy"), call("numpy32")))
 device.WIDEN_ON = "device"
