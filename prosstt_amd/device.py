@@ -553,11 +553,12 @@ def _to_host_widened(counts, chunk_bytes, row_order, dtype, wire):
     return host
 
 
-def to_host_csr(counts, chunk_bytes=256 << 20, row_order=None):
+def to_host_csr(counts, chunk_bytes=256 << 20, row_order=None, _narrow=(True, True)):
     """int32 device counts -> ``scipy.sparse.csr_matrix`` (int32 data, int32 column indices sorted within a row, int64
     row pointers) in plan order: what the single-cell toolchains downstream of the reference's count files hold a count
-    matrix in.  Two thirds of such a matrix are zeros, so 8 bytes per NON-ZERO cross PCIe (2.8 GB for 50 000 x 20 000
-    against 4 GB as int32 and 8 GB as the reference's int64) and the dense matrix never exists on the host.
+    matrix in.  Two thirds of such a matrix are zeros, and only the NON-ZEROS cross PCIe -- 3 bytes each (the value's low 8
+    bits, a 16-bit column index; 8 bytes for a matrix of large counts or of more than 65 536 columns), widened by the host
+    library's threads -- and the dense matrix never exists on the host.
 
     Two passes over the device matrix, a chunk of rows at a time: the non-zeros per row first (the row pointers, and with
     them the exact size of the page-locked result), then every chunk's non-zeros are compacted on the device (row-major:
@@ -606,10 +607,44 @@ def to_host_csr(counts, chunk_bytes=256 << 20, row_order=None):
     compute = torch.cuda.current_stream(dev)
     copier = torch.cuda.Stream(dev)
     slots = 2 if len(bounds) > 2 else 1
-    vals = [torch.empty(max(cap, 1), dtype=torch.int32, device=dev) for _ in range(slots)]
-    cols = [torch.empty(max(cap, 1), dtype=torch.int32, device=dev) for _ in range(slots)]
     gathered = torch.empty((rows, g), dtype=torch.int32, device=dev) if inv is not None else None
+    # The wire (as in ``to_host``): values as their low 8 bits -- the few above 255 beside them as (position, value) pairs --
+    # and column indices as 16 bits when the matrix has at most 65 536 columns: 3 bytes per non-zero over PCIe instead of
+    # 8, widened into the two int32 arrays by the host library's threads under the transfer of the next chunk.
+    # (_narrow: which of the two this attempt may narrow -- the call starts again without the first for a matrix of large
+    # counts, without both when the page-locked bounce buffers are refused)
+    narrow_vals = _narrow[0] and WIDEN_ON == "host" and WIRE == "u8" and total >= (1 << 22)
+    narrow_cols = _narrow[1] and WIDEN_ON == "host" and WIRE in ("u8", "u16") and total >= (1 << 22) and g <= 65536
+    lib = _native.load_host() if (narrow_vals or narrow_cols) else None
+    t_vals = torch.uint8 if narrow_vals else torch.int32
+    t_cols = torch.int16 if narrow_cols else torch.int32
+    vals = [torch.empty(max(cap, 1), dtype=t_vals, device=dev) for _ in range(slots)]
+    cols = [torch.empty(max(cap, 1), dtype=t_cols, device=dev) for _ in range(slots)]
+    vals32 = torch.empty(max(cap, 1), dtype=torch.int32, device=dev) if narrow_vals else None
+    try:
+        bounce_v = [torch.empty(max(cap, 1), dtype=t_vals, pin_memory=True) for _ in range(slots)] if narrow_vals else None
+        bounce_c = [torch.empty(max(cap, 1), dtype=t_cols, pin_memory=True) for _ in range(slots)] if narrow_cols else None
+    except RuntimeError:
+        return to_host_csr(counts, chunk_bytes, row_order, _narrow=(False, False))
     copied = [None, None]
+    spans = [None, None]
+    exceptions = []
+
+    def widen_chunk(slot):
+        """The narrow halves of the chunk in ``slot``: wait for them, widen them into their place."""
+        if spans[slot] is None:
+            return
+        first, last = spans[slot]
+        spans[slot] = None
+        copied[slot].synchronize()
+        k = last - first
+        if narrow_vals and lib.prosstt_amd_host_widen_u8_i32(ctypes.c_void_p(bounce_v[slot].data_ptr()), ctypes.c_void_p(data.data_ptr() + 4 * first),
+                                                             ctypes.c_uint64(k), HOST_THREADS) != 0:
+            raise RuntimeError("the host library refused its arguments")
+        if narrow_cols and lib.prosstt_amd_host_widen_u16_i32(ctypes.c_void_p(bounce_c[slot].data_ptr()), ctypes.c_void_p(indices.data_ptr() + 4 * first),
+                                                              ctypes.c_uint64(k), HOST_THREADS) != 0:
+            raise RuntimeError("the host library refused its arguments")
+
     # pass 2
     for i, (lo, hi) in enumerate(zip(bounds[:-1], bounds[1:])):
         first, last = int(indptr[lo]), int(indptr[hi])
@@ -627,18 +662,40 @@ def to_host_csr(counts, chunk_bytes=256 << 20, row_order=None):
         where = torch.nonzero(flat).squeeze(1)             # ascending flat positions = CSR order (synchronises: its size)
         if int(where.numel()) != k:
             raise RuntimeError("the device matrix changed between the two passes of the sparse copy")
-        torch.index_select(flat, 0, where, out=vals[slot][:k])
+        if narrow_vals:
+            torch.index_select(flat, 0, where, out=vals32[:k])
+            vals[slot][:k].copy_(vals32[:k])                # the low 8 bits
+            big = torch.nonzero(torch.bitwise_and(vals32[:k], -256)).squeeze(1)
+            if int(big.numel()) * 16 > k:                  # a matrix of large counts: 4-byte values after all
+                copier.synchronize()
+                return to_host_csr(counts, chunk_bytes, row_order, _narrow=(False, _narrow[1]))
+            if int(big.numel()):
+                exceptions.append(((big + first).cpu(), vals32[:k].index_select(0, big).cpu()))
+        else:
+            torch.index_select(flat, 0, where, out=vals[slot][:k])
         cols[slot][:k].copy_(torch.remainder(where, g))
         del where
+        widen_chunk(slot)                                  # (the bounce buffers' previous chunk, i - 2)
         ready = torch.cuda.Event()
         ready.record(compute)
         copier.wait_event(ready)
         with torch.cuda.stream(copier):
-            data[first:last].copy_(vals[slot][:k], non_blocking=True)
-            indices[first:last].copy_(cols[slot][:k], non_blocking=True)
+            (bounce_v[slot][:k] if narrow_vals else data[first:last]).copy_(vals[slot][:k], non_blocking=True)
+            (bounce_c[slot][:k] if narrow_cols else indices[first:last]).copy_(cols[slot][:k], non_blocking=True)
             copied[slot] = torch.cuda.Event()
             copied[slot].record(copier)
+        spans[slot] = (first, last)
+        if slots == 2:
+            widen_chunk(slot ^ 1)                          # chunk i - 1, while chunk i is on the bus
     copier.synchronize()
+    for slot in range(slots):
+        widen_chunk(slot)
+    if exceptions:
+        where = np.ascontiguousarray(torch.cat([e[0] for e in exceptions]).numpy())
+        values = np.ascontiguousarray(torch.cat([e[1] for e in exceptions]).numpy())
+        if lib.prosstt_amd_host_scatter_i32(ctypes.c_void_p(data.data_ptr()), 4, ctypes.c_void_p(where.ctypes.data),
+                                            ctypes.c_void_p(values.ctypes.data), ctypes.c_uint64(where.size), HOST_THREADS) != 0:
+            raise RuntimeError("the host library refused its arguments")
     out = sparse.csr_matrix((data.numpy(), indices.numpy(), indptr), shape=(n, g), copy=False)
     out.has_sorted_indices = True
     return out

@@ -316,6 +316,37 @@ def test_host_returns_widened_on_the_host_equal_the_device_widened_ones(monkeypa
         assert got.dtype == dtype and got.flags.writeable and np.array_equal(got[order], small.cpu().numpy())
 
 
+def test_sparse_return_over_the_narrow_wire(monkeypatch):
+    """to_host_csr of a matrix with 2^22 non-zeros and more: values as their low 8 bits (+ the larger ones as pairs), column
+    indices as 16 bits, widened by the host library == the dense matrix; a matrix of large counts falls back to 4-byte
+    values; WIRE / WIDEN_ON switch the narrowing off; rows in plan order through row_order."""
+    import scipy.sparse as sparse
+    import torch
+    from prosstt_amd import device
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    n, g = 4100, 4100
+    keep = torch.rand((n, g), device="cuda", generator=gen) < 0.4
+    small = torch.randint(1, 256, (n, g), device="cuda", generator=gen, dtype=torch.int32) * keep
+    small[5, 5], small[n - 1, g - 1], small[100, 0], small[7] = 84036, 256, 2 ** 31 - 1, 0
+    small[9, :64] = 70000
+    large = (torch.randint(300, 100000, (n, g), device="cuda", generator=gen, dtype=torch.int32)) * keep
+    order = np.random.default_rng(2).permutation(n)
+    for name, counts in (("small", small), ("large", large)):
+        want = counts.cpu().numpy()
+        assert np.count_nonzero(want) >= 1 << 22
+        want_perm = np.empty_like(want)
+        want_perm[order] = want
+        for wire, where in (("u8", "host"), ("u16", "host"), ("i32", "host"), ("u8", "device")):
+            monkeypatch.setattr(device, "WIRE", wire)
+            monkeypatch.setattr(device, "WIDEN_ON", where)
+            for chunk_bytes in (256 << 20, 4 * g * 1000, 4 * g * 333):
+                S = device.to_host_csr(counts, chunk_bytes=chunk_bytes)
+                assert sparse.isspmatrix_csr(S) and S.dtype == np.int32 and S.indices.dtype == np.int32 and S.has_sorted_indices
+                assert S.nnz == np.count_nonzero(want) and np.array_equal(S.toarray(), want), (name, wire, where, chunk_bytes)
+            S = device.to_host_csr(counts, chunk_bytes=4 * g * 777, row_order=order)
+            assert np.array_equal(S.toarray(), want_perm), (name, wire, where)
+
+
 def test_max_attempts_guard():
     from prosstt_amd import simulation as sim
     from prosstt_amd import tree as ptree

@@ -28,7 +28,6 @@ for wire in ("u8", "u16", "i32"):
     device.WIRE = wire
     for threads in (8, 16, 32):
         device.HOST_THREADS = threads
-        print("wire %s, %2d host threads: int64 %.1f ms   int32 %.1f ms" % (wire, threads, call("numpy"), call("numpy32")))
+        print("wire %s, %2d host threads: int64 %.1f ms   int32 %.1f ms   csr %.1f ms" % (wire, threads, call("numpy"), call("numpy32"), call("csr")))
 device.WIDEN_ON = "device"
-print("widened on the device / copied as it lies: int64 %.1f ms   int32 %.1f ms" % (call("numpy"), call("numpy32")))
-print("csr: %.1f ms" % call("csr"))
+print("widened on the device / copied as it lies: int64 %.1f ms   int32 %.1f ms   csr %.1f ms" % (call("numpy"), call("numpy32"), call("csr")))
