@@ -496,21 +496,44 @@ def _to_host_widened(counts, chunk_bytes, row_order, dtype, wire):
     arrived = [None, None]
     bounds = list(range(0, n, rows)) + [n]
     host_at = host.ctypes.data
-    exceptions = []                                     # a narrow wire: (positions in the host matrix, values) of what did not fit
+    # A narrow wire: what did not fit travels beside the chunk as (position in the host matrix, value) pairs -- up to one
+    # entry in 256 of the chunk, in fixed-size buffers, so that nothing on the way waits for the device (the number of
+    # exceptions of a chunk is read when the chunk has arrived; more than fit: the copy starts again with a wider wire).
+    exceptions = []
+    room = max(1, rows * g // 256)
+    if narrow:
+        exc_where = [torch.empty(room, dtype=torch.int64, device=dev) for _ in range(slots)]
+        exc_value = [torch.empty(room, dtype=torch.int32, device=dev) for _ in range(slots)]
+        exc_count = [torch.empty((), dtype=torch.int64, device=dev) for _ in range(slots)]
+        try:
+            h_where = [torch.empty(room, dtype=torch.int64, pin_memory=True) for _ in range(slots)]
+            h_value = [torch.empty(room, dtype=torch.int32, pin_memory=True) for _ in range(slots)]
+            h_count = [torch.empty((), dtype=torch.int64, pin_memory=True) for _ in range(slots)]
+        except RuntimeError as exc:
+            raise _NoBounceBuffers() from exc
 
-    def note_exceptions(block, lo):
-        """The entries of the chunk (int32, rows in host order from row ``lo``) with high bits set (synchronises the compute stream: their number)."""
-        where = torch.nonzero(torch.bitwise_and(block, high_bits).view(-1)).squeeze(1)
-        if int(where.numel()) * 256 > int(block.numel()):
-            copier.synchronize()                        # (nothing of this attempt is in flight when its buffers go back)
-            raise _WireTooNarrow()
-        if int(where.numel()):
-            exceptions.append(((where + lo * g).cpu(), block.reshape(-1).index_select(0, where).cpu()))
+    def note_exceptions(block, lo, slot):
+        """The entries of the chunk (int32, rows in host order from row ``lo``) with higher bits set, into the slot's buffers."""
+        flat = block.reshape(-1)
+        high = torch.bitwise_and(flat, high_bits)
+        exc_count[slot].copy_(torch.count_nonzero(high))
+        where = torch.nonzero_static(high, size=room, fill_value=0).squeeze(1)     # (padded with position 0: written with its own value)
+        torch.index_select(flat, 0, where, out=exc_value[slot])
+        torch.add(where, lo * g, out=exc_where[slot])
 
     def widen_chunk(i):
         lo, hi = bounds[i], bounds[i + 1]
-        arrived[i % slots].synchronize()
-        if widen(ctypes.c_void_p(bounce[i % slots].data_ptr()), ctypes.c_void_p(host_at + lo * g * dtype.itemsize),
+        slot = i % slots
+        arrived[slot].synchronize()
+        if narrow:
+            k = int(h_count[slot])
+            if k > room or k * 256 > (hi - lo) * g:
+                copier.synchronize()                    # (nothing of this attempt is in flight when its buffers go back)
+                torch.cuda.current_stream(dev).synchronize()
+                raise _WireTooNarrow()
+            if k:
+                exceptions.append((h_where[slot][:k].clone(), h_value[slot][:k].clone()))
+        if widen(ctypes.c_void_p(bounce[slot].data_ptr()), ctypes.c_void_p(host_at + lo * g * dtype.itemsize),
                  ctypes.c_uint64((hi - lo) * g), HOST_THREADS) != 0:
             raise RuntimeError("the host library refused its arguments")
 
@@ -526,19 +549,23 @@ def _to_host_widened(counts, chunk_bytes, row_order, dtype, wire):
             src = staged[slot][:hi - lo]
             if inv is None:
                 src.copy_(counts[lo:hi])                # the low bits
-                note_exceptions(counts[lo:hi], lo)
+                note_exceptions(counts[lo:hi], lo, slot)
             elif not narrow:
                 torch.index_select(counts, 0, inv[lo:hi], out=src)
             else:
                 torch.index_select(counts, 0, inv[lo:hi], out=gathered[:hi - lo])
                 src.copy_(gathered[:hi - lo])
-                note_exceptions(gathered[:hi - lo], lo)
+                note_exceptions(gathered[:hi - lo], lo, slot)
             ready = torch.cuda.Event()
             ready.record(compute)
             copier.wait_event(ready)
         # (the bounce buffer's previous chunk, i - 2, was widened in the last turn of this loop)
         with torch.cuda.stream(copier):
             bounce[slot][:hi - lo].copy_(src, non_blocking=True)
+            if narrow:
+                h_count[slot].copy_(exc_count[slot], non_blocking=True)
+                h_where[slot].copy_(exc_where[slot], non_blocking=True)
+                h_value[slot].copy_(exc_value[slot], non_blocking=True)
             arrived[slot] = torch.cuda.Event()
             arrived[slot].record(copier)
         if i >= 1:
