@@ -656,6 +656,22 @@ def to_host_csr(counts, chunk_bytes=256 << 20, row_order=None, _narrow=(True, Tr
     copied = [None, None]
     spans = [None, None]
     exceptions = []
+    # (the values above 255 of a chunk: in fixed-size buffers beside it, their number read when the chunk has arrived --
+    # as in ``_to_host_widened``; more than one in sixteen: 4-byte values after all)
+    room = max(1, cap // 16)
+    if narrow_vals:
+        exc_where = [torch.empty(room, dtype=torch.int64, device=dev) for _ in range(slots)]
+        exc_value = [torch.empty(room, dtype=torch.int32, device=dev) for _ in range(slots)]
+        exc_count = [torch.empty((), dtype=torch.int64, device=dev) for _ in range(slots)]
+        try:
+            h_where = [torch.empty(room, dtype=torch.int64, pin_memory=True) for _ in range(slots)]
+            h_value = [torch.empty(room, dtype=torch.int32, pin_memory=True) for _ in range(slots)]
+            h_count = [torch.empty((), dtype=torch.int64, pin_memory=True) for _ in range(slots)]
+        except RuntimeError:
+            return to_host_csr(counts, chunk_bytes, row_order, _narrow=(False, False))
+
+    class _LargeCounts(Exception):
+        pass
 
     def widen_chunk(slot):
         """The narrow halves of the chunk in ``slot``: wait for them, widen them into their place."""
@@ -665,6 +681,12 @@ def to_host_csr(counts, chunk_bytes=256 << 20, row_order=None, _narrow=(True, Tr
         spans[slot] = None
         copied[slot].synchronize()
         k = last - first
+        if narrow_vals:
+            n_big = int(h_count[slot])
+            if n_big > room or n_big * 16 > k:
+                raise _LargeCounts()
+            if n_big:
+                exceptions.append((h_where[slot][:n_big].clone(), h_value[slot][:n_big].clone()))
         if narrow_vals and lib.prosstt_amd_host_widen_u8_i32(ctypes.c_void_p(bounce_v[slot].data_ptr()), ctypes.c_void_p(data.data_ptr() + 4 * first),
                                                              ctypes.c_uint64(k), HOST_THREADS) != 0:
             raise RuntimeError("the host library refused its arguments")
@@ -672,51 +694,59 @@ def to_host_csr(counts, chunk_bytes=256 << 20, row_order=None, _narrow=(True, Tr
                                                               ctypes.c_uint64(k), HOST_THREADS) != 0:
             raise RuntimeError("the host library refused its arguments")
 
-    # pass 2
-    for i, (lo, hi) in enumerate(zip(bounds[:-1], bounds[1:])):
-        first, last = int(indptr[lo]), int(indptr[hi])
-        k = last - first
-        if k == 0:
-            continue
-        slot = i % slots
-        if copied[slot] is not None:
-            compute.wait_event(copied[slot])               # the staging pair's previous chunk has left
-        if inv is None:
-            block = counts[lo:hi]
-        else:
-            block = torch.index_select(counts, 0, inv[lo:hi], out=gathered[:hi - lo])
-        flat = block.reshape(-1)
-        where = torch.nonzero(flat).squeeze(1)             # ascending flat positions = CSR order (synchronises: its size)
-        if int(where.numel()) != k:
-            raise RuntimeError("the device matrix changed between the two passes of the sparse copy")
-        if narrow_vals:
-            torch.index_select(flat, 0, where, out=vals32[:k])
-            vals[slot][:k].copy_(vals32[:k])                # the low 8 bits
-            big = torch.nonzero(torch.bitwise_and(vals32[:k], -256)).squeeze(1)
-            if int(big.numel()) * 16 > k:                  # a matrix of large counts: 4-byte values after all
-                copier.synchronize()
-                return to_host_csr(counts, chunk_bytes, row_order, _narrow=(False, _narrow[1]))
-            if int(big.numel()):
-                exceptions.append(((big + first).cpu(), vals32[:k].index_select(0, big).cpu()))
-        else:
-            torch.index_select(flat, 0, where, out=vals[slot][:k])
-        cols[slot][:k].copy_(torch.remainder(where, g))
-        del where
-        widen_chunk(slot)                                  # (the bounce buffers' previous chunk, i - 2)
-        ready = torch.cuda.Event()
-        ready.record(compute)
-        copier.wait_event(ready)
-        with torch.cuda.stream(copier):
-            (bounce_v[slot][:k] if narrow_vals else data[first:last]).copy_(vals[slot][:k], non_blocking=True)
-            (bounce_c[slot][:k] if narrow_cols else indices[first:last]).copy_(cols[slot][:k], non_blocking=True)
-            copied[slot] = torch.cuda.Event()
-            copied[slot].record(copier)
-        spans[slot] = (first, last)
-        if slots == 2:
-            widen_chunk(slot ^ 1)                          # chunk i - 1, while chunk i is on the bus
-    copier.synchronize()
-    for slot in range(slots):
-        widen_chunk(slot)
+    # pass 2 (the number of non-zeros of every chunk is known from pass 1: torch.nonzero_static, no waiting for the device)
+    def pass_two():
+        for i, (lo, hi) in enumerate(zip(bounds[:-1], bounds[1:])):
+            first, last = int(indptr[lo]), int(indptr[hi])
+            k = last - first
+            if k == 0:
+                continue
+            slot = i % slots
+            if copied[slot] is not None:
+                compute.wait_event(copied[slot])               # the staging pair's previous chunk has left
+            if inv is None:
+                block = counts[lo:hi]
+            else:
+                block = torch.index_select(counts, 0, inv[lo:hi], out=gathered[:hi - lo])
+            flat = block.reshape(-1)
+            where = torch.nonzero_static(flat, size=k, fill_value=0).squeeze(1)     # ascending flat positions = CSR order
+            if narrow_vals:
+                torch.index_select(flat, 0, where, out=vals32[:k])
+                vals[slot][:k].copy_(vals32[:k])                # the low 8 bits
+                high = torch.bitwise_and(vals32[:k], -256)
+                exc_count[slot].copy_(torch.count_nonzero(high))
+                big = torch.nonzero_static(high, size=room, fill_value=0).squeeze(1)
+                torch.index_select(vals32[:k], 0, big, out=exc_value[slot])
+                torch.add(big, first, out=exc_where[slot])
+            else:
+                torch.index_select(flat, 0, where, out=vals[slot][:k])
+            cols[slot][:k].copy_(torch.remainder(where, g))
+            del where
+            widen_chunk(slot)                                  # (the bounce buffers' previous chunk, i - 2)
+            ready = torch.cuda.Event()
+            ready.record(compute)
+            copier.wait_event(ready)
+            with torch.cuda.stream(copier):
+                (bounce_v[slot][:k] if narrow_vals else data[first:last]).copy_(vals[slot][:k], non_blocking=True)
+                (bounce_c[slot][:k] if narrow_cols else indices[first:last]).copy_(cols[slot][:k], non_blocking=True)
+                if narrow_vals:
+                    h_count[slot].copy_(exc_count[slot], non_blocking=True)
+                    h_where[slot].copy_(exc_where[slot], non_blocking=True)
+                    h_value[slot].copy_(exc_value[slot], non_blocking=True)
+                copied[slot] = torch.cuda.Event()
+                copied[slot].record(copier)
+            spans[slot] = (first, last)
+            if slots == 2:
+                widen_chunk(slot ^ 1)                          # chunk i - 1, while chunk i is on the bus
+        copier.synchronize()
+        for slot in range(slots):
+            widen_chunk(slot)
+    try:
+        pass_two()
+    except _LargeCounts:                                   # a matrix of large counts: 4-byte values after all
+        copier.synchronize()
+        compute.synchronize()
+        return to_host_csr(counts, chunk_bytes, row_order, _narrow=(False, _narrow[1]))
     if exceptions:
         where = np.ascontiguousarray(torch.cat([e[0] for e in exceptions]).numpy())
         values = np.ascontiguousarray(torch.cat([e[1] for e in exceptions]).numpy())
