@@ -427,7 +427,7 @@ def to_host(counts, dtype=np.int64, chunk_bytes=256 << 20, row_order=None):
 # again with the next wider wire: "u16" (the low 16 bits), then "i32" (the int32 as it lies).  WIRE names the narrowest
 # wire that is tried.
 # (tools/host_widen_probe.py, tools/e2e_threads.py on an MI355X box's host: the pool writes 250 - 340 GB/s from eight threads
-# on; PCIe carries 52 GB/s.  C3 end to end: int64 147 -> 48 ms, int32 76 -> 44 ms.)
+# on; PCIe carries 52 GB/s.  C3 end to end: int64 147 -> 39 - 51 ms, int32 76 -> 32 - 39 ms, out="csr" 58 -> 38 ms.)
 WIDEN_ON = os.environ.get("PROSSTT_AMD_WIDEN", "host")
 WIRE = os.environ.get("PROSSTT_AMD_WIRE", "u8")
 WIRES = ("u8", "u16", "i32")
