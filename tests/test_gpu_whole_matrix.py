@@ -14,7 +14,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _whole_matrix_vs_model(name, n_cells, block, grouped=False):
+def _whole_matrix_vs_model(name, n_cells, block, grouped=False, seed=777):
     """grouped: the cells presented grouped by their row of the mean tensor, keyed by their position in the plan (what
     simulation.draw_counts does); everything below then runs on the matrix in that order."""
     import torch
@@ -29,12 +29,12 @@ def _whole_matrix_vs_model(name, n_cells, block, grouped=False):
     if grouped:
         cell = device.plan_order(rows, means.shape[0]).astype(np.int64)
         rows, sc = rows[cell], sc[cell]
-    X = ctx.sample_counts(means, rows, sc, work.alpha, work.beta, seed=777, cell_index=cell if grouped else None)
+    X = ctx.sample_counts(means, rows, sc, work.alpha, work.beta, seed=seed, cell_index=cell if grouped else None)
     host_means = means.cpu().numpy()
     differing = 0
     for lo in range(0, n_cells, block):
         sl = slice(lo, min(lo + block, n_cells))
-        want = nb_model.sample_counts(host_means, rows[sl], sc[sl], work.alpha, work.beta, 777, cell_index=cell[sl])
+        want = nb_model.sample_counts(host_means, rows[sl], sc[sl], work.alpha, work.beta, seed, cell_index=cell[sl])
         got = X[sl].cpu().numpy()
         differing += int((got != want).sum())
     assert differing == 0, "%d of %d counts differ from the model" % (differing, X.numel())
