@@ -6,6 +6,8 @@ call into libprosstt_amd.so.  Nothing here computes on the CPU.
 """
 import ctypes
 import os
+import sys
+import threading
 
 import numpy as np
 
@@ -431,8 +433,38 @@ def to_host(counts, dtype=np.int64, chunk_bytes=256 << 20, row_order=None):
 WIDEN_ON = os.environ.get("PROSSTT_AMD_WIDEN", "host")
 WIRE = os.environ.get("PROSSTT_AMD_WIRE", "u8")
 WIRES = ("u8", "u16", "i32")
-RESULT_MEMORY = os.environ.get("PROSSTT_AMD_RESULT_MEMORY", "pinned")
+RESULT_MEMORY = os.environ.get("PROSSTT_AMD_RESULT_MEMORY", "pageable")
 HOST_THREADS = int(os.environ.get("PROSSTT_AMD_HOST_THREADS", str(max(1, min(16, os.cpu_count() or 1)))))
+
+
+_result_blocks = []            # pageable result memory handed out before: [uint8 ndarray]; see _result_array
+_result_lock = threading.Lock()
+RESULT_CACHE_BYTES = int(os.environ.get("PROSSTT_AMD_RESULT_CACHE_BYTES", str(40 << 30)))
+
+
+def _result_array(shape, dtype):
+    """A pageable (n, g) result of the host-widened copy.  The memory is a numpy allocation (numpy asks for transparent
+    huge pages: the pool's first touch of 8 GB costs 45 ms instead of the 500 ms of 4 KB pages) that this module keeps a
+    reference to: once the caller has dropped the result and every view of it -- the block's reference count says so --
+    the next result of that size or less is laid over the same, already touched pages, as torch's caching host allocator
+    does for page-locked memory, without its 0.6 - 0.9 s of page-locking in front of the first 8 GB result."""
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    with _result_lock:
+        block = cached = None
+        for i in range(len(_result_blocks)):
+            cached = _result_blocks[i]
+            # (references: the list's, this variable's, getrefcount's own argument)
+            if cached.size >= nbytes and cached.size <= 2 * nbytes + (1 << 20) and sys.getrefcount(cached) == 3:
+                block = _result_blocks.pop(i)
+                break
+        del cached
+        if block is None:
+            block = np.empty(nbytes, dtype=np.uint8)
+        _result_blocks.append(block)
+        held = sum(b.size for b in _result_blocks)
+        while len(_result_blocks) > 1 and held > RESULT_CACHE_BYTES:
+            held -= _result_blocks.pop(0).size         # (the oldest; its memory goes when its last user does)
+    return block[:nbytes].view(dtype).reshape(shape)
 
 
 class _WireTooNarrow(Exception):
@@ -459,12 +491,11 @@ def _to_host_widened(counts, chunk_bytes, row_order, dtype, wire):
     widen = {("i32", 8): lib.prosstt_amd_host_widen_i32_i64, ("u16", 8): lib.prosstt_amd_host_widen_u16_i64,
              ("u16", 4): lib.prosstt_amd_host_widen_u16_i32, ("u8", 8): lib.prosstt_amd_host_widen_u8_i64,
              ("u8", 4): lib.prosstt_amd_host_widen_u8_i32}[(wire, dtype.itemsize)]
-    # The result is written by the host's threads, not by DMA: it needs no page-locking.  RESULT_MEMORY = "pinned" (default):
-    # from torch's caching host allocator -- 0.5 to 0.9 s to page-lock C3's 8 GB the first time a size is asked for, nothing
-    # afterwards (C3 end to end: first call of a process 560 - 960 ms, then 54 - 59 ms); "pageable": a fresh numpy array --
-    # numpy asks for transparent huge pages, so the pool's first touch costs 45 ms spread over its threads (a torch CPU tensor,
-    # 4 KB pages: 500 ms) -- every call, nothing up front (first call 240 - 470 ms, then 91 - 112 ms: the choice for a script
-    # that makes a handful of calls; tools/hugepage_probe.py, tools/first_call.py).
+    # The result is written by the host's threads, not by DMA: it needs no page-locking.  RESULT_MEMORY = "pageable"
+    # (default): numpy memory on transparent huge pages, recycled once the caller has dropped the result (_result_array) --
+    # C3 end to end: first call of a process 160 - 420 ms, then 40 - 50 ms; "pinned": from torch's caching host allocator --
+    # 0.5 to 0.9 s to page-lock C3's 8 GB the first time a size is asked for (first call 560 - 960 ms, then 54 - 80 ms;
+    # tools/hugepage_probe.py, tools/first_call.py).
     host = None
     if RESULT_MEMORY == "pinned" and n * g * dtype.itemsize <= PINNED_RETURN_MAX:
         try:
@@ -472,7 +503,7 @@ def _to_host_widened(counts, chunk_bytes, row_order, dtype, wire):
         except RuntimeError:
             host = None
     if host is None:
-        host = np.empty((n, g), dtype=dtype)
+        host = _result_array((n, g), dtype)
     rows = max(1, min(n, int(chunk_bytes) // (g * 4)))
     dev = counts.device
     compute = torch.cuda.current_stream(dev)

@@ -418,3 +418,44 @@ def test_plan_order_is_a_stable_grouping_by_row():
         assert np.array_equal(device.plan_order(roc, rows), np.argsort(roc, kind="stable"))
     with pytest.raises(_native.NativeError):
         device.plan_order(np.array([0, 9], np.int32), 9)
+
+
+def test_pageable_result_blocks_are_recycled_only_when_nobody_holds_them():
+    """device._result_array (the pageable results of the host-widened copy): a block is laid under a new result only
+    once the earlier result and every view of it -- numpy or torch -- are gone; a small result never takes a huge
+    block; the cache forgets its oldest blocks beyond its budget."""
+    import torch
+    from prosstt_amd import device
+    saved = list(device._result_blocks)
+    del device._result_blocks[:]
+    try:
+        a = device._result_array((300, 1000), np.int64)
+        b = device._result_array((300, 1000), np.int64)
+        pa, pb = a.ctypes.data, b.ctypes.data
+        assert pa != pb and a.flags.writeable and a.flags.c_contiguous and a.dtype == np.int64 and a.shape == (300, 1000)
+        view = a[5:9]
+        del a
+        c = device._result_array((300, 1000), np.int64)
+        assert c.ctypes.data not in (pa, pb)                     # the view still holds a's block
+        pc = c.ctypes.data
+        del view, c
+        d = device._result_array((280, 1000), np.int32)          # smaller, another type: laid over a freed block
+        assert d.ctypes.data in (pa, pc) and d.dtype == np.int32 and d.shape == (280, 1000)
+        pd = d.ctypes.data
+        t = torch.from_numpy(d)
+        del d
+        assert device._result_array((280, 1000), np.int32).ctypes.data != pd      # held through the tensor
+        del t
+        assert device._result_array((3, 3), np.int64).ctypes.data not in (pa, pb, pc)   # far smaller: its own block
+        held = sum(x.size for x in device._result_blocks)
+        assert held >= 2 * 300 * 1000 * 8
+        old = device.RESULT_CACHE_BYTES
+        device.RESULT_CACHE_BYTES = 1000
+        try:
+            device._result_array((3, 3), np.int64)
+            assert len(device._result_blocks) == 1
+        finally:
+            device.RESULT_CACHE_BYTES = old
+        assert np.array_equal(b, b)                              # (b is still the caller's: dropping it from the cache freed nothing)
+    finally:
+        device._result_blocks[:] = saved

@@ -1,6 +1,7 @@
 """What a one-shot script pays: the FIRST sample_density call of a process (C3, int64 ndarray) and the two after it, with the
-result in page-locked memory from torch's caching host allocator (the default) and in ordinary memory (a numpy array on
-transparent huge pages: PROSSTT_AMD_RESULT_MEMORY=pageable).  One box: pinned 564 / 54 / 59 ms; pageable 244 - 474 / 91 - 112 / 91 - 102 ms.  Usage: python3 tools/first_call.py"""
+result in ordinary memory (numpy blocks on transparent huge pages, recycled once the caller has dropped the result: the default) and
+in page-locked memory from torch's caching host allocator (PROSSTT_AMD_RESULT_MEMORY=pinned).  One box: pageable 159 - 423 / 47 - 51 / 40 - 42 ms;
+pinned 724 / 80 / 80 ms (other boxes: 564 - 958 / 54 / 59 ms).  Usage: python3 tools/first_call.py"""
 import sys
 import time
 
