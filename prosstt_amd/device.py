@@ -653,7 +653,11 @@ def to_host_csr(counts, chunk_bytes=256 << 20, row_order=None, _narrow=(True, Tr
     bounds = list(range(0, n, rows)) + [n]
     cap = max(int(indptr[b] - indptr[a]) for a, b in zip(bounds[:-1], bounds[1:]))
 
-    def host_array():
+    def host_array(written_by_the_host):
+        """A result array as a torch tensor: page-locked when DMA lands in it (or RESULT_MEMORY says so), else over a
+        recycled pageable block (_result_array)."""
+        if written_by_the_host and RESULT_MEMORY != "pinned":
+            return torch.from_numpy(_result_array((total,), np.int32))
         if 0 < total * 4 <= PINNED_RETURN_MAX:
             try:
                 return torch.empty(total, dtype=torch.int32, pin_memory=True)
@@ -661,7 +665,6 @@ def to_host_csr(counts, chunk_bytes=256 << 20, row_order=None, _narrow=(True, Tr
                 pass
         return torch.empty(total, dtype=torch.int32)
 
-    data, indices = host_array(), host_array()
     compute = torch.cuda.current_stream(dev)
     copier = torch.cuda.Stream(dev)
     slots = 2 if len(bounds) > 2 else 1
@@ -674,6 +677,7 @@ def to_host_csr(counts, chunk_bytes=256 << 20, row_order=None, _narrow=(True, Tr
     narrow_vals = _narrow[0] and WIDEN_ON == "host" and WIRE == "u8" and total >= (1 << 22)
     narrow_cols = _narrow[1] and WIDEN_ON == "host" and WIRE in ("u8", "u16") and total >= (1 << 22) and g <= 65536
     lib = _native.load_host() if (narrow_vals or narrow_cols) else None
+    data, indices = host_array(narrow_vals), host_array(narrow_cols)
     t_vals = torch.uint8 if narrow_vals else torch.int32
     t_cols = torch.int16 if narrow_cols else torch.int32
     vals = [torch.empty(max(cap, 1), dtype=t_vals, device=dev) for _ in range(slots)]
