@@ -467,6 +467,13 @@ def _result_array(shape, dtype):
     return block[:nbytes].view(dtype).reshape(shape)
 
 
+def release_result_memory():
+    """Forget the recycled result blocks (PROSSTT_AMD_RESULT_CACHE_BYTES bounds what is kept: 40 GiB): the memory of the
+    ones nobody holds goes back to the system at once, the others' when their last user drops them."""
+    with _result_lock:
+        del _result_blocks[:]
+
+
 class _WireTooNarrow(Exception):
     """Too many entries of a chunk do not fit the wire: the copy starts again with the next wider one."""
 

@@ -457,5 +457,8 @@ def test_pageable_result_blocks_are_recycled_only_when_nobody_holds_them():
         finally:
             device.RESULT_CACHE_BYTES = old
         assert np.array_equal(b, b)                              # (b is still the caller's: dropping it from the cache freed nothing)
+        device._result_array((50, 50), np.int64)
+        device.release_result_memory()
+        assert device._result_blocks == []
     finally:
         device._result_blocks[:] = saved
