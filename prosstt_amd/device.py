@@ -322,19 +322,19 @@ HOST_DTYPES = {"numpy": np.int64, "numpy32": np.int32, "numpy16": np.uint16}
 
 def to_host(counts, dtype=np.int64, chunk_bytes=256 << 20, row_order=None):
     """int32 device counts -> host ndarray of ``dtype``: int64 (the reference's return type,
-    simulation.py:651), int32 (what the device holds: half the bytes over PCIe) or uint16 (a quarter; raises
-    OverflowError if a count does not fit -- counts of scRNA-seq simulations are far below 65 536).
+    simulation.py:651), int32 (what the device holds) or uint16 (raises OverflowError if a count does not fit: C3's
+    largest is 84 036).
 
-    The matrix travels a chunk of rows at a time by asynchronous copies on a second stream into page-locked
-    host memory from torch's caching host allocator -- the array that is returned -- whenever it is at most
-    PROSSTT_AMD_PINNED_MAX_BYTES (default 32 GiB): DMA straight into the result, no bounce buffers and no
-    first-touch page faults; the block goes back to the allocator's cache when the caller drops the array, so
-    the pinning cost is paid once per size.  Larger results (or a failed page-lock) take the same chunked path
-    into ordinary memory.  uint16 is narrowed on the device, chunk by chunk (two staging buffers), under the transfer of
-    the previous chunk.  int64 and int32 of 2^24 counts or more cross PCIe in a narrower wire format -- their low 8 (or 16) bits,
-    and the few entries with higher bits set beside them (``WIRE``), or the int32 as it lies -- and are widened by the host library's threads under the transfer
-    of the next chunk (``_to_host_widened``; ``WIDEN_ON`` = "device", or a smaller matrix: int64 is formed on the device
-    like uint16 is narrowed and 8 bytes per count cross PCIe, int32 is copied as it lies).
+    int64 and int32 of 2^24 counts or more (``_to_host_widened``): the matrix travels a chunk of rows at a time by
+    asynchronous copies on a second stream, in a WIRE format -- the low 8 (or 16) bits of every count, the few entries with
+    higher bits set beside them as (position, value) pairs, or the int32 as it lies (``WIRE``) -- into two page-locked
+    bounce buffers, and the host library's threads widen chunk i - 1 into the result while chunk i is on the bus; the
+    result lies in pageable memory on huge pages that is recycled once the caller has dropped it (``RESULT_MEMORY``,
+    ``_result_array``).  Everything else -- uint16, smaller matrices, ``WIDEN_ON`` = "device" -- as until round 5: the
+    chunks land by DMA straight in a page-locked result from torch's caching host allocator (at most
+    PROSSTT_AMD_PINNED_MAX_BYTES, default 32 GiB; beyond that, or when page-locking fails, in ordinary memory); int64 is
+    formed and uint16 narrowed on the device, chunk by chunk (two staging buffers) under the transfer of the previous chunk,
+    int32 is copied as it lies.
 
     row_order: the device matrix holds its cells in an order of PRESENTATION (``plan_order``): row i is cell
     ``row_order[i]``.  The host array comes back in plan order -- row ``row_order[i]`` = device row i -- the rows of every
