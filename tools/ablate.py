@@ -120,6 +120,18 @@ VARIANTS = {
     "bail24": [("constexpr int kBail = 6;", "constexpr int kBail = 24;")],
     "bail32": [("constexpr int kBail = 6;", "constexpr int kBail = 32;")],
     "strip128": [("    g.strip_cells = k3::kStripCells / 2;", "    g.strip_cells = k3::kStripCells;")],
+    # small problems (C2): a fixed strip length instead of halving down to 8 (real variants: any strip length is correct)
+    "smallstrip10": [("    while (g.strip_cells > 8 && ((n + g.strip_cells - 1) / g.strip_cells) * g.tiles_g < 4 * 5 * 1024) g.strip_cells /= 2;",
+                     "    if (((n + g.strip_cells - 1) / g.strip_cells) * g.tiles_g < 4 * 5 * 1024) g.strip_cells = 10;")],
+    "smallstrip12": [("    while (g.strip_cells > 8 && ((n + g.strip_cells - 1) / g.strip_cells) * g.tiles_g < 4 * 5 * 1024) g.strip_cells /= 2;",
+                     "    if (((n + g.strip_cells - 1) / g.strip_cells) * g.tiles_g < 4 * 5 * 1024) g.strip_cells = 12;")],
+    "smallstrip16": [("    while (g.strip_cells > 8 && ((n + g.strip_cells - 1) / g.strip_cells) * g.tiles_g < 4 * 5 * 1024) g.strip_cells /= 2;",
+                     "    if (((n + g.strip_cells - 1) / g.strip_cells) * g.tiles_g < 4 * 5 * 1024) g.strip_cells = 16;")],
+    "smallstrip20": [("    while (g.strip_cells > 8 && ((n + g.strip_cells - 1) / g.strip_cells) * g.tiles_g < 4 * 5 * 1024) g.strip_cells /= 2;",
+                     "    if (((n + g.strip_cells - 1) / g.strip_cells) * g.tiles_g < 4 * 5 * 1024) g.strip_cells = 20;")],
+    "smallstrip32": [("    while (g.strip_cells > 8 && ((n + g.strip_cells - 1) / g.strip_cells) * g.tiles_g < 4 * 5 * 1024) g.strip_cells /= 2;",
+                     "    if (((n + g.strip_cells - 1) / g.strip_cells) * g.tiles_g < 4 * 5 * 1024) g.strip_cells = 32;")],
+
     "strip32": [("    g.strip_cells = k3::kStripCells / 2;", "    g.strip_cells = k3::kStripCells / 4;")],
     # plain instead of non-temporal row stores
     "plainstore": [(STORE_2, "            __builtin_amdgcn_raw_buffer_store_b128(row4, out_rsrc, store_voff, flush_off, 0);")],
